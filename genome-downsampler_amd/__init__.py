@@ -1,0 +1,277 @@
+"""ctypes binding of the MI355X quasi-MCP solver (C ABI: include/qmcp_hip.h).
+
+The directory name has a hyphen, so import it with
+``importlib.import_module("genome-downsampler_amd")`` (the repo root on sys.path) or through
+``__graft_entry__.load_package()``.
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing it raises at
+import, and without a GPU every solver call raises :class:`QmcpError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_LIB_PATH = os.path.join(LIB_DIR, "libqmcp_hip.so")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libqmcp_host.so")
+
+# every symbol include/qmcp_hip.h declares
+ABI_SYMBOLS = (
+    "qmcp_hip_abi_version", "qmcp_hip_last_error", "qmcp_hip_device_count", "qmcp_hip_create",
+    "qmcp_hip_destroy", "qmcp_hip_solve_host", "qmcp_hip_solve_device", "qmcp_hip_coverage_host",
+    "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
+    "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host",
+)
+
+QMCP_OK = 0
+PATH_UNIFORM, PATH_GENERAL = 1, 2
+KIND_UNIFORM, KIND_LOW_BOTH_SIDES, KIND_HOLE, KIND_ZERO_BOTH_SIDES = 0, 1, 2, 3
+
+
+class QmcpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"qmcp_hip error {code}: {message}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64), ("n_kept", C.c_uint64), ("total_length", C.c_uint64),
+        ("n_contigs", C.c_uint32), ("path", C.c_uint32), ("min_span", C.c_uint32),
+        ("max_span", C.c_uint32), ("sort_passes", C.c_uint32), ("reserved0", C.c_uint32),
+        ("ms_total", C.c_float), ("ms_prepare", C.c_float), ("ms_scan", C.c_float),
+        ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_mark", C.c_float),
+        ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+if not os.path.exists(HIP_LIB_PATH):
+    raise ImportError(
+        f"{HIP_LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
+        "this package has no CPU fallback")
+
+_hip = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
+_host = C.CDLL(HOST_LIB_PATH) if os.path.exists(HOST_LIB_PATH) else None
+
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_hip.qmcp_hip_last_error.restype = C.c_char_p
+_hip.qmcp_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+_hip.qmcp_hip_destroy.argtypes = [C.c_void_p]
+_hip.qmcp_hip_destroy.restype = None
+_hip.qmcp_hip_solve_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
+                                     C.c_uint32, C.c_uint32, _u64p, C.POINTER(Stats)]
+_hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
+                                       C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                       C.POINTER(Stats)]
+_hip.qmcp_hip_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
+                                        C.c_uint32, _u32p]
+_hip.qmcp_hip_filtered_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
+                                                 C.c_uint32, _u64p, _u32p]
+_hip.qmcp_hip_complete_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+_hip.qmcp_hip_complete_pairs_host.argtypes = [C.c_void_p, _u64p, C.c_uint64]
+_hip.qmcp_hip_amplicon_filter_host.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, _u32p, C.c_uint64,
+                                               _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               _u64p]
+if _host is not None:
+    _host.qmcp_host_reads_gen.argtypes = [C.c_uint32, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
+                                          _u32p, _u32p, _u32p]
+    _host.qmcp_host_reads_gen_aos.argtypes = _host.qmcp_host_reads_gen.argtypes
+    _host.qmcp_host_solver_names.argtypes = [C.c_char_p, C.c_size_t]
+    _host.qmcp_host_solve.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                      C.c_int, _u64p]
+    _host.qmcp_host_solve.restype = C.c_int64
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p) if a is not None else None
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p) if a is not None else None
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _check(rc):
+    if rc != QMCP_OK:
+        raise QmcpError(rc, _hip.qmcp_hip_last_error().decode())
+
+
+def abi_version():
+    return _hip.qmcp_hip_abi_version()
+
+
+def device_count():
+    return _hip.qmcp_hip_device_count()
+
+
+def exported_symbols():
+    return [s for s in ABI_SYMBOLS if hasattr(_hip, s)]
+
+
+def mask_words(n_reads):
+    return (int(n_reads) + 63) // 64
+
+
+def mask_to_indices(mask, n_reads):
+    """ascending kept ReadIndex list == the reference's Solution vector"""
+    bits = np.unpackbits(np.ascontiguousarray(mask).view(np.uint8), bitorder="little")[:n_reads]
+    return np.flatnonzero(bits).astype(np.uint64)
+
+
+def indices_to_mask(indices, n_reads):
+    bits = np.zeros(mask_words(n_reads) * 64, dtype=np.uint8)
+    bits[np.asarray(indices, dtype=np.int64)] = 1
+    return np.packbits(bits, bitorder="little").view(np.uint64).copy()
+
+
+def _contig_tables(n_reads, contig_read_offsets, contig_lengths):
+    if contig_read_offsets is None:
+        lengths = np.atleast_1d(np.asarray(contig_lengths, dtype=np.uint32))
+        assert lengths.size == 1, "contig_read_offsets required for several contigs"
+        offs = np.array([0, n_reads], dtype=np.uint64)
+    else:
+        offs = np.ascontiguousarray(contig_read_offsets, dtype=np.uint64)
+        lengths = np.ascontiguousarray(contig_lengths, dtype=np.uint32)
+    return offs, lengths
+
+
+class Solver:
+    """One solver context == one reference solver instance (created once, solved many times)."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        _check(_hip.qmcp_hip_create(int(device), C.byref(self._ctx)))
+        self.device = device
+        self.last_stats = None
+
+    def close(self):
+        if self._ctx:
+            _hip.qmcp_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def solve(self, starts, ends, contig_lengths, max_coverage, contig_read_offsets=None):
+        """host arrays in, host keep bitmask (np.uint64 words) out"""
+        starts, ends = _u32(starts), _u32(ends)
+        n = starts.size
+        offs, lengths = _contig_tables(n, contig_read_offsets, contig_lengths)
+        mask = np.zeros(max(mask_words(n), 1), dtype=np.uint64)
+        st = Stats()
+        _check(_hip.qmcp_hip_solve_host(self._ctx, _p32(starts), _p32(ends), n, _p64(offs),
+                                        _p32(lengths), lengths.size, int(max_coverage), _p64(mask),
+                                        C.byref(st)))
+        self.last_stats = st
+        return mask[:mask_words(n)]
+
+    def solve_device(self, d_starts, d_ends, n_reads, contig_lengths, max_coverage, d_mask,
+                     contig_read_offsets=None, stream=0):
+        """device pointers (ints) in; the mask is written to d_mask (device pointer)"""
+        offs, lengths = _contig_tables(n_reads, contig_read_offsets, contig_lengths)
+        st = Stats()
+        _check(_hip.qmcp_hip_solve_device(self._ctx, C.c_void_p(d_starts), C.c_void_p(d_ends),
+                                          int(n_reads), _p64(offs), _p32(lengths), lengths.size,
+                                          int(max_coverage), C.c_void_p(d_mask),
+                                          C.c_void_p(stream), C.byref(st)))
+        self.last_stats = st
+        return st
+
+    def coverage(self, starts, ends, contig_lengths, contig_read_offsets=None, keep_mask=None):
+        starts, ends = _u32(starts), _u32(ends)
+        n = starts.size
+        offs, lengths = _contig_tables(n, contig_read_offsets, contig_lengths)
+        cov = np.zeros(max(int(lengths.sum()), 1), dtype=np.uint32)
+        if keep_mask is None:
+            _check(_hip.qmcp_hip_coverage_host(self._ctx, _p32(starts), _p32(ends), n, _p64(offs),
+                                               _p32(lengths), lengths.size, _p32(cov)))
+        else:
+            km = np.ascontiguousarray(keep_mask, dtype=np.uint64)
+            _check(_hip.qmcp_hip_filtered_coverage_host(self._ctx, _p32(starts), _p32(ends), n,
+                                                        _p64(offs), _p32(lengths), lengths.size,
+                                                        _p64(km), _p32(cov)))
+        return cov[:int(lengths.sum())]
+
+    def complete_pairs(self, mask, n_reads):
+        out = np.ascontiguousarray(mask, dtype=np.uint64).copy()
+        _check(_hip.qmcp_hip_complete_pairs_host(self._ctx, _p64(out), int(n_reads)))
+        return out
+
+    def complete_pairs_device(self, d_mask, n_reads, stream=0):
+        _check(_hip.qmcp_hip_complete_pairs_device(self._ctx, C.c_void_p(d_mask), int(n_reads),
+                                                   C.c_void_p(stream)))
+
+    def amplicon_filter(self, starts, ends, amp_starts, amp_ends, seq_lengths=None, qualities=None,
+                        min_length=0, min_mapq=0):
+        starts, ends = _u32(starts), _u32(ends)
+        a0, a1 = _u32(amp_starts), _u32(amp_ends)
+        sl = _u32(seq_lengths) if seq_lengths is not None else None
+        q = _u32(qualities) if qualities is not None else None
+        n = starts.size
+        out = np.zeros(max(mask_words(n // 2), 1), dtype=np.uint64)
+        _check(_hip.qmcp_hip_amplicon_filter_host(self._ctx, _p32(starts), _p32(ends), _p32(sl),
+                                                  _p32(q), n, _p32(a0), _p32(a1), a0.size,
+                                                  int(min_length), int(min_mapq), _p64(out)))
+        return out[:mask_words(n // 2)]
+
+
+# ---------------------------------------------------------------- host mirror (libqmcp_host.so)
+def _need_host():
+    if _host is None:
+        raise ImportError(f"{HOST_LIB_PATH} is missing: build it with `make lib`")
+
+
+def reads_gen(kind, pairs, genome_length, read_length=150, seed=12345, with_qualities=False,
+              aos=False):
+    """reads-gen restatement (libs/reads-gen): returns (starts, ends[, qualities]) as uint32"""
+    _need_host()
+    n = 2 * int(pairs)
+    s = np.empty(n, dtype=np.uint32)
+    e = np.empty(n, dtype=np.uint32)
+    q = np.empty(n, dtype=np.uint32) if with_qualities else None
+    fn = _host.qmcp_host_reads_gen_aos if aos else _host.qmcp_host_reads_gen
+    rc = fn(int(seed), int(kind), int(pairs), int(genome_length), int(read_length), _p32(s), _p32(e),
+            _p32(q))
+    if rc != 0:
+        raise ValueError(f"reads_gen failed ({rc})")
+    return (s, e, q) if with_qualities else (s, e)
+
+
+def solver_names():
+    _need_host()
+    buf = C.create_string_buffer(4096)
+    n = _host.qmcp_host_solver_names(buf, len(buf))
+    if n < 0:
+        raise RuntimeError("solver name buffer too small")
+    return [x for x in buf.value.decode().split("\n") if x]
+
+
+def host_solve(solver_name, starts, ends, ref_genome_length, max_coverage, with_pairs=False):
+    """SolverManager::get(name).solve(M, BamApi) through the C++ adapter; ascending ReadIndex"""
+    _need_host()
+    starts, ends = _u32(starts), _u32(ends)
+    kept = np.empty(max(starts.size, 1), dtype=np.uint64)
+    n = _host.qmcp_host_solve(solver_name.encode(), _p32(starts), _p32(ends), starts.size,
+                              int(ref_genome_length), int(max_coverage), int(bool(with_pairs)),
+                              _p64(kept))
+    if n < 0:
+        raise KeyError(solver_name)
+    return kept[:n].copy()

@@ -1,0 +1,578 @@
+// qmcp_api.hip -- context, device arena and stage orchestration behind include/qmcp_hip.h.
+//
+// Stage order of one solve (all on the context's stream):
+//   prepare   validate, span min/max, global start keys, reads-per-start counts
+//   scan      exclusive scan of the counts -> bucket offsets boff (and eoff on the mixed path)
+//   sort      LSD radix bucketing of read indices by (start[, span desc]), stable in index
+//   sweep     selection: block-parallel shortest-path sweep (uniform span) or the
+//             event-driven priority sweep (mixed spans); one wave per contig
+//   mark      keep bitmask from per-bucket selected prefixes
+// One host round trip (12 bytes) after `prepare` picks the path and the radix width.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "qmcp_hip.h"
+#include "qmcp_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(_e == hipErrorOutOfMemory ? QMCP_ENOMEM : QMCP_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                 \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+enum Ev { EV_BEGIN = 0, EV_PREP, EV_SCAN, EV_SORT, EV_SWEEP, EV_MARK, EV_COUNT };
+
+}  // namespace
+
+struct qmcp_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    hipEvent_t ev_in = nullptr;
+    // arena (grow-only, reused across solves like a reference solver instance's members)
+    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist;
+    DevBuf keys[2], vals[2];
+    DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp;
+    DevBuf scalars;  // popcount + sweep iteration counters
+    uint32_t last_iters = 0, last_blocks = 0;
+};
+
+namespace {
+
+int ensure(qmcp_hip_ctx* c, DevBuf& b, size_t bytes) {
+    (void)c;
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return QMCP_OK;
+    if (b.p) {
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIP_TRY(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return QMCP_OK;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != QMCP_OK) return _rc; \
+    } while (0)
+
+uint32_t bit_width(uint32_t v) { return v == 0 ? 0u : 32u - (uint32_t)__builtin_clz(v); }
+
+struct Problem {
+    uint64_t n = 0;
+    uint32_t n_contigs = 0;
+    uint64_t ltot = 0;
+    std::vector<uint64_t> poff;
+};
+
+int check_problem(const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n,
+                  Problem& pr) {
+    if (!roff || !lengths || n_contigs == 0) return fail(QMCP_EINVAL, "contig tables missing or n_contigs == 0");
+    if (roff[0] != 0 || roff[n_contigs] != n)
+        return fail(QMCP_EINVAL, "contig_read_offsets must start at 0 and end at n_reads");
+    pr.poff.assign((size_t)n_contigs + 1, 0);
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        if (roff[c + 1] < roff[c]) return fail(QMCP_EINVAL, "contig_read_offsets not monotone at %u", c);
+        pr.poff[c + 1] = pr.poff[c] + lengths[c];
+    }
+    pr.n = n;
+    pr.n_contigs = n_contigs;
+    pr.ltot = pr.poff[n_contigs];
+    if (n > (1ull << 30)) return fail(QMCP_ERANGE, "n_reads %llu exceeds 2^30 per call", (unsigned long long)n);
+    if (pr.ltot > (1ull << 31) - 2)
+        return fail(QMCP_ERANGE, "total contig length %llu exceeds 2^31-2", (unsigned long long)pr.ltot);
+    return QMCP_OK;
+}
+
+int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
+    const size_t bytes = ((size_t)pr.n_contigs + 1) * sizeof(uint64_t);
+    TRY(ensure(c, c->roff, bytes));
+    TRY(ensure(c, c->poff, bytes));
+    HIP_TRY(hipMemcpyAsync(c->roff.p, roff, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->poff.p, pr.poff.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    // the host vectors must outlive the copies
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+// prepare + host round trip.  Leaves gstart in keys[0] (as u32) when want_keys.
+int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                const Problem& pr, const uint64_t* d_keep_mask, bool want_keys,
+                uint32_t host_stats[3]) {
+    const uint32_t n = (uint32_t)pr.n;
+    TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
+    TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
+    if (want_keys) TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
+    const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->cstart.p, 0, ((size_t)pr.ltot + 1) * sizeof(uint32_t), c->stream));
+    qmcp::launch_prepare(c->stream, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
+                         (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
+                         want_keys ? (uint32_t*)c->keys[0].p : nullptr, (uint32_t*)c->cstart.p,
+                         (uint32_t*)c->stats.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (host_stats[2] != 0)
+        return fail(QMCP_EREAD, "a read has start > end or end >= its contig length");
+    return QMCP_OK;
+}
+
+int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
+    TRY(ensure(c, out, ((size_t)ltot + 1) * sizeof(uint32_t)));
+    TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(ltot) * sizeof(uint32_t) + 16));
+    qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)counts.p, ltot, (uint32_t*)out.p,
+                                (uint32_t*)c->spine.p, true);
+    HIP_TRY(hipGetLastError());
+    return QMCP_OK;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                    const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
+                    uint32_t M, uint64_t* d_mask, qmcp_hip_stats* st) {
+    Problem pr;
+    TRY(check_problem(roff, lengths, n_contigs, n64, pr));
+    const uint32_t n = (uint32_t)pr.n;
+    const uint32_t ltot = (uint32_t)pr.ltot;
+    const size_t mask_words = (size_t)((n64 + 63) / 64);
+    qmcp_hip_stats local;
+    std::memset(&local, 0, sizeof(local));
+    local.n_reads = n64;
+    local.n_contigs = n_contigs;
+    local.total_length = pr.ltot;
+    if (mask_words) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
+    if (n == 0 || ltot == 0) {
+        if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (st) *st = local;
+        return QMCP_OK;
+    }
+    // size the whole arena before anything is enqueued (growing a buffer frees it, and
+    // hipFree would stall on the work in flight)
+    {
+        const uint32_t tiles = qmcp::sort_tiles(n);
+        const uint32_t spine_a = qmcp::scan_spine_entries(256u * tiles);
+        const uint32_t spine_b = qmcp::scan_spine_entries(ltot);
+        TRY(ensure(c, c->spine, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
+        TRY(ensure(c, c->hist, (size_t)256 * tiles * sizeof(uint32_t)));
+        TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
+        TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
+        TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
+        TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
+        TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->scalars, 64));
+        TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
+    TRY(upload_tables(c, roff, pr));
+
+    uint32_t hs[3];
+    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, hs));
+    HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
+    const uint32_t min_span = hs[0], max_span = hs[1];
+    local.min_span = min_span;
+    local.max_span = max_span;
+    const bool uniform = (min_span == max_span) && max_span <= qmcp::kMaxUniformSpan;
+    if (!uniform && max_span > qmcp::kMaxGeneralSpan)
+        return fail(QMCP_ERANGE, "mixed-span reads with span %u > %u are not supported by this build",
+                    max_span, qmcp::kMaxGeneralSpan);
+    local.path = uniform ? QMCP_PATH_UNIFORM : QMCP_PATH_GENERAL;
+
+    // bucket offsets
+    TRY(scan_counts(c, c->cstart, c->boff, ltot));
+
+    // bucketing keys
+    const uint32_t pos_bits = bit_width(ltot - 1) == 0 ? 1u : bit_width(ltot - 1);
+    uint32_t span_bits = 0;
+    bool wide = false;
+    if (!uniform) {
+        span_bits = bit_width(max_span - min_span);
+        wide = pos_bits + span_bits > 32;
+        TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
+        // gstart sits in keys[0]; composite keys go to keys[1]
+        qmcp::launch_general_keys(c->stream, wide, (const uint32_t*)c->keys[0].p, d_starts, d_ends, n,
+                                  span_bits, max_span, nullptr, c->keys[1].p, (uint32_t*)c->ecnt.p);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
+
+    // radix bucketing
+    const uint32_t key_bits = pos_bits + span_bits;
+    const uint32_t passes = (key_bits + 7) / 8;
+    local.sort_passes = passes;
+    const uint32_t n_tiles = qmcp::sort_tiles(n);
+    TRY(ensure(c, c->hist, (size_t)256 * n_tiles * sizeof(uint32_t)));
+    TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(256u * n_tiles) * sizeof(uint32_t) + 16));
+    TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(ltot) * sizeof(uint32_t) + 16));
+    TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
+    TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
+    TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
+    TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
+    int kin = uniform ? 0 : 1;  // buffer holding the unsorted keys
+    int vin = 0;
+    const uint32_t* vals_in = nullptr;  // first pass: payload is the read index itself
+    for (uint32_t p = 0; p < passes; ++p) {
+        const int kout = kin ^ 1, vout = (vals_in == nullptr) ? 0 : (vin ^ 1);
+        qmcp::launch_radix_pass(c->stream, wide, c->keys[kin].p, vals_in, n, 8 * p, c->keys[kout].p,
+                                (uint32_t*)c->vals[vout].p, (uint32_t*)c->hist.p,
+                                (uint32_t*)c->spine.p);
+        HIP_TRY(hipGetLastError());
+        kin = kout;
+        vin = vout;
+        vals_in = (const uint32_t*)c->vals[vin].p;
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_SORT], c->stream));
+
+    // selection sweep
+    TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
+    TRY(ensure(c, c->scalars, 64));
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
+    uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
+    if (uniform) {
+        if (!qmcp::launch_sweep_uniform(c->stream, (const uint32_t*)c->boff.p,
+                                        (const uint64_t*)c->poff.p, n_contigs, max_span, M,
+                                        (uint32_t*)c->selend.p, d_iters))
+            return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
+    } else {
+        uint32_t ring = 64;
+        while (ring <= max_span) ring <<= 1;
+        qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
+                                   (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                   (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
+                                   (uint32_t*)c->selend.p, ring);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], c->stream));
+
+    // keep mask
+    qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n, span_bits,
+                      (const uint32_t*)c->selend.p, d_mask);
+    HIP_TRY(hipGetLastError());
+    qmcp::launch_popcount(c->stream, d_mask, (uint32_t)mask_words, (unsigned long long*)c->scalars.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
+    unsigned long long host_scalars[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(host_scalars, c->scalars.p, sizeof(host_scalars), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    local.n_kept = host_scalars[0];
+    c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
+    c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
+    local.reserved0 = c->last_iters;
+    local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
+    local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
+    local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);
+    local.ms_sweep = elapsed(c->ev[EV_SORT], c->ev[EV_SWEEP]);
+    local.ms_mark = elapsed(c->ev[EV_SWEEP], c->ev[EV_MARK]);
+    local.ms_total = elapsed(c->ev[EV_BEGIN], c->ev[EV_MARK]);
+    if (st) *st = local;
+    return QMCP_OK;
+}
+
+int use_device(qmcp_hip_ctx* c) {
+    if (!c) return fail(QMCP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return QMCP_OK;
+}
+
+// Order the solver stream after the caller's producer stream (NULL = the default stream:
+// the solver stream is non-blocking, so even that needs an explicit edge).
+int order_after(qmcp_hip_ctx* c, void* user_stream) {
+    if ((hipStream_t)user_stream != c->stream) {
+        HIP_TRY(hipEventRecord(c->ev_in, (hipStream_t)user_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    }
+    return QMCP_OK;
+}
+
+int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends, uint64_t n64,
+                    const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs,
+                    const uint64_t* keep_mask, uint32_t* cov_out) {
+    TRY(use_device(c));
+    if (!cov_out || (n64 && (!starts || !ends))) return fail(QMCP_EINVAL, "null buffer");
+    Problem pr;
+    TRY(check_problem(roff, lengths, n_contigs, n64, pr));
+    const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot;
+    if (ltot == 0) return n ? fail(QMCP_EREAD, "reads given for zero-length contigs") : QMCP_OK;
+    if (n == 0) { std::memset(cov_out, 0, (size_t)ltot * sizeof(uint32_t)); return QMCP_OK; }
+    TRY(ensure(c, c->in_starts, (size_t)n * 4));
+    TRY(ensure(c, c->in_ends, (size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(c->in_starts.p, starts, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->in_ends.p, ends, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    const uint64_t* d_keep = nullptr;
+    if (keep_mask) {
+        const size_t words = (size_t)((n64 + 63) / 64);
+        TRY(ensure(c, c->mask, words * 8));
+        HIP_TRY(hipMemcpyAsync(c->mask.p, keep_mask, words * 8, hipMemcpyHostToDevice, c->stream));
+        d_keep = (const uint64_t*)c->mask.p;
+    }
+    TRY(upload_tables(c, roff, pr));
+    uint32_t hs[3];
+    TRY(run_prepare(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, pr, d_keep,
+                    true, hs));
+    TRY(scan_counts(c, c->cstart, c->boff, ltot));
+    TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
+    qmcp::launch_general_keys(c->stream, false, (const uint32_t*)c->keys[0].p,
+                              (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, n, 0,
+                              hs[1], d_keep, nullptr, (uint32_t*)c->ecnt.p);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
+    TRY(ensure(c, c->cov, (size_t)ltot * sizeof(uint32_t)));
+    qmcp::launch_coverage(c->stream, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p, ltot,
+                          (uint32_t*)c->cov.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(cov_out, c->cov.p, (size_t)ltot * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qmcp_hip_abi_version(void) { return QMCP_HIP_ABI_VERSION; }
+
+const char* qmcp_hip_last_error(void) { return g_err; }
+
+int qmcp_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx) {
+    if (!out_ctx) return fail(QMCP_EINVAL, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(QMCP_ENODEVICE, "no HIP device available (quasi-mcp-hip has no CPU fallback)");
+    }
+    if (device < 0 || device >= n) return fail(QMCP_ENODEVICE, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    qmcp_hip_ctx* c = new (std::nothrow) qmcp_hip_ctx();
+    if (!c) return fail(QMCP_ENOMEM, "host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < EV_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        qmcp_hip_destroy(c);
+        return fail(QMCP_EHIP, "context setup: %s", hipGetErrorString(e));
+    }
+    *out_ctx = c;
+    return QMCP_OK;
+}
+
+void qmcp_hip_destroy(qmcp_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
+                      &c->selend, &c->spine, &c->hist, &c->keys[0], &c->keys[1], &c->vals[0],
+                      &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
+                      &c->cov, &c->amp, &c->scalars};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int qmcp_hip_solve_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                          uint64_t n_reads, const uint64_t* contig_read_offsets,
+                          const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t max_coverage,
+                          uint64_t* d_keep_mask_out, void* hip_stream, qmcp_hip_stats* stats) {
+    TRY(use_device(c));
+    if (n_reads && (!d_starts || !d_ends || !d_keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    TRY(order_after(c, hip_stream));
+    return solve_on_device(c, d_starts, d_ends, contig_read_offsets, contig_lengths, n_contigs,
+                           n_reads, max_coverage, d_keep_mask_out, stats);
+}
+
+int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
+                        uint64_t n_reads, const uint64_t* contig_read_offsets,
+                        const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t max_coverage,
+                        uint64_t* keep_mask_out, qmcp_hip_stats* stats) {
+    TRY(use_device(c));
+    if (n_reads && (!starts || !ends || !keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    if (n_reads > (1ull << 30)) return fail(QMCP_ERANGE, "n_reads exceeds 2^30 per call");
+    const size_t nb = (size_t)n_reads * sizeof(uint32_t);
+    const size_t words = (size_t)((n_reads + 63) / 64);
+    TRY(ensure(c, c->in_starts, nb));
+    TRY(ensure(c, c->in_ends, nb));
+    TRY(ensure(c, c->mask, words * sizeof(uint64_t)));
+    hipEvent_t t0, t1, t2, t3;
+    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventCreate(&t2)); HIP_TRY(hipEventCreate(&t3));
+    int rc = QMCP_OK;
+    do {
+        if (hipEventRecord(t0, c->stream) != hipSuccess) { rc = fail(QMCP_EHIP, "event record"); break; }
+        if (nb) {
+            if (hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+        }
+        (void)hipEventRecord(t1, c->stream);
+        rc = solve_on_device(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p,
+                             contig_read_offsets, contig_lengths, n_contigs, n_reads, max_coverage,
+                             (uint64_t*)c->mask.p, stats);
+        if (rc != QMCP_OK) break;
+        (void)hipEventRecord(t2, c->stream);
+        if (words) {
+            if (hipMemcpyAsync(keep_mask_out, c->mask.p, words * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+                rc = fail(QMCP_EHIP, "D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+        }
+        (void)hipEventRecord(t3, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(QMCP_EHIP, "stream sync failed"); break; }
+        if (stats) {
+            stats->ms_h2d = elapsed(t0, t1);
+            stats->ms_d2h = elapsed(t2, t3);
+        }
+    } while (0);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    (void)hipEventDestroy(t2); (void)hipEventDestroy(t3);
+    return rc;
+}
+
+int qmcp_hip_coverage_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
+                           uint64_t n_reads, const uint64_t* contig_read_offsets,
+                           const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t* cov_out) {
+    return coverage_common(c, starts, ends, n_reads, contig_read_offsets, contig_lengths, n_contigs,
+                           nullptr, cov_out);
+}
+
+int qmcp_hip_filtered_coverage_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
+                                    uint64_t n_reads, const uint64_t* contig_read_offsets,
+                                    const uint32_t* contig_lengths, uint32_t n_contigs,
+                                    const uint64_t* keep_mask, uint32_t* cov_out) {
+    if (!keep_mask && n_reads) return fail(QMCP_EINVAL, "keep_mask is null");
+    return coverage_common(c, starts, ends, n_reads, contig_read_offsets, contig_lengths, n_contigs,
+                           keep_mask, cov_out);
+}
+
+int qmcp_hip_complete_pairs_device(qmcp_hip_ctx* c, uint64_t* d_keep_mask, uint64_t n_reads,
+                                   void* hip_stream) {
+    TRY(use_device(c));
+    const uint64_t words = (n_reads + 63) / 64;
+    if (words == 0) return QMCP_OK;
+    if (!d_keep_mask) return fail(QMCP_EINVAL, "null mask");
+    if (words > 0xFFFFFFFFull) return fail(QMCP_ERANGE, "mask too large");
+    TRY(order_after(c, hip_stream));
+    qmcp::launch_complete_pairs(c->stream, d_keep_mask, (uint32_t)words, n_reads);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+int qmcp_hip_complete_pairs_host(qmcp_hip_ctx* c, uint64_t* keep_mask, uint64_t n_reads) {
+    TRY(use_device(c));
+    const size_t words = (size_t)((n_reads + 63) / 64);
+    if (words == 0) return QMCP_OK;
+    if (!keep_mask) return fail(QMCP_EINVAL, "null mask");
+    TRY(ensure(c, c->mask, words * 8));
+    HIP_TRY(hipMemcpyAsync(c->mask.p, keep_mask, words * 8, hipMemcpyHostToDevice, c->stream));
+    qmcp::launch_complete_pairs(c->stream, (uint64_t*)c->mask.p, (uint32_t)words, n_reads);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(keep_mask, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+int qmcp_hip_amplicon_filter_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
+                                  const uint32_t* seq_lengths, const uint32_t* qualities,
+                                  uint64_t n_reads, const uint32_t* amp_starts,
+                                  const uint32_t* amp_ends, uint32_t n_amplicons,
+                                  uint32_t min_length, uint32_t min_mapq, uint64_t* pair_keep_out) {
+    TRY(use_device(c));
+    const uint64_t n_pairs = n_reads / 2;
+    const size_t words = (size_t)((n_pairs + 63) / 64);
+    if (words == 0) return QMCP_OK;
+    if (!starts || !ends || !pair_keep_out || (n_amplicons && (!amp_starts || !amp_ends)))
+        return fail(QMCP_EINVAL, "null buffer");
+    const size_t nb = (size_t)n_reads * 4;
+    TRY(ensure(c, c->in_starts, nb));
+    TRY(ensure(c, c->in_ends, nb));
+    HIP_TRY(hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream));
+    const uint32_t* d_len = nullptr;
+    const uint32_t* d_q = nullptr;
+    if (seq_lengths) {
+        TRY(ensure(c, c->in_aux0, nb));
+        HIP_TRY(hipMemcpyAsync(c->in_aux0.p, seq_lengths, nb, hipMemcpyHostToDevice, c->stream));
+        d_len = (const uint32_t*)c->in_aux0.p;
+    }
+    if (qualities) {
+        TRY(ensure(c, c->in_aux1, nb));
+        HIP_TRY(hipMemcpyAsync(c->in_aux1.p, qualities, nb, hipMemcpyHostToDevice, c->stream));
+        d_q = (const uint32_t*)c->in_aux1.p;
+    }
+    TRY(ensure(c, c->amp, (size_t)2 * (n_amplicons + 1) * 4));
+    uint32_t* d_as = (uint32_t*)c->amp.p;
+    uint32_t* d_ae = d_as + n_amplicons + 1;
+    if (n_amplicons) {
+        HIP_TRY(hipMemcpyAsync(d_as, amp_starts, (size_t)n_amplicons * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_ae, amp_ends, (size_t)n_amplicons * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(ensure(c, c->mask, words * 8));
+    qmcp::launch_amplicon_filter(c->stream, (const uint32_t*)c->in_starts.p,
+                                 (const uint32_t*)c->in_ends.p, d_len, d_q, n_pairs, d_as, d_ae,
+                                 n_amplicons, min_length, min_mapq, (uint64_t*)c->mask.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pair_keep_out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Launchers of the gfx950 kernels in qmcp_kernels.hip (internal to the library; the public
+// surface is include/qmcp_hip.h).
+#ifndef QMCP_KERNELS_H
+#define QMCP_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qmcp {
+
+static constexpr uint32_t kMaxGeneralSpan = 16383;  // two LDS rings of 16384 u32 = 128 KiB
+static constexpr uint32_t kMaxUniformSpan = 512;    // 8 positions per lane in the block sweep
+
+void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
+                    const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
+                    const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
+                    uint32_t* stats);
+void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
+                         const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
+                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt);
+uint32_t scan_spine_entries(uint32_t n);
+void launch_exclusive_scan(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out,
+                           uint32_t* spine, bool write_total);
+uint32_t sort_tiles(uint32_t n);
+void launch_radix_pass(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
+                       uint32_t n, uint32_t shift, void* keys_out, uint32_t* vals_out,
+                       uint32_t* hist, uint32_t* spine);
+bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t* selend,
+                          uint32_t* iter_stats);
+void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
+                          const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
+                          uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
+                          uint32_t ring_size);
+void launch_mark(hipStream_t st, bool wide, const void* skeys, const uint32_t* svals, uint32_t n,
+                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask);
+void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
+                     unsigned long long* out);
+void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
+                     uint32_t* cov);
+void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads);
+void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
+                            const uint32_t* seq_lengths, const uint32_t* qualities,
+                            uint64_t n_pairs, const uint32_t* amp_starts, const uint32_t* amp_ends,
+                            uint32_t n_amp, uint32_t min_length, uint32_t min_mapq,
+                            uint64_t* pair_keep);
+
+}  // namespace qmcp
+#endif

@@ -1,0 +1,884 @@
+// qmcp_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the quasi-MCP solver path.
+//
+// Everything here is integer scatter / scan / selection: HBM- or latency-bound, no MFMA.
+// wave = 64 lanes throughout.  The path these kernels replace is the reference's
+//   coverage build        quasi_mcp_cpu_max_flow_solver.cpp:58-73 (O(N*len) per-base loop)
+//   max-flow + readout    quasi_mcp_cpu_max_flow_solver.cpp:19-20,89-100
+//   (CUDA equivalent      quasi_mcp_cuda_max_flow_solver.cu:12-79,319-435)
+// with the canonical selection rule stated in oracle/qmcp_oracle.c.
+//
+// Coordinates: contigs are concatenated into one global axis; gpos = pos_offset[c] + pos,
+// Ltot = sum of contig lengths.  Reads never cross a contig, so per-position prefix counts
+// taken over the global axis cancel exactly at contig borders.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmcp_kernels.h"
+
+namespace qmcp {
+
+static constexpr int kWave = 64;
+static constexpr uint32_t kInf = 0x7FFFFFFFu;  // "no constraint"; real counts stay < 2^30
+
+// ------------------------------------------------------------------ wave primitives
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t w = (uint64_t)__shfl_xor((long long)v, o, kWave);
+        v = v > w ? v : w;
+    }
+    return v;
+}
+
+// DPP-based wave64 inclusive scans (row_shr within 16-lane rows, then row_bcast:15 / :31).
+// `id` is the identity the shifted-in lanes see.
+#define QMCP_DPP(old, src, ctrl, rmask) \
+    (uint32_t) __builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xF, false)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
+    v += QMCP_DPP(0u, v, 0x111, 0xF);
+    v += QMCP_DPP(0u, v, 0x112, 0xF);
+    v += QMCP_DPP(0u, v, 0x114, 0xF);
+    v += QMCP_DPP(0u, v, 0x118, 0xF);
+    v += QMCP_DPP(0u, v, 0x142, 0xA);
+    v += QMCP_DPP(0u, v, 0x143, 0xC);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_min(uint32_t v) {
+    v = min(v, QMCP_DPP(kInf, v, 0x111, 0xF));
+    v = min(v, QMCP_DPP(kInf, v, 0x112, 0xF));
+    v = min(v, QMCP_DPP(kInf, v, 0x114, 0xF));
+    v = min(v, QMCP_DPP(kInf, v, 0x118, 0xF));
+    v = min(v, QMCP_DPP(kInf, v, 0x142, 0xA));
+    v = min(v, QMCP_DPP(kInf, v, 0x143, 0xC));
+    return v;
+}
+// value of lane-1 (lane 0 gets `id`)
+__device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v, uint32_t id) {
+    uint32_t r = (uint32_t)__shfl_up((int)v, 1, kWave);
+    return (threadIdx.x & 63) == 0 ? id : r;
+}
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return min(a + b, kInf); }
+
+// Inclusive scan of "x -> min(x + c, b)" maps under composition (apply lower lanes first):
+// (c1,b1) then (c2,b2) = (c1 + c2, min(b1 + c2, b2)).
+__device__ __forceinline__ void wave_incl_scan_affine(uint32_t& c, uint32_t& b) {
+#define QMCP_STEP(ctrl, rmask)                                   \
+    {                                                            \
+        uint32_t pc = QMCP_DPP(0u, c, ctrl, rmask);              \
+        uint32_t pb = QMCP_DPP(kInf, b, ctrl, rmask);            \
+        b = min(sat_add(pb, c), b);                              \
+        c = c + pc;                                              \
+    }
+    QMCP_STEP(0x111, 0xF)
+    QMCP_STEP(0x112, 0xF)
+    QMCP_STEP(0x114, 0xF)
+    QMCP_STEP(0x118, 0xF)
+    QMCP_STEP(0x142, 0xA)
+    QMCP_STEP(0x143, 0xC)
+#undef QMCP_STEP
+}
+
+// ------------------------------------------------------------------ prepare
+// One pass over the reads: validate (start <= end < contig length), reduce min/max span,
+// write the global start position of every read (the bucketing key of the uniform path) and
+// count reads per start position.  Reference counterpart: the read loop of
+// create_b_function (quasi_mcp_cpu_max_flow_solver.cpp:61-67) -- here O(1) per read.
+//
+// stats[0] = min span, stats[1] = max span, stats[2] = error flag
+__global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ starts,
+                                                 const uint32_t* __restrict__ ends, uint32_t n,
+                                                 const uint64_t* __restrict__ contig_read_off,
+                                                 const uint64_t* __restrict__ contig_pos_off,
+                                                 uint32_t n_contigs,
+                                                 const uint64_t* __restrict__ keep_mask,
+                                                 uint32_t* __restrict__ gstart_out,
+                                                 uint32_t* __restrict__ cstart,
+                                                 uint32_t* __restrict__ stats) {
+    __shared__ uint64_t s_roff[65];
+    __shared__ uint64_t s_poff[65];
+    const uint32_t nc = min(n_contigs, 64u);
+    for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
+        s_roff[i] = contig_read_off[i];
+        s_poff[i] = contig_pos_off[i];
+    }
+    __syncthreads();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t s = starts[i], e = ends[i];
+        uint32_t c = 0;
+        if (n_contigs > 1) {
+            if (n_contigs <= 64) {
+                uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (s_roff[mid] <= i) lo = mid; else hi = mid;
+                }
+                c = lo;
+            } else {
+                uint32_t lo = 0, hi = n_contigs;
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+                }
+                c = lo;
+            }
+        }
+        uint64_t p0, p1;
+        if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
+        else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
+        const uint32_t len_c = (uint32_t)(p1 - p0);
+        if (s > e || e >= len_c) { bad = 1; if (gstart_out) gstart_out[i] = 0; continue; }
+        const uint32_t span = e - s + 1;
+        mn = min(mn, span);
+        mx = max(mx, span);
+        const uint32_t gs = (uint32_t)p0 + s;
+        if (gstart_out) gstart_out[i] = gs;
+        if (cstart) {
+            bool on = true;
+            if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
+            if (on) atomicAdd(&cstart[gs], 1u);
+        }
+    }
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    bad = wave_max_u32(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (mn != 0xFFFFFFFFu) atomicMin(&stats[0], mn);
+        if (mx != 0) atomicMax(&stats[1], mx);
+        if (bad) atomicOr(&stats[2], 1u);
+    }
+}
+
+// Mixed-span path: per-position end counts and the composite bucketing key
+// (gstart << span_bits) | (max_span - span): ascending key == (start asc, end desc).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_general_keys(const uint32_t* __restrict__ gstart,
+                                                      const uint32_t* __restrict__ starts,
+                                                      const uint32_t* __restrict__ ends,
+                                                      uint32_t n, uint32_t span_bits,
+                                                      uint32_t max_span,
+                                                      const uint64_t* __restrict__ keep_mask,
+                                                      KeyT* __restrict__ keys,
+                                                      uint32_t* __restrict__ ecnt) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t span = ends[i] - starts[i] + 1;
+        const uint32_t gs = gstart[i];
+        if (keys) keys[i] = ((KeyT)gs << span_bits) | (KeyT)(max_span - span);
+        if (ecnt) {
+            bool on = true;
+            if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
+            if (on) atomicAdd(&ecnt[gs + span - 1], 1u);
+        }
+    }
+}
+template __global__ void k_general_keys<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                  uint32_t, uint32_t, uint32_t, const uint64_t*,
+                                                  uint32_t*, uint32_t*);
+template __global__ void k_general_keys<uint64_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                  uint32_t, uint32_t, uint32_t, const uint64_t*,
+                                                  uint64_t*, uint32_t*);
+
+// ------------------------------------------------------------------ exclusive scan (u32)
+// Three launches: tile sums -> spine scan (one workgroup) -> tile scan with carried offset.
+// out may alias in.  out has n+1 entries when write_total is set (out[n] = grand total).
+static constexpr int kScanThreads = 256;
+static constexpr int kScanItems = 16;
+static constexpr int kScanTile = kScanThreads * kScanItems;  // 4096
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wave,
+                                                        uint32_t& block_total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan_add(v);
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = s_wave[k];
+        if (k < w) base += x;
+        tot += x;
+    }
+    block_total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t* __restrict__ in,
+                                                                  uint32_t n,
+                                                                  uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k * kScanThreads + threadIdx.x;
+        if (i < n) acc += in[i];
+    }
+    acc = wave_sum_u32(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// single workgroup, exclusive in place; spine[n_tiles] = total
+__global__ __launch_bounds__(kScanThreads) void k_scan_spine(uint32_t* __restrict__ spine,
+                                                              uint32_t n_tiles) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_tiles ? spine[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_256(v, s_wave, tot);
+        if (i < n_tiles) spine[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) spine[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint32_t* __restrict__ in,
+                                                              uint32_t n,
+                                                              const uint32_t* __restrict__ spine,
+                                                              uint32_t* __restrict__ out,
+                                                              int write_total) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        v[k] = i < n ? in[i] : 0;
+        sum += v[k];
+    }
+    uint32_t tot;
+    uint32_t run = spine[blockIdx.x] + block_excl_scan_256(sum, s_wave, tot);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+    if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = spine[gridDim.x];
+}
+
+// ------------------------------------------------------------------ LSD radix sort, 8-bit digits
+// Stable, keys + u32 payload.  Tile = 256 threads x 16 keys; wave w of a tile owns a
+// contiguous 1024-key slice and walks it 64 keys at a time, so tile order == memory order.
+static constexpr int kSortThreads = 256;
+static constexpr int kSortItems = 16;
+static constexpr int kSortTile = kSortThreads * kSortItems;  // 4096
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const KeyT* __restrict__ keys,
+                                                              uint32_t n, uint32_t shift,
+                                                              uint32_t n_tiles,
+                                                              uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t i = base + k * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];  // digit-major
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __restrict__ keys_in,
+                                                                 const uint32_t* __restrict__ vals_in,
+                                                                 uint32_t n, uint32_t shift,
+                                                                 uint32_t n_tiles,
+                                                                 const uint32_t* __restrict__ offs,
+                                                                 KeyT* __restrict__ keys_out,
+                                                                 uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_cnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t wbase = blockIdx.x * kSortTile + w * (kSortItems * 64);
+    KeyT key[kSortItems];
+    uint32_t rank[kSortItems];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : (KeyT)0;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+        // lanes holding the same digit (invalid lanes form their own group)
+        uint64_t peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t in_group = __popcll(peers & lt_mask);
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = s_cnt[w][d];
+            s_cnt[w][d] = old + __popcll(peers);
+        }
+        old = (uint32_t)__shfl((int)old, leader, kWave);
+        rank[k] = old + in_group;
+    }
+    __syncthreads();
+    {
+        // digit = threadIdx.x: turn per-wave counts into absolute output bases
+        const uint32_t d = threadIdx.x;
+        uint32_t run = offs[d * n_tiles + blockIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const uint32_t c = s_cnt[ww][d];
+            s_cnt[ww][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+            const uint32_t dst = s_cnt[w][d] + rank[k];
+            keys_out[dst] = key[k];
+            vals_out[dst] = vals_in ? vals_in[i] : i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ uniform-span sweep
+// All reads of the call have span `ell`.  With W(p) = #dropped reads with start <= p the
+// canonical greedy (oracle/qmcp_oracle.c) is the pointwise-maximal W under
+//     0 <= W(p) - W(p-1) <= c(p)          c(p)  = reads starting at p
+//     W(p) - W(p-ell) <= ex(p)            ex(p) = cov(p) - min(cov(p), M)
+// i.e. single-source shortest paths on a line graph with edges p-1 -> p (c(p)),
+// p-ell -> p (ex(p)) and p -> p-1 (0).  Distances obey
+//     d(p) = min( d(p-1) + c(p),  min_{j in [p-ell, p-1]} ( d(j) + ex(j+ell) ) )
+// Positions are processed in blocks of `ell`; the window minimum splits into a suffix
+// minimum over the previous block (held in registers, same lane/slot) and a prefix minimum
+// inside the block, resolved by a short fixed-point iteration of wave-wide scans.
+// Selected count at p: S(p) = c(p) - (d(p) - d(p-1)); the kept reads of a start position are
+// its S(p) lowest read indices (all ends are equal, so the rule's tie-break is the index).
+//
+// One wave per contig; local index i = lane * E + r, valid while i < ell.
+template <int E>
+__global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict__ boff,
+                                                      const uint64_t* __restrict__ contig_pos_off,
+                                                      uint32_t ell, uint32_t M,
+                                                      uint32_t* __restrict__ selend,
+                                                      uint32_t* __restrict__ iter_stats) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    if (L == 0) return;
+    const uint32_t n_blocks = (L + ell - 1) / ell;
+
+    uint32_t sufA[E];  // suffix-min of the previous block's h, aligned with this block's slots
+    // virtual block -1: d == 0 and the jump from j = i - ell lands on p = i
+    {
+        uint32_t hv[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            hv[r] = kInf;
+            if (i < ell && i < L) {
+                const uint32_t cov = boff[base + i + 1] - boff[base];
+                hv[r] = cov > M ? cov - M : 0u;
+            }
+        }
+        uint32_t run = kInf;
+#pragma unroll
+        for (int r = E - 1; r >= 0; --r) { run = min(run, hv[r]); hv[r] = run; }
+        // suffix over lanes: reverse, inclusive scan, reverse, then make it exclusive
+        uint32_t rev = (uint32_t)__shfl((int)run, 63 - (int)lane, kWave);
+        rev = wave_incl_scan_min(rev);
+        uint32_t after = (uint32_t)__shfl((int)rev, 63 - (int)lane - 1 < 0 ? 0 : 63 - (int)lane - 1, kWave);
+        if (lane == 63) after = kInf;
+#pragma unroll
+        for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
+    }
+    uint32_t d_last = 0;
+    uint32_t total_iters = 0;
+
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t a = b * ell;
+        uint32_t cnt[E], exj[E], x0[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            const uint32_t p = a + i;
+            cnt[r] = 0; exj[r] = kInf; x0[r] = 0;
+            if (i < ell && p < L) {
+                const uint32_t v0 = boff[base + p];
+                const uint32_t v1 = boff[base + p + 1];
+                x0[r] = v0;
+                cnt[r] = v1 - v0;
+                const uint32_t t = p + ell;  // landing position of the jump from p
+                if (t < L) {
+                    const uint32_t cov = boff[base + t + 1] - v1;
+                    exj[r] = cov > M ? cov - M : 0u;
+                }
+            }
+        }
+        uint32_t intra[E], d[E], h[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) intra[r] = kInf;
+        uint32_t d_in = 0;
+        for (;;) {
+            ++total_iters;
+            // compose the lane's maps, scan across lanes, then replay inside the lane
+            uint32_t cs = 0, bs = kInf;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t bb = min(sufA[r], intra[r]);
+                bs = min(sat_add(bs, cnt[r]), bb);
+                cs += cnt[r];
+            }
+            uint32_t sc = cs, sb = bs;
+            wave_incl_scan_affine(sc, sb);
+            uint32_t pc = wave_shift_up1(sc, 0u);
+            uint32_t pb = wave_shift_up1(sb, kInf);
+            uint32_t x = min(sat_add(d_last, pc), pb);
+            d_in = x;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t bb = min(sufA[r], intra[r]);
+                x = min(sat_add(x, cnt[r]), bb);
+                d[r] = x;
+                h[r] = exj[r] >= kInf ? kInf : sat_add(x, exj[r]);
+            }
+            // exclusive prefix-min of h over the block
+            uint32_t lmin = kInf;
+#pragma unroll
+            for (int r = 0; r < E; ++r) lmin = min(lmin, h[r]);
+            uint32_t before = wave_shift_up1(wave_incl_scan_min(lmin), kInf);
+            bool changed = false;
+            uint32_t run = before;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t old_eff = min(sufA[r], intra[r]);
+                const uint32_t new_eff = min(sufA[r], run);
+                changed |= (new_eff != old_eff);
+                intra[r] = run;
+                run = min(run, h[r]);
+            }
+            if (!__any(changed)) break;
+        }
+        // emit selected counts, carry state to the next block
+        uint32_t prev = d_in;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            const uint32_t p = a + i;
+            if (i < ell && p < L) selend[base + p] = x0[r] + (cnt[r] - (d[r] - prev));
+            prev = d[r];
+        }
+        // d at local index ell-1
+        {
+            const uint32_t li = ell - 1;
+            const uint32_t src_lane = li / E, src_r = li % E;
+            uint32_t pick = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) if ((uint32_t)r == src_r) pick = d[r];
+            d_last = (uint32_t)__shfl((int)pick, (int)src_lane, kWave);
+        }
+        {
+            uint32_t run = kInf;
+            uint32_t hv[E];
+#pragma unroll
+            for (int r = E - 1; r >= 0; --r) { run = min(run, h[r]); hv[r] = run; }
+            uint32_t rev = (uint32_t)__shfl((int)run, 63 - (int)lane, kWave);
+            rev = wave_incl_scan_min(rev);
+            uint32_t after = (uint32_t)__shfl((int)rev, lane == 63 ? 0 : 62 - (int)lane, kWave);
+            if (lane == 63) after = kInf;
+#pragma unroll
+            for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
+        }
+    }
+    if (iter_stats && lane == 0) {
+        atomicAdd(&iter_stats[0], total_iters);
+        atomicAdd(&iter_stats[1], n_blocks);
+    }
+}
+
+// ------------------------------------------------------------------ general (mixed-span) sweep
+// Event-driven form of the canonical rule for arbitrary spans.  Reads are bucketed by start
+// and ordered (end desc, index asc) inside a bucket, so the selected reads of a bucket are
+// always a prefix; the pool of candidates at position p is the set of bucket heads of the
+// last max_span start positions, compared by (end desc, start desc).
+// One wave per contig.  Two rings of `ring_size` (power of two > max_span) entries live in
+// LDS: the prefix pointer of every bucket still inside the window, and the number of
+// selected reads by end position (what stops covering when the sweep passes that end).
+// A bucket's pointer is flushed to selend (as an absolute offset) when its slot is recycled.
+template <typename KeyT>
+__global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict__ boff,
+                                                      const uint32_t* __restrict__ eoff,
+                                                      const KeyT* __restrict__ skeys,
+                                                      const uint64_t* __restrict__ contig_pos_off,
+                                                      uint32_t span_bits, uint32_t max_span,
+                                                      uint32_t M, uint32_t* __restrict__ selend,
+                                                      uint32_t ring_size) {
+    extern __shared__ uint32_t s_ring[];
+    uint32_t* s_ptr = s_ring;              // [ring_size] bucket prefix pointers
+    uint32_t* s_exp = s_ring + ring_size;  // [ring_size] selected reads by end position
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    const uint32_t rmask = ring_size - 1;
+    const KeyT code_mask = (((KeyT)1) << span_bits) - 1;
+    for (uint32_t i = lane; i < 2 * ring_size; i += 64) s_ring[i] = 0;
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t p = 0; p < L; ++p) {
+        const uint32_t gp = base + p;
+        if (lane == 0) {
+            if (p >= ring_size) {
+                const uint32_t q = p - ring_size;  // long dead: ring_size > max_span
+                selend[base + q] = boff[base + q] + s_ptr[p & rmask];
+            }
+            s_ptr[p & rmask] = 0;
+        }
+        __syncthreads();
+        const uint32_t cov = boff[gp + 1] - eoff[gp];
+        const uint32_t need = min(cov, M);
+        uint32_t k = need > cur ? need - cur : 0u;
+        while (k > 0) {
+            // best head among buckets q in (p - max_span, p]
+            uint64_t best = 0;
+            for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
+                const uint32_t q = p - t;
+                const uint32_t gq = base + q;
+                const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
+                const uint32_t ptr = s_ptr[q & rmask];
+                if (b0 + ptr < b1) {
+                    const KeyT key = skeys[b0 + ptr];
+                    const uint32_t span = max_span - (uint32_t)(key & code_mask);
+                    const uint32_t end = q + span - 1;
+                    if (end >= p) {
+                        const uint64_t pri = ((uint64_t)(end + 1) << 32) | (uint64_t)(q + 1);
+                        best = pri > best ? pri : best;
+                    }
+                }
+            }
+            best = wave_max_u64(best);
+            // need <= cov guarantees a candidate; guard anyway so the loop always ends
+            if (best == 0) break;
+            const uint32_t bend = (uint32_t)(best >> 32) - 1;
+            const uint32_t bq = (uint32_t)(best & 0xFFFFFFFFu) - 1;
+            const uint32_t gq = base + bq;
+            const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
+            const uint32_t ptr = s_ptr[bq & rmask];
+            // length of the run of equal-end reads at the head of the winning bucket (<= 64)
+            bool same = false;
+            const uint32_t j = b0 + ptr + lane;
+            if (j < b1) {
+                const KeyT key = skeys[j];
+                const uint32_t span = max_span - (uint32_t)(key & code_mask);
+                same = (bq + span - 1) == bend;
+            }
+            const uint64_t ball = __ballot(same);
+            const uint32_t run = (~ball == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~ball) - 1);
+            const uint32_t take = min(k, run);
+            __syncthreads();
+            if (lane == 0) {
+                s_ptr[bq & rmask] = ptr + take;
+                s_exp[bend & rmask] += take;
+            }
+            __syncthreads();
+            cur += take;
+            k -= take;
+        }
+        // reads ending at p stop covering p+1
+        const uint32_t ex = s_exp[p & rmask];
+        cur -= ex;
+        __syncthreads();
+        if (lane == 0) s_exp[p & rmask] = 0;
+    }
+    __syncthreads();
+    // flush the buckets still in the ring
+    const uint32_t first = L > ring_size ? L - ring_size : 0u;
+    for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + s_ptr[q & rmask];
+}
+template __global__ void k_sweep_general<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                   const uint64_t*, uint32_t, uint32_t, uint32_t,
+                                                   uint32_t*, uint32_t);
+template __global__ void k_sweep_general<uint64_t>(const uint32_t*, const uint32_t*, const uint64_t*,
+                                                   const uint64_t*, uint32_t, uint32_t, uint32_t,
+                                                   uint32_t*, uint32_t);
+
+// ------------------------------------------------------------------ keep-mask emission
+// sorted entry j (bucket = its start position) is kept iff j < selend[bucket].
+// obtain_sequence counterpart (quasi_mcp_cpu_max_flow_solver.cpp:89-100).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_mark(const KeyT* __restrict__ skeys,
+                                              const uint32_t* __restrict__ svals, uint32_t n,
+                                              uint32_t span_bits,
+                                              const uint32_t* __restrict__ selend,
+                                              uint32_t* __restrict__ mask32) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t q = (uint32_t)(skeys[j] >> span_bits);
+        if (j < selend[q]) {
+            const uint32_t idx = svals[j];
+            atomicOr(&mask32[idx >> 5], 1u << (idx & 31));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_popcount(const uint64_t* __restrict__ mask,
+                                                  uint32_t n_words,
+                                                  unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        acc += __popcll(mask[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o, kWave);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+// cov[p] = #reads started at or before p - #reads ended before p
+// (what BamApi::find_input_cover builds with per-base increments, bam_api.cpp:275-286)
+__global__ __launch_bounds__(256) void k_coverage(const uint32_t* __restrict__ boff,
+                                                  const uint32_t* __restrict__ eoff,
+                                                  uint32_t ltot, uint32_t* __restrict__ cov) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < ltot; p += stride)
+        cov[p] = boff[p + 1] - eoff[p];
+}
+
+// ------------------------------------------------------------------ "next" rows
+// BamApi::find_pairs on the bitmask (bam_api.cpp:239-273): mates are (2q, 2q+1).
+__global__ __launch_bounds__(256) void k_complete_pairs(uint64_t* __restrict__ mask,
+                                                        uint32_t n_words, uint64_t n_reads) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint64_t even = 0x5555555555555555ull;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        uint64_t m = mask[w];
+        m |= ((m & even) << 1) | ((m >> 1) & even);
+        // an unpaired trailing read (odd n_reads) has no mate: never set bits past n_reads
+        const uint64_t first = (uint64_t)w * 64;
+        if (first + 64 > n_reads) {
+            const uint32_t live = (uint32_t)(n_reads - first);
+            m &= live >= 64 ? ~0ull : ((1ull << live) - 1ull);
+        }
+        mask[w] = m;
+    }
+}
+
+// Amplicon FILTER predicate per pair (bam_api.cpp:311-327, amplicon.cpp:5-7,
+// amplicon_set.cpp:5-9); one wave emits one 64-pair word with a ballot.
+__global__ __launch_bounds__(256) void k_amplicon_filter(const uint32_t* __restrict__ starts,
+                                                         const uint32_t* __restrict__ ends,
+                                                         const uint32_t* __restrict__ seq_lengths,
+                                                         const uint32_t* __restrict__ qualities,
+                                                         uint64_t n_pairs,
+                                                         const uint32_t* __restrict__ amp_starts,
+                                                         const uint32_t* __restrict__ amp_ends,
+                                                         uint32_t n_amp, uint32_t min_length,
+                                                         uint32_t min_mapq,
+                                                         uint64_t* __restrict__ pair_keep) {
+    extern __shared__ uint32_t s_amp[];  // [2 * n_cached]
+    const uint32_t n_cached = min(n_amp, 4096u);
+    for (uint32_t i = threadIdx.x; i < n_cached; i += blockDim.x) {
+        s_amp[i] = amp_starts[i];
+        s_amp[n_cached + i] = amp_ends[i];
+    }
+    __syncthreads();
+    const uint64_t n_words = (n_pairs + 63) / 64;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t w = wave_global; w < n_words; w += n_waves) {
+        const uint64_t q = w * 64 + lane;
+        bool ok = false;
+        if (q < n_pairs) {
+            const uint64_t i = 2 * q, j = i + 1;
+            const uint32_t s1 = starts[i], e1 = ends[i], s2 = starts[j], e2 = ends[j];
+            bool pass = true;
+            if (qualities) pass = pass && qualities[i] >= min_mapq && qualities[j] >= min_mapq;
+            if (seq_lengths) pass = pass && seq_lengths[i] >= min_length && seq_lengths[j] >= min_length;
+            bool in_one = false;
+            for (uint32_t a = 0; a < n_cached && !in_one; ++a) {
+                const uint32_t as = s_amp[a], ae = s_amp[n_cached + a];
+                in_one = as <= s1 && e1 <= ae && as <= s2 && e2 <= ae;
+            }
+            for (uint32_t a = n_cached; a < n_amp && !in_one; ++a) {
+                const uint32_t as = amp_starts[a], ae = amp_ends[a];
+                in_one = as <= s1 && e1 <= ae && as <= s2 && e2 <= ae;
+            }
+            ok = pass && in_one;
+        }
+        const uint64_t word = __ballot(ok);
+        if (lane == 0) pair_keep[w] = word;
+    }
+}
+
+// ------------------------------------------------------------------ host-side launchers
+static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 * 8) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
+                    const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
+                    const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
+                    uint32_t* stats) {
+    hipLaunchKernelGGL(k_prepare, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, d_roff,
+                       d_poff, n_contigs, keep_mask, gstart, cstart, stats);
+}
+
+void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
+                         const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
+                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt) {
+    if (wide)
+        hipLaunchKernelGGL(k_general_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, gstart,
+                           starts, ends, n, span_bits, max_span, keep_mask, (uint64_t*)keys, ecnt);
+    else
+        hipLaunchKernelGGL(k_general_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, gstart,
+                           starts, ends, n, span_bits, max_span, keep_mask, (uint32_t*)keys, ecnt);
+}
+
+uint32_t scan_spine_entries(uint32_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+void launch_exclusive_scan(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out,
+                           uint32_t* spine, bool write_total) {
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    if (n_tiles == 0) return;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(kScanThreads), 0, st, in, n, spine);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanThreads), 0, st, spine, n_tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, in, n, spine, out,
+                       write_total ? 1 : 0);
+}
+
+uint32_t sort_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+void launch_radix_pass(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
+                       uint32_t n, uint32_t shift, void* keys_out, uint32_t* vals_out,
+                       uint32_t* hist, uint32_t* spine) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    if (wide)
+        hipLaunchKernelGGL(k_radix_hist<uint64_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
+                           (const uint64_t*)keys_in, n, shift, n_tiles, hist);
+    else
+        hipLaunchKernelGGL(k_radix_hist<uint32_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
+                           (const uint32_t*)keys_in, n, shift, n_tiles, hist);
+    launch_exclusive_scan(st, hist, 256u * n_tiles, hist, spine, false);
+    if (wide)
+        hipLaunchKernelGGL(k_radix_scatter<uint64_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
+                           (const uint64_t*)keys_in, vals_in, n, shift, n_tiles, hist,
+                           (uint64_t*)keys_out, vals_out);
+    else
+        hipLaunchKernelGGL(k_radix_scatter<uint32_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
+                           (const uint32_t*)keys_in, vals_in, n, shift, n_tiles, hist,
+                           (uint32_t*)keys_out, vals_out);
+}
+
+bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t* selend,
+                          uint32_t* iter_stats) {
+    const uint32_t e = (ell + 63) / 64;
+#define QMCP_SWEEP(EE)                                                                          \
+    hipLaunchKernelGGL(k_sweep_uniform<EE>, dim3(n_contigs), dim3(64), 0, st, boff, d_poff, ell, \
+                       M, selend, iter_stats)
+    switch (e) {
+        case 1: QMCP_SWEEP(1); break;
+        case 2: QMCP_SWEEP(2); break;
+        case 3: QMCP_SWEEP(3); break;
+        case 4: QMCP_SWEEP(4); break;
+        case 5: QMCP_SWEEP(5); break;
+        case 6: QMCP_SWEEP(6); break;
+        case 7: QMCP_SWEEP(7); break;
+        case 8: QMCP_SWEEP(8); break;
+        default: return false;
+    }
+#undef QMCP_SWEEP
+    return true;
+}
+
+void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
+                          const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
+                          uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
+                          uint32_t ring_size) {
+    const size_t lds = 2 * (size_t)ring_size * sizeof(uint32_t);
+    if (wide) {
+        (void)hipFuncSetAttribute((const void*)k_sweep_general<uint64_t>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general<uint64_t>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+                           (const uint64_t*)skeys, d_poff, span_bits, max_span, M, selend, ring_size);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_sweep_general<uint32_t>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general<uint32_t>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+                           (const uint32_t*)skeys, d_poff, span_bits, max_span, M, selend, ring_size);
+    }
+}
+
+void launch_mark(hipStream_t st, bool wide, const void* skeys, const uint32_t* svals, uint32_t n,
+                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask) {
+    if (wide)
+        hipLaunchKernelGGL(k_mark<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           (const uint64_t*)skeys, svals, n, span_bits, selend, (uint32_t*)mask);
+    else
+        hipLaunchKernelGGL(k_mark<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           (const uint32_t*)skeys, svals, n, span_bits, selend, (uint32_t*)mask);
+}
+
+void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
+                     unsigned long long* out) {
+    hipLaunchKernelGGL(k_popcount, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask, n_words, out);
+}
+
+void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
+                     uint32_t* cov) {
+    hipLaunchKernelGGL(k_coverage, dim3(grid_for(ltot, 256)), dim3(256), 0, st, boff, eoff, ltot, cov);
+}
+
+void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads) {
+    hipLaunchKernelGGL(k_complete_pairs, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask,
+                       n_words, n_reads);
+}
+
+void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
+                            const uint32_t* seq_lengths, const uint32_t* qualities,
+                            uint64_t n_pairs, const uint32_t* amp_starts, const uint32_t* amp_ends,
+                            uint32_t n_amp, uint32_t min_length, uint32_t min_mapq,
+                            uint64_t* pair_keep) {
+    const uint32_t n_cached = n_amp < 4096u ? n_amp : 4096u;
+    const uint64_t n_words = (n_pairs + 63) / 64;
+    hipLaunchKernelGGL(k_amplicon_filter, dim3(grid_for(n_words * 64, 256)), dim3(256),
+                       2 * n_cached * sizeof(uint32_t), st, starts, ends, seq_lengths, qualities,
+                       n_pairs, amp_starts, amp_ends, n_amp, min_length, min_mapq, pair_keep);
+}
+
+}  // namespace qmcp

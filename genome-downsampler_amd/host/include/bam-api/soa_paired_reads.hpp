@@ -1,0 +1,1 @@
+#include "bam-api/paired_reads.hpp"

@@ -1,0 +1,43 @@
+// "quasi-mcp-hip": the MI355X solver behind the reference's plugin surface.
+// Takes the place QuasiMcpCudaMaxFlowSolver has in the reference
+// (libs/qmcp-solver/include/qmcp-solver/quasi_mcp_cuda_max_flow_solver.hpp:17-36):
+// same base class, same two overrides, uses_quality_of_reads() == false so the app selects
+// amplicon FILTER (src/app.cpp:121-127).  All device work goes through the C ABI in
+// include/qmcp_hip.h; this class only narrows the SoA columns and expands the keep mask.
+#ifndef QMCP_AMD_QUASI_MCP_HIP_SOLVER_HPP
+#define QMCP_AMD_QUASI_MCP_HIP_SOLVER_HPP
+
+#include <cstdint>
+#include <memory>
+
+#include "qmcp-solver/solver.hpp"
+#include "qmcp_hip.h"
+
+namespace qmcp {
+
+class QuasiMcpHipSolver : public Solver {
+   public:
+    QuasiMcpHipSolver() = default;  // trivial: solvers are built eagerly (src/app.hpp:35)
+    ~QuasiMcpHipSolver() override;
+    QuasiMcpHipSolver(const QuasiMcpHipSolver&) = delete;
+    QuasiMcpHipSolver& operator=(const QuasiMcpHipSolver&) = delete;
+
+    std::unique_ptr<Solution> solve(std::uint32_t required_cover,
+                                    bam_api::BamApi& bam_api) override;
+    bool uses_quality_of_reads() override { return false; }
+
+    void set_device(int device);  // before the first solve; default 0
+    // complete mate pairs on the device before returning (what src/app.cpp:141 does on the
+    // host with BamApi::find_pairs); off by default, like the reference solvers
+    void set_complete_pairs(bool on) { complete_pairs_ = on; }
+    const qmcp_hip_stats& last_stats() const { return stats_; }
+
+   private:
+    qmcp_hip_ctx* ctx_ = nullptr;  // created on first solve, reused across solves
+    int device_ = 0;
+    bool complete_pairs_ = false;
+    qmcp_hip_stats stats_{};
+};
+
+}  // namespace qmcp
+#endif

@@ -1,0 +1,163 @@
+/*
+ * qmcp_hip.h -- C ABI of the MI355X-native quasi-MCP coverage-downsampling solver.
+ *
+ * This is the drop-in boundary for the one hot path this repository accelerates:
+ * the `-a quasi-mcp-*` solver behind the reference's plugin surface
+ *
+ *     qmcp::Solver::solve(uint32_t max_coverage, bam_api::BamApi&)
+ *         -> std::unique_ptr<std::vector<bam_api::ReadIndex>>
+ *     (reference: libs/qmcp-solver/include/qmcp-solver/solver.hpp:13-20,
+ *      registered by name in src/solver_manager.hpp:18-27).
+ *
+ * The reference has no FFI of its own (it is one C++ binary).  A maintainer drops
+ * this library in by adding one `qmcp::Solver` subclass that narrows
+ * `SOAPairedReads::start_inds/end_inds` (libs/bam-api/include/bam-api/soa_paired_reads.hpp:19-24)
+ * to uint32 and calls `qmcp_hip_solve_host`; that adapter ships in
+ * genome-downsampler_amd/host/ and is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary
+ *   - read i is the inclusive interval [starts[i], ends[i]] on its contig
+ *     (end_ind is inclusive in the reference: libs/bam-api/src/read.cpp:13)
+ *   - reads are grouped by contig: contig c owns reads
+ *     [contig_read_offsets[c], contig_read_offsets[c+1]); n_contigs == 1 reproduces the
+ *     reference exactly (it is single-contig: libs/bam-api/src/bam_api.cpp:422)
+ *   - the result is a keep bitmask: bit (i & 63) of word (i >> 6) is set iff read i is kept;
+ *     expanding it in ascending order gives the reference's `Solution` vector
+ *     (quasi_mcp_cpu_max_flow_solver.cpp:89-100)
+ *   - every function returns QMCP_OK (0) or a negative QMCP_E* code; the message for the
+ *     calling thread's last failure is available from qmcp_hip_last_error().  Nothing here
+ *     terminates the process (the reference's CUDA path calls std::terminate():
+ *     libs/qmcp-solver/include/qmcp-solver/cuda_helpers.cuh:13-22 -- the C++ adapter
+ *     re-creates that behaviour on top of the status code).
+ *   - there is no CPU fallback: without a usable HIP device every entry point fails.
+ */
+#ifndef QMCP_HIP_H
+#define QMCP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMCP_HIP_ABI_VERSION 1
+
+enum {
+    QMCP_OK = 0,
+    QMCP_EINVAL = -1,      /* bad argument (null pointer, n_contigs == 0, offsets not monotone ...) */
+    QMCP_EREAD = -2,       /* a read has start > end or end >= contig length                       */
+    QMCP_ERANGE = -3,      /* problem exceeds the 32-bit coordinate / count limits of this build   */
+    QMCP_ENODEVICE = -4,   /* no HIP device / device index out of range                            */
+    QMCP_EHIP = -5,        /* a HIP runtime call failed (message has the hipError string)          */
+    QMCP_ENOMEM = -6       /* device or host allocation failed                                     */
+};
+
+/* Selection paths the solver can take per call (reported in qmcp_hip_stats.path). */
+enum {
+    QMCP_PATH_NONE = 0,
+    QMCP_PATH_UNIFORM = 1, /* all reads of the call have one span: block-parallel sweep            */
+    QMCP_PATH_GENERAL = 2  /* mixed spans: event-driven priority sweep                             */
+};
+
+/* Opaque solver context: owns one HIP stream and a reusable device arena.  Mirrors the
+ * lifetime rules of a reference solver instance (constructed once, `solve` called many
+ * times: src/tests/coverage_tester.cpp:30-34); creating it is the first and only point
+ * where the GPU is touched (reference solvers are constructed eagerly even for --help:
+ * src/app.hpp:35, so the C++ adapter creates the context lazily on first solve). */
+typedef struct qmcp_hip_ctx qmcp_hip_ctx;
+
+typedef struct qmcp_hip_stats {
+    uint64_t n_reads;
+    uint64_t n_kept;          /* popcount of the keep mask                                        */
+    uint64_t total_length;    /* sum of contig lengths                                            */
+    uint32_t n_contigs;
+    uint32_t path;            /* QMCP_PATH_*                                                      */
+    uint32_t min_span;        /* min / max of (end - start + 1) over the call                     */
+    uint32_t max_span;
+    uint32_t sort_passes;     /* radix passes used by the bucketing stage                         */
+    uint32_t reserved0;
+    float ms_total;           /* device time of the whole solve (HIP events on the solver stream) */
+    float ms_prepare;         /* validate + span reduction + per-position start/end counts        */
+    float ms_scan;            /* prefix scans -> bucket offsets / coverage                        */
+    float ms_sort;            /* radix bucketing of reads by (start, span)                        */
+    float ms_sweep;           /* selection sweep                                                  */
+    float ms_mark;            /* keep-mask emission                                               */
+    float ms_h2d;             /* host entry point only                                            */
+    float ms_d2h;             /* host entry point only                                            */
+} qmcp_hip_stats;
+
+int qmcp_hip_abi_version(void);
+const char* qmcp_hip_last_error(void);
+
+/* Number of HIP devices visible to the process (0 if none); never initialises a context. */
+int qmcp_hip_device_count(void);
+
+int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx);
+void qmcp_hip_destroy(qmcp_hip_ctx* ctx);
+
+/* Replaces QuasiMcpCpuMaxFlowSolver::solve / QuasiMcpCudaMaxFlowSolver::solve
+ * (libs/qmcp-solver/src/quasi_mcp_cpu_max_flow_solver.cpp:11-28,
+ *  libs/qmcp-solver/src/quasi_mcp_cuda_max_flow_solver.cu:319-435) for host-resident reads.
+ * keep_mask_out has ceil(n_reads / 64) words and is fully overwritten.  stats may be NULL. */
+int qmcp_hip_solve_host(qmcp_hip_ctx* ctx,
+                        const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                        const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                        uint32_t n_contigs, uint32_t max_coverage,
+                        uint64_t* keep_mask_out, qmcp_hip_stats* stats);
+
+/* Same solve with reads and mask already resident in this context's device memory
+ * (d_* are device pointers; contig tables stay on the host).  `hip_stream` is a
+ * hipStream_t the caller's producer work was enqueued on, or NULL: the solve is ordered
+ * after it and the call returns after the solve has completed on the device. */
+int qmcp_hip_solve_device(qmcp_hip_ctx* ctx,
+                          const uint32_t* d_starts, const uint32_t* d_ends, uint64_t n_reads,
+                          const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                          uint32_t n_contigs, uint32_t max_coverage,
+                          uint64_t* d_keep_mask_out, void* hip_stream, qmcp_hip_stats* stats);
+
+/* Stage probe for parity tests of the deterministic half of the reference solver:
+ * writes cov[p] for every base of every contig (contigs concatenated, sum(contig_lengths)
+ * entries) -- the array BamApi::find_input_cover returns (libs/bam-api/src/bam_api.cpp:275-286)
+ * and from which b and d of create_b_function / create_demand_function
+ * (quasi_mcp_cpu_max_flow_solver.cpp:58-87) follow as b[p+1] = min(cov[p], M). */
+int qmcp_hip_coverage_host(qmcp_hip_ctx* ctx,
+                           const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                           const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                           uint32_t n_contigs, uint32_t* cov_out);
+
+/* Coverage of the kept subset only (BamApi::find_filtered_cover, bam_api.cpp:288-301);
+ * keep_mask is a host bitmask as produced by qmcp_hip_solve_host. */
+int qmcp_hip_filtered_coverage_host(qmcp_hip_ctx* ctx,
+                                    const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                                    const uint64_t* contig_read_offsets,
+                                    const uint32_t* contig_lengths, uint32_t n_contigs,
+                                    const uint64_t* keep_mask, uint32_t* cov_out);
+
+/* BamApi::find_pairs (libs/bam-api/src/bam_api.cpp:239-273) on the bitmask: mates sit at
+ * indices (2q, 2q+1) (bam_api.cpp:456-461), so completing pairs is an OR inside each
+ * aligned bit pair.  In place on a device mask of ceil(n_reads/64) words. */
+int qmcp_hip_complete_pairs_device(qmcp_hip_ctx* ctx, uint64_t* d_keep_mask, uint64_t n_reads,
+                                   void* hip_stream);
+int qmcp_hip_complete_pairs_host(qmcp_hip_ctx* ctx, uint64_t* keep_mask, uint64_t n_reads);
+
+/* Amplicon FILTER pre-pass (BamApi::should_be_filtered_out with AmpliconBehaviour::FILTER,
+ * libs/bam-api/src/bam_api.cpp:311-319; Amplicon::includes amplicon.cpp:5-7;
+ * AmpliconSet::member_includes_both amplicon_set.cpp:5-9; min length / min MAPQ
+ * bam_api.cpp:321-327).  Pair q = reads (2q, 2q+1).  pair_keep_out gets one bit per pair:
+ * set iff the pair survives (both mates inside one amplicon [amp_start, amp_end] inclusive,
+ * both seq_lengths >= min_length, both qualities >= min_mapq).  seq_lengths / qualities may
+ * be NULL (that filter is then skipped, as with the reference's defaults of 0). */
+int qmcp_hip_amplicon_filter_host(qmcp_hip_ctx* ctx,
+                                  const uint32_t* starts, const uint32_t* ends,
+                                  const uint32_t* seq_lengths, const uint32_t* qualities,
+                                  uint64_t n_reads,
+                                  const uint32_t* amp_starts, const uint32_t* amp_ends,
+                                  uint32_t n_amplicons, uint32_t min_length, uint32_t min_mapq,
+                                  uint64_t* pair_keep_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMCP_HIP_H */
