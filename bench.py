@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the quasi-MCP solver path: Mreads/s selected at target coverage M=100.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2]
+
+A step is one pass of the hot path (device-resident reads -> device keep bitmask, plus the
+RCCL gather of the masks when N > 1) over one batch of libs/reads-gen-style synthetic reads.
+Workload per GPU (weak scaling): BASELINE.json configs[3] -- 8 contigs x rand_reads_uniform(
+seed 12345 + c, 6 250 000 pairs, L = 1 000 000, len 150), 100 M reads, M = 100; rank r uses
+seeds 12345 + 8 r + c.  Inputs are resident in HBM when the timed region starts.
+
+For N > 1 launch through torch.distributed.run (one rank per GPU over RCCL); rank 0 prints ONE
+JSON line.  The CPU baseline (oracle/, rank 0, N = 1 only) is a reported number, not the target.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+WORKLOADS = {
+    # name: (contigs per GPU, pairs per contig, contig length, read length, M)
+    "cfg4": (8, 6_250_000, 1_000_000, 150, 100),
+    "cfg2": (1, 500_000, 30_000, 150, 100),
+}
+
+
+def algorithmic_bytes(n_reads, total_len, n_contigs):
+    """8 B/read in, 1 bit/read out, 8 B per base of coverage array"""
+    return 8.0 * n_reads + n_reads / 8.0 + 8.0 * (total_len + n_contigs)
+
+
+def cpu_baseline(pkg, workload):
+    """oracle (single thread) on a bounded sample of the same workload: one contig"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    n_contigs, pairs, L, rl, M = WORKLOADS[workload]
+    n_sample = min(n_contigs, 3)
+    dt, n_done, first_mask = 0.0, 0, None
+    for c in range(n_sample):
+        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, pairs, L, rl, seed=12345 + c)
+        t0 = time.perf_counter()
+        # the reference's two host stages: per-base coverage build (create_b_function) ...
+        oracle_py.b_function(s, e, L, M)
+        # ... and the selection (SimpleMaxFlow::Solve + obtain_sequence -> canonical maximum flow)
+        mask = oracle_py.solve(s, e, L, M)
+        dt += time.perf_counter() - t0
+        n_done += s.size
+        if first_mask is None:
+            first_mask = mask
+    return {
+        "value": round(n_done / dt / 1e6, 3), "unit": "Mreads/s", "cores": 1, "kind": "port",
+        "sample": f"{n_sample} of {n_contigs} contigs of the workload ({n_done} reads, L={L} each, "
+                  f"M={M}): per-base coverage build + canonical selection, {dt:.2f} s on one "
+                  "thread; OR-Tools-backed reference binary not runnable (dependency unavailable)",
+        "host_cpus": os.cpu_count(),
+    }, first_mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("genome-downsampler_amd")
+    n_contigs, pairs, L, rl, M = WORKLOADS[args.workload]
+    ss, ee = [], []
+    for c in range(n_contigs):
+        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, pairs, L, rl, seed=12345 + n_contigs * rank + c)
+        ss.append(s)
+        ee.append(e)
+    starts = np.concatenate(ss)
+    ends = np.concatenate(ee)
+    n_reads = starts.size
+    offs = (np.arange(n_contigs + 1, dtype=np.uint64) * np.uint64(2 * pairs))
+    lengths = np.full(n_contigs, L, dtype=np.uint32)
+    words = pkg.mask_words(n_reads)
+
+    d_starts = torch.from_numpy(starts.view(np.int32)).to(dev)
+    d_ends = torch.from_numpy(ends.view(np.int32)).to(dev)
+    d_mask = torch.zeros(words, dtype=torch.int64, device=dev)
+    d_all = torch.zeros(words * world, dtype=torch.int64, device=dev) if world > 1 else None
+    solver = pkg.Solver(local_rank)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        solver.solve_device(d_starts.data_ptr(), d_ends.data_ptr(), n_reads, lengths, M,
+                            d_mask.data_ptr(), contig_read_offsets=offs, stream=stream)
+        if world > 1:
+            # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
+            dist.all_gather_into_tensor(d_all, d_mask)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    solver.set_profiling(True)  # HIP events around every kernel launch, on the solver stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ktimes = solver.kernel_times()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_reads = n_reads * world
+    value = total_reads * args.steps / elapsed / 1e6
+    st = solver.last_stats
+
+    out = None
+    if rank == 0:
+        b_alg = algorithmic_bytes(n_reads, n_contigs * L, n_contigs)
+        dom_name, (dom_launches, dom_ms) = max(ktimes.items(), key=lambda kv: kv[1][1])
+        dom_avg_ms = dom_ms / dom_launches
+        achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9
+        dev_ms = sum(ms for _, ms in ktimes.values()) / args.steps
+        out = {
+            "metric": "Mreads/s selected at target coverage M=100",
+            "value": round(value, 2), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload} per GPU: {n_contigs} contigs x rand_reads_uniform("
+                            f"{pairs} pairs, L={L}, len={rl}), {n_reads} reads, M={M}; "
+                            "device-resident reads -> device keep bitmask"
+                            + ("; + RCCL all_gather of keep masks" if world > 1 else ""),
+                "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
+                "path": {1: "uniform-span block sweep", 2: "mixed-span event sweep"}.get(st.path),
+                "kept_reads_per_gpu": int(st.n_kept),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": b_alg,
+                "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_launches,
+                "whole_solve": {
+                    "device_ms": round(dev_ms, 4),
+                    "achieved": round(b_alg / (dev_ms * 1e-3) / 1e9, 2),
+                    "frac": round(b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                },
+                "kernels_ms_per_step": {k: round(ms / args.steps, 4) for k, (_, ms) in
+                                        sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, oracle_mask = cpu_baseline(pkg, args.workload)
+            out["cpu_baseline"] = base
+            # parity spot check on the sampled contig: GPU bits == oracle bits
+            got = d_mask.cpu().numpy().view(np.uint64)
+            w0 = oracle_mask.size
+            tail_bits = (2 * pairs) % 64
+            same = np.array_equal(got[:w0 - (1 if tail_bits else 0)],
+                                  oracle_mask[:w0 - (1 if tail_bits else 0)])
+            out["parity_vs_oracle_on_sample"] = bool(same)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,8 @@ ABI_SYMBOLS = (
     "qmcp_hip_abi_version", "qmcp_hip_last_error", "qmcp_hip_device_count", "qmcp_hip_create",
     "qmcp_hip_destroy", "qmcp_hip_solve_host", "qmcp_hip_solve_device", "qmcp_hip_coverage_host",
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
-    "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host",
+    "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
+    "qmcp_hip_kernel_times",
 )
 
 QMCP_OK = 0
@@ -78,6 +79,8 @@ _hip.qmcp_hip_complete_pairs_host.argtypes = [C.c_void_p, _u64p, C.c_uint64]
 _hip.qmcp_hip_amplicon_filter_host.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, _u32p, C.c_uint64,
                                                _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                _u64p]
+_hip.qmcp_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+_hip.qmcp_hip_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 if _host is not None:
     _host.qmcp_host_reads_gen.argtypes = [C.c_uint32, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
                                           _u32p, _u32p, _u32p]
@@ -169,6 +172,22 @@ class Solver:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_profiling(self, enabled):
+        """bracket every kernel launch with HIP events on the solver stream (resets the totals)"""
+        _check(_hip.qmcp_hip_set_profiling(self._ctx, int(bool(enabled))))
+
+    def kernel_times(self):
+        """{kernel: (launches, total_ms)} accumulated since set_profiling(True)"""
+        buf = C.create_string_buffer(8192)
+        n = _hip.qmcp_hip_kernel_times(self._ctx, buf, len(buf))
+        if n < 0:
+            _check(n)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms = line.split("\t")
+            out[name] = (int(launches), float(ms))
+        return out
 
     def solve(self, starts, ends, contig_lengths, max_coverage, contig_read_offsets=None):
         """host arrays in, host keep bitmask (np.uint64 words) out"""

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "qmcp_hip.h"
@@ -59,9 +60,60 @@ struct qmcp_hip_ctx {
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp;
     DevBuf scalars;  // popcount + sweep iteration counters
     uint32_t last_iters = 0, last_blocks = 0;
+    // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
+    bool profiling = false;
+    struct Span { const char* name; hipEvent_t a, b; };
+    std::vector<Span> spans;          // spans of the solve in flight
+    std::vector<hipEvent_t> ev_pool;  // recycled events
+    struct Acc { std::string name; uint64_t launches; double ms; };
+    std::vector<Acc> acc;             // accumulated since the last reset
 };
 
 namespace {
+
+hipEvent_t pool_event(qmcp_hip_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// RAII bracket around one kernel (or one kernel + its helper launches) when profiling is on
+struct KernelSpan {
+    qmcp_hip_ctx* c;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    KernelSpan(qmcp_hip_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+        if (!c->profiling) return;
+        a = pool_event(c);
+        b = pool_event(c);
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~KernelSpan() {
+        if (!c->profiling || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({name, a, b});
+    }
+};
+
+void collect_spans(qmcp_hip_ctx* c) {
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            bool found = false;
+            for (auto& a : c->acc)
+                if (a.name == sp.name) { a.launches++; a.ms += ms; found = true; break; }
+            if (!found) c->acc.push_back({sp.name, 1, ms});
+        }
+        c->ev_pool.push_back(sp.a);
+        c->ev_pool.push_back(sp.b);
+    }
+    c->spans.clear();
+}
 
 int ensure(qmcp_hip_ctx* c, DevBuf& b, size_t bytes) {
     (void)c;
@@ -133,10 +185,13 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->cstart.p, 0, ((size_t)pr.ltot + 1) * sizeof(uint32_t), c->stream));
-    qmcp::launch_prepare(c->stream, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
-                         (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
-                         want_keys ? (uint32_t*)c->keys[0].p : nullptr, (uint32_t*)c->cstart.p,
-                         (uint32_t*)c->stats.p);
+    {
+        KernelSpan sp(c, "k_prepare");
+        qmcp::launch_prepare(c->stream, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
+                             (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
+                             want_keys ? (uint32_t*)c->keys[0].p : nullptr, (uint32_t*)c->cstart.p,
+                             (uint32_t*)c->stats.p);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            c->stream));
@@ -149,8 +204,11 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
 int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
     TRY(ensure(c, out, ((size_t)ltot + 1) * sizeof(uint32_t)));
     TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(ltot) * sizeof(uint32_t) + 16));
-    qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)counts.p, ltot, (uint32_t*)out.p,
-                                (uint32_t*)c->spine.p, true);
+    {
+        KernelSpan sp(c, "scan_positions(3 kernels)");
+        qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)counts.p, ltot, (uint32_t*)out.p,
+                                    (uint32_t*)c->spine.p, true);
+    }
     HIP_TRY(hipGetLastError());
     return QMCP_OK;
 }
@@ -228,8 +286,12 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
         // gstart sits in keys[0]; composite keys go to keys[1]
-        qmcp::launch_general_keys(c->stream, wide, (const uint32_t*)c->keys[0].p, d_starts, d_ends, n,
-                                  span_bits, max_span, nullptr, c->keys[1].p, (uint32_t*)c->ecnt.p);
+        {
+            KernelSpan sp(c, "k_general_keys");
+            qmcp::launch_general_keys(c->stream, wide, (const uint32_t*)c->keys[0].p, d_starts, d_ends,
+                                      n, span_bits, max_span, nullptr, c->keys[1].p,
+                                      (uint32_t*)c->ecnt.p);
+        }
         HIP_TRY(hipGetLastError());
         TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
     }
@@ -252,9 +314,21 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     const uint32_t* vals_in = nullptr;  // first pass: payload is the read index itself
     for (uint32_t p = 0; p < passes; ++p) {
         const int kout = kin ^ 1, vout = (vals_in == nullptr) ? 0 : (vin ^ 1);
-        qmcp::launch_radix_pass(c->stream, wide, c->keys[kin].p, vals_in, n, 8 * p, c->keys[kout].p,
-                                (uint32_t*)c->vals[vout].p, (uint32_t*)c->hist.p,
-                                (uint32_t*)c->spine.p);
+        {
+            KernelSpan sp(c, "k_radix_hist");
+            qmcp::launch_radix_hist(c->stream, wide, c->keys[kin].p, n, 8 * p, (uint32_t*)c->hist.p);
+        }
+        {
+            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+            qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)c->hist.p, 256u * n_tiles,
+                                        (uint32_t*)c->hist.p, (uint32_t*)c->spine.p, false);
+        }
+        {
+            KernelSpan sp(c, "k_radix_scatter");
+            qmcp::launch_radix_scatter(c->stream, wide, c->keys[kin].p, vals_in, n, 8 * p,
+                                       (const uint32_t*)c->hist.p, c->keys[kout].p,
+                                       (uint32_t*)c->vals[vout].p);
+        }
         HIP_TRY(hipGetLastError());
         kin = kout;
         vin = vout;
@@ -268,6 +342,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     if (uniform) {
+        KernelSpan sp(c, "k_sweep_uniform");
         if (!qmcp::launch_sweep_uniform(c->stream, (const uint32_t*)c->boff.p,
                                         (const uint64_t*)c->poff.p, n_contigs, max_span, M,
                                         (uint32_t*)c->selend.p, d_iters))
@@ -275,6 +350,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     } else {
         uint32_t ring = 64;
         while (ring <= max_span) ring <<= 1;
+        KernelSpan sp(c, "k_sweep_general");
         qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
                                    (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                    (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
@@ -284,16 +360,24 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], c->stream));
 
     // keep mask
-    qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n, span_bits,
-                      (const uint32_t*)c->selend.p, d_mask);
+    {
+        KernelSpan sp(c, "k_mark");
+        qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n,
+                          span_bits, (const uint32_t*)c->selend.p, d_mask);
+    }
     HIP_TRY(hipGetLastError());
-    qmcp::launch_popcount(c->stream, d_mask, (uint32_t)mask_words, (unsigned long long*)c->scalars.p);
+    {
+        KernelSpan sp(c, "k_popcount");
+        qmcp::launch_popcount(c->stream, d_mask, (uint32_t)mask_words,
+                              (unsigned long long*)c->scalars.p);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
     unsigned long long host_scalars[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(host_scalars, c->scalars.p, sizeof(host_scalars), hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    collect_spans(c);
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
@@ -421,8 +505,30 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     for (int i = 0; i < EV_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int qmcp_hip_set_profiling(qmcp_hip_ctx* c, int enabled) {
+    if (!c) return fail(QMCP_EINVAL, "null context");
+    c->profiling = enabled != 0;
+    c->acc.clear();
+    return QMCP_OK;
+}
+
+int qmcp_hip_kernel_times(qmcp_hip_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return fail(QMCP_EINVAL, "null argument");
+    size_t used = 0;
+    buf[0] = 0;
+    for (const auto& a : c->acc) {
+        int w = snprintf(buf + used, cap - used, "%s\t%llu\t%.6f\n", a.name.c_str(),
+                         (unsigned long long)a.launches, a.ms);
+        if (w < 0 || (size_t)w >= cap - used) return fail(QMCP_EINVAL, "buffer too small");
+        used += (size_t)w;
+    }
+    return (int)c->acc.size();
 }
 
 int qmcp_hip_solve_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,

@@ -21,9 +21,11 @@ uint32_t scan_spine_entries(uint32_t n);
 void launch_exclusive_scan(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out,
                            uint32_t* spine, bool write_total);
 uint32_t sort_tiles(uint32_t n);
-void launch_radix_pass(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
-                       uint32_t n, uint32_t shift, void* keys_out, uint32_t* vals_out,
-                       uint32_t* hist, uint32_t* spine);
+void launch_radix_hist(hipStream_t st, bool wide, const void* keys_in, uint32_t n, uint32_t shift,
+                       uint32_t* hist);
+void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
+                          uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
+                          uint32_t* vals_out);
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t* selend,
                           uint32_t* iter_stats);

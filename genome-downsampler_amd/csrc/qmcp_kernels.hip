@@ -782,9 +782,8 @@ void launch_exclusive_scan(hipStream_t st, const uint32_t* in, uint32_t n, uint3
 
 uint32_t sort_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 
-void launch_radix_pass(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
-                       uint32_t n, uint32_t shift, void* keys_out, uint32_t* vals_out,
-                       uint32_t* hist, uint32_t* spine) {
+void launch_radix_hist(hipStream_t st, bool wide, const void* keys_in, uint32_t n, uint32_t shift,
+                       uint32_t* hist) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     if (wide)
@@ -793,14 +792,20 @@ void launch_radix_pass(hipStream_t st, bool wide, const void* keys_in, const uin
     else
         hipLaunchKernelGGL(k_radix_hist<uint32_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
                            (const uint32_t*)keys_in, n, shift, n_tiles, hist);
-    launch_exclusive_scan(st, hist, 256u * n_tiles, hist, spine, false);
+}
+
+void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
+                          uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
+                          uint32_t* vals_out) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
     if (wide)
         hipLaunchKernelGGL(k_radix_scatter<uint64_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
-                           (const uint64_t*)keys_in, vals_in, n, shift, n_tiles, hist,
+                           (const uint64_t*)keys_in, vals_in, n, shift, n_tiles, offs,
                            (uint64_t*)keys_out, vals_out);
     else
         hipLaunchKernelGGL(k_radix_scatter<uint32_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
-                           (const uint32_t*)keys_in, vals_in, n, shift, n_tiles, hist,
+                           (const uint32_t*)keys_in, vals_in, n, shift, n_tiles, offs,
                            (uint32_t*)keys_out, vals_out);
 }
 

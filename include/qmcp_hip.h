@@ -97,6 +97,14 @@ int qmcp_hip_device_count(void);
 int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx);
 void qmcp_hip_destroy(qmcp_hip_ctx* ctx);
 
+/* Instrumentation (the reference's only timing is the "solve took" wall-clock log line,
+ * src/app.cpp:132-139).  With profiling on, every kernel launch of a solve is bracketed by HIP
+ * events on the solver stream; qmcp_hip_kernel_times writes one line per kernel,
+ * "name<TAB>launches<TAB>total_ms", accumulated since profiling was last switched on, and
+ * returns the number of lines (negative on error). */
+int qmcp_hip_set_profiling(qmcp_hip_ctx* ctx, int enabled);
+int qmcp_hip_kernel_times(qmcp_hip_ctx* ctx, char* buf, size_t cap);
+
 /* Replaces QuasiMcpCpuMaxFlowSolver::solve / QuasiMcpCudaMaxFlowSolver::solve
  * (libs/qmcp-solver/src/quasi_mcp_cpu_max_flow_solver.cpp:11-28,
  *  libs/qmcp-solver/src/quasi_mcp_cuda_max_flow_solver.cu:319-435) for host-resident reads.
