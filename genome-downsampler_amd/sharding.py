@@ -1,0 +1,67 @@
+"""Multi-GPU composition of the solver path: contigs are independent solves (the reference is
+single-contig, libs/bam-api/src/bam_api.cpp:422), so they shard across ranks with no data-path
+collective; the only exchange is the gather of the keep bitmasks (RCCL over xGMI on the GPU
+box, gloo in the CPU tests).  Nothing here exists in the reference (it has no multi-GPU path).
+
+This module is host-side plumbing only: which contigs a rank owns, how the reads of those
+contigs are sliced, and how per-rank masks merge back into one global ReadIndex bitmask."""
+import numpy as np
+
+
+def assign_contigs(read_counts, world_size):
+    """longest-processing-time assignment of contigs to ranks by read count; deterministic.
+    Returns a list (per rank) of ascending contig ids."""
+    order = sorted(range(len(read_counts)), key=lambda c: (-int(read_counts[c]), c))
+    load = [0] * world_size
+    owned = [[] for _ in range(world_size)]
+    for c in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owned[r].append(c)
+        load[r] += int(read_counts[c])
+    return [sorted(o) for o in owned]
+
+
+def local_problem(starts, ends, contig_read_offsets, contig_lengths, contigs):
+    """slice the reads of `contigs` (ascending) into one contiguous local problem"""
+    offs = np.asarray(contig_read_offsets, dtype=np.uint64)
+    parts_s, parts_e, counts = [], [], []
+    for c in contigs:
+        lo, hi = int(offs[c]), int(offs[c + 1])
+        parts_s.append(np.asarray(starts[lo:hi], dtype=np.uint32))
+        parts_e.append(np.asarray(ends[lo:hi], dtype=np.uint32))
+        counts.append(hi - lo)
+    s = np.concatenate(parts_s) if parts_s else np.zeros(0, np.uint32)
+    e = np.concatenate(parts_e) if parts_e else np.zeros(0, np.uint32)
+    local_offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    lengths = np.asarray(contig_lengths, dtype=np.uint32)[list(contigs)] if len(contigs) else \
+        np.zeros(0, np.uint32)
+    return s, e, local_offs, lengths
+
+
+def merge_masks(gathered_masks, owned, contig_read_offsets, n_reads):
+    """place every rank's local keep bits at their global ReadIndex positions"""
+    offs = np.asarray(contig_read_offsets, dtype=np.uint64)
+    bits = np.zeros(((int(n_reads) + 63) // 64) * 64, dtype=np.uint8)
+    for rank, contigs in enumerate(owned):
+        local = np.unpackbits(np.ascontiguousarray(gathered_masks[rank]).view(np.uint8),
+                              bitorder="little")
+        pos = 0
+        for c in contigs:
+            lo, hi = int(offs[c]), int(offs[c + 1])
+            bits[lo:hi] = local[pos:pos + (hi - lo)]
+            pos += hi - lo
+    return np.packbits(bits, bitorder="little").view(np.uint64).copy()
+
+
+def gather_masks(local_mask, max_words, dist, device=None):
+    """all-gather of the per-rank keep bitmasks, padded to `max_words` 64-bit words.
+    `dist` is torch.distributed (nccl == RCCL on the GPU box, gloo on CPU)."""
+    import torch
+    world = dist.get_world_size()
+    buf = torch.zeros(max_words, dtype=torch.int64, device=device)
+    src = torch.from_numpy(np.ascontiguousarray(local_mask).view(np.int64))
+    buf[:src.numel()] = src.to(buf.device)
+    out = torch.zeros(max_words * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    host = out.cpu().numpy().view(np.uint64)
+    return [host[r * max_words:(r + 1) * max_words] for r in range(world)]
