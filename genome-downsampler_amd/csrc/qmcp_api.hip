@@ -174,23 +174,26 @@ int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
     return QMCP_OK;
 }
 
-// prepare + host round trip.  Leaves gstart in keys[0] (as u32) when want_keys.
+// prepare + host round trip.  Leaves gstart (global start position per read) in vals[1] when
+// want_keys; counts reads per start position into cstart (global atomics) only when
+// want_counts -- the solve derives its bucket offsets from the sorted keys instead.
 int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
-                const Problem& pr, const uint64_t* d_keep_mask, bool want_keys,
+                const Problem& pr, const uint64_t* d_keep_mask, bool want_keys, bool want_counts,
                 uint32_t host_stats[3]) {
     const uint32_t n = (uint32_t)pr.n;
     TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
-    TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
-    if (want_keys) TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
+    if (want_counts) TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
+    if (want_keys) TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->cstart.p, 0, ((size_t)pr.ltot + 1) * sizeof(uint32_t), c->stream));
+    if (want_counts)
+        HIP_TRY(hipMemsetAsync(c->cstart.p, 0, ((size_t)pr.ltot + 1) * sizeof(uint32_t), c->stream));
     {
         KernelSpan sp(c, "k_prepare");
         qmcp::launch_prepare(c->stream, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
                              (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
-                             want_keys ? (uint32_t*)c->keys[0].p : nullptr, (uint32_t*)c->cstart.p,
-                             (uint32_t*)c->stats.p);
+                             want_keys ? (uint32_t*)c->vals[1].p : nullptr,
+                             want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -244,14 +247,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     {
         const uint32_t tiles = qmcp::sort_tiles(n);
         const uint32_t spine_a = qmcp::scan_spine_entries(256u * tiles);
-        const uint32_t spine_b = qmcp::scan_spine_entries(ltot);
+        const uint32_t spine_b = qmcp::scan_spine_entries(ltot + 1) + 1;
         TRY(ensure(c, c->spine, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist, (size_t)256 * tiles * sizeof(uint32_t)));
         TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
         TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
-        TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->scalars, 64));
@@ -261,7 +263,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     TRY(upload_tables(c, roff, pr));
 
     uint32_t hs[3];
-    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, hs));
+    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, hs));
     HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
@@ -272,68 +274,99 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                     max_span, qmcp::kMaxGeneralSpan);
     local.path = uniform ? QMCP_PATH_UNIFORM : QMCP_PATH_GENERAL;
 
-    // bucket offsets
-    TRY(scan_counts(c, c->cstart, c->boff, ltot));
-
-    // bucketing keys
+    // bucketing keys.  gstart (global start position per read) sits in vals[1].
     const uint32_t pos_bits = bit_width(ltot - 1) == 0 ? 1u : bit_width(ltot - 1);
     uint32_t span_bits = 0;
     bool wide = false;
+    const uint32_t* d_gstart = (const uint32_t*)c->vals[1].p;
+    const uint32_t* d_key32 = d_gstart;  // uniform span: the key is the start position itself
     if (!uniform) {
         span_bits = bit_width(max_span - min_span);
         wide = pos_bits + span_bits > 32;
         TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
-        TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
+        TRY(ensure(c, c->eoff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
-        // gstart sits in keys[0]; composite keys go to keys[1]
+        void* key_dst = wide ? c->keys[0].p : c->vals[0].p;
         {
             KernelSpan sp(c, "k_general_keys");
-            qmcp::launch_general_keys(c->stream, wide, (const uint32_t*)c->keys[0].p, d_starts, d_ends,
-                                      n, span_bits, max_span, nullptr, c->keys[1].p,
-                                      (uint32_t*)c->ecnt.p);
+            qmcp::launch_general_keys(c->stream, wide, d_gstart, d_starts, d_ends, n, span_bits,
+                                      max_span, nullptr, key_dst, (uint32_t*)c->ecnt.p);
         }
         HIP_TRY(hipGetLastError());
         TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
+        d_key32 = (const uint32_t*)c->vals[0].p;
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
 
-    // radix bucketing
+    // radix bucketing: stable LSD, 8-bit digits
     const uint32_t key_bits = pos_bits + span_bits;
     const uint32_t passes = (key_bits + 7) / 8;
     local.sort_passes = passes;
     const uint32_t n_tiles = qmcp::sort_tiles(n);
-    TRY(ensure(c, c->hist, (size_t)256 * n_tiles * sizeof(uint32_t)));
-    TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(256u * n_tiles) * sizeof(uint32_t) + 16));
-    TRY(ensure(c, c->spine, (size_t)qmcp::scan_spine_entries(ltot) * sizeof(uint32_t) + 16));
-    TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
-    TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
-    TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
-    TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
-    int kin = uniform ? 0 : 1;  // buffer holding the unsorted keys
-    int vin = 0;
-    const uint32_t* vals_in = nullptr;  // first pass: payload is the read index itself
-    for (uint32_t p = 0; p < passes; ++p) {
-        const int kout = kin ^ 1, vout = (vals_in == nullptr) ? 0 : (vin ^ 1);
-        {
-            KernelSpan sp(c, "k_radix_hist");
-            qmcp::launch_radix_hist(c->stream, wide, c->keys[kin].p, n, 8 * p, (uint32_t*)c->hist.p);
+    int kin = 0, vin = 0;  // buffers holding the sorted output at the end
+    if (!wide) {
+        // records {key, read index}: keys[0] <-> keys[1]; the first pass reads bare keys
+        const void* recs_in = nullptr;
+        for (uint32_t p = 0; p < passes; ++p) {
+            const bool first = p == 0;
+            const int kout = first ? 0 : (kin ^ 1);
+            {
+                KernelSpan sp(c, "k_radix_hist_rec");
+                qmcp::launch_radix_hist_rec(c->stream, first, d_key32, recs_in, n, 8 * p,
+                                            (uint32_t*)c->hist.p);
+            }
+            {
+                KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+                qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)c->hist.p, 256u * n_tiles,
+                                            (uint32_t*)c->hist.p, (uint32_t*)c->spine.p, false);
+            }
+            {
+                KernelSpan sp(c, "k_radix_scatter_rec");
+                qmcp::launch_radix_scatter_rec(c->stream, first, d_key32, recs_in, n, 8 * p,
+                                               (const uint32_t*)c->hist.p, c->keys[kout].p);
+            }
+            HIP_TRY(hipGetLastError());
+            kin = kout;
+            recs_in = c->keys[kin].p;
         }
-        {
-            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
-            qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)c->hist.p, 256u * n_tiles,
-                                        (uint32_t*)c->hist.p, (uint32_t*)c->spine.p, false);
+    } else {
+        // 64-bit composite keys (huge genome x wide span range): split key / payload arrays
+        const uint32_t* vals_in = nullptr;
+        for (uint32_t p = 0; p < passes; ++p) {
+            const int kout = kin ^ 1, vout = (vals_in == nullptr) ? 0 : (vin ^ 1);
+            {
+                KernelSpan sp(c, "k_radix_hist");
+                qmcp::launch_radix_hist(c->stream, true, c->keys[kin].p, n, 8 * p, (uint32_t*)c->hist.p);
+            }
+            {
+                KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+                qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)c->hist.p, 256u * n_tiles,
+                                            (uint32_t*)c->hist.p, (uint32_t*)c->spine.p, false);
+            }
+            {
+                KernelSpan sp(c, "k_radix_scatter");
+                qmcp::launch_radix_scatter(c->stream, true, c->keys[kin].p, vals_in, n, 8 * p,
+                                           (const uint32_t*)c->hist.p, c->keys[kout].p,
+                                           (uint32_t*)c->vals[vout].p);
+            }
+            HIP_TRY(hipGetLastError());
+            kin = kout;
+            vin = vout;
+            vals_in = (const uint32_t*)c->vals[vin].p;
         }
-        {
-            KernelSpan sp(c, "k_radix_scatter");
-            qmcp::launch_radix_scatter(c->stream, wide, c->keys[kin].p, vals_in, n, 8 * p,
-                                       (const uint32_t*)c->hist.p, c->keys[kout].p,
-                                       (uint32_t*)c->vals[vout].p);
-        }
-        HIP_TRY(hipGetLastError());
-        kin = kout;
-        vin = vout;
-        vals_in = (const uint32_t*)c->vals[vin].p;
     }
+    // bucket offsets straight from the sorted keys (no atomics)
+    HIP_TRY(hipMemsetAsync(c->boff.p, 0xFF, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
+    {
+        KernelSpan sp(c, "k_bucket_heads");
+        qmcp::launch_bucket_heads(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n,
+                                  span_bits, ltot, (uint32_t*)c->boff.p);
+    }
+    {
+        KernelSpan sp(c, "reverse_min_scan(3 kernels)");
+        qmcp::launch_reverse_min_scan(c->stream, (uint32_t*)c->boff.p, ltot + 1, (uint32_t*)c->spine.p);
+    }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_SORT], c->stream));
 
     // selection sweep
@@ -432,11 +465,11 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     TRY(upload_tables(c, roff, pr));
     uint32_t hs[3];
     TRY(run_prepare(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, pr, d_keep,
-                    true, hs));
+                    true, true, hs));
     TRY(scan_counts(c, c->cstart, c->boff, ltot));
     TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
-    qmcp::launch_general_keys(c->stream, false, (const uint32_t*)c->keys[0].p,
+    qmcp::launch_general_keys(c->stream, false, (const uint32_t*)c->vals[1].p,
                               (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, n, 0,
                               hs[1], d_keep, nullptr, (uint32_t*)c->ecnt.p);
     HIP_TRY(hipGetLastError());

@@ -33,8 +33,16 @@ void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
                           uint32_t ring_size);
-void launch_mark(hipStream_t st, bool wide, const void* skeys, const uint32_t* svals, uint32_t n,
+// `sorted` is a Rec{key,val} array (wide == false) or u64 keys with `svals` beside them
+void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
                  uint32_t span_bits, const uint32_t* selend, uint64_t* mask);
+void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
+                         uint32_t n, uint32_t span_bits, uint32_t ltot, uint32_t* boff);
+void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_t* spine);
+void launch_radix_hist_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs,
+                           uint32_t n, uint32_t shift, uint32_t* hist);
+void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
+                              uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out);
 void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
                      unsigned long long* out);
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,

@@ -371,6 +371,222 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
     }
 }
 
+// ------------------------------------------------------------------ record radix (32-bit keys)
+// Same stable LSD pass on {key, read index} records (one 8-byte store per element), with the
+// tile reordered through LDS so that consecutive lanes store to consecutive addresses: a
+// tile's elements of one digit leave as one contiguous run.  The first pass reads bare keys
+// (the payload is the element's own index).
+struct Rec { uint32_t key, val; };
+
+template <bool FIRST>
+__device__ __forceinline__ uint32_t rec_key(const uint32_t* __restrict__ keys,
+                                            const Rec* __restrict__ recs, uint32_t i) {
+    if (FIRST) return keys[i];
+    return recs[i].key;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist_rec(const uint32_t* __restrict__ keys,
+                                                                  const Rec* __restrict__ recs,
+                                                                  uint32_t n, uint32_t shift,
+                                                                  uint32_t n_tiles,
+                                                                  uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t i = base + k * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(rec_key<FIRST>(keys, recs, i) >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];  // digit-major
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
+    const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, uint32_t n, uint32_t shift,
+    uint32_t n_tiles, const uint32_t* __restrict__ offs, Rec* __restrict__ recs_out) {
+    __shared__ uint32_t s_cnt[4][256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ Rec s_rec[kSortTile];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t tile_base = blockIdx.x * kSortTile;
+    const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
+    const uint32_t wbase = tile_base + w * (kSortItems * 64);
+    Rec rec[kSortItems];
+    uint32_t rank[kSortItems];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < n;
+        if (FIRST) { rec[k].key = valid ? keys[i] : 0u; rec[k].val = i; }
+        else { rec[k] = valid ? recs_in[i] : Rec{0u, 0u}; }
+        const uint32_t d = (rec[k].key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t in_group = __popcll(peers & lt_mask);
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = s_cnt[w][d];
+            s_cnt[w][d] = old + __popcll(peers);
+        }
+        old = (uint32_t)__shfl((int)old, leader, kWave);
+        rank[k] = old + in_group;
+    }
+    __syncthreads();
+    {
+        // digit = threadIdx.x: position of (wave, digit) inside the tile's digit-sorted order,
+        // and the global base of the digit's run
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+        uint32_t tot;
+        const uint32_t tile_off = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, tot);
+        s_cnt[0][d] = tile_off;
+        s_cnt[1][d] = tile_off + c0;
+        s_cnt[2][d] = tile_off + c0 + c1;
+        s_cnt[3][d] = tile_off + c0 + c1 + c2;
+        s_gbase[d] = offs[d * n_tiles + blockIdx.x] - tile_off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (rec[k].key >> shift) & 255u;
+            s_rec[s_cnt[w][d] + rank[k]] = rec[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t j = k * kSortThreads + threadIdx.x;
+        if (j < tile_count) {
+            const Rec r = s_rec[j];
+            const uint32_t d = (r.key >> shift) & 255u;
+            recs_out[s_gbase[d] + j] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ bucket offsets from sorted keys
+// boff[q] = first sorted entry whose start position is >= q.  Run heads write their own
+// slot (boff pre-filled with 0xFFFFFFFF, boff[ltot] = n); a reverse inclusive min-scan then
+// fills the positions nobody starts at.  No atomics, any gap structure.
+struct KeysRec { const Rec* r; __device__ uint32_t pos(uint32_t j, uint32_t sb) const { return r[j].key >> sb; }
+                 __device__ uint32_t idx(uint32_t j) const { return r[j].val; } };
+struct KeysSplit64 { const uint64_t* k; const uint32_t* v;
+                     __device__ uint32_t pos(uint32_t j, uint32_t sb) const { return (uint32_t)(k[j] >> sb); }
+                     __device__ uint32_t idx(uint32_t j) const { return v[j]; } };
+
+template <typename Keys>
+__global__ __launch_bounds__(256) void k_bucket_heads(Keys keys, uint32_t n, uint32_t span_bits,
+                                                      uint32_t ltot, uint32_t* __restrict__ boff) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t q = keys.pos(j, span_bits);
+        if (j == 0 || keys.pos(j - 1, span_bits) != q) boff[q] = j;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) boff[ltot] = n;
+}
+
+// reverse inclusive min-scan, in place: data[i] = min(data[i .. n-1]).  Implemented as a
+// forward scan over mirrored indices m -> n-1-m.
+__global__ __launch_bounds__(kScanThreads) void k_rmin_tile_mins(const uint32_t* __restrict__ data,
+                                                                  uint32_t n,
+                                                                  uint32_t* __restrict__ tile_mins) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint32_t acc = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t m = base + k * kScanThreads + threadIdx.x;
+        if (m < n) acc = min(acc, data[n - 1 - m]);
+    }
+    acc = wave_min_u32(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_mins[blockIdx.x] = min(min(s_wave[0], s_wave[1]), min(s_wave[2], s_wave[3]));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_min_full(uint32_t v) {
+    const uint32_t id = 0xFFFFFFFFu;
+    v = min(v, QMCP_DPP(id, v, 0x111, 0xF));
+    v = min(v, QMCP_DPP(id, v, 0x112, 0xF));
+    v = min(v, QMCP_DPP(id, v, 0x114, 0xF));
+    v = min(v, QMCP_DPP(id, v, 0x118, 0xF));
+    v = min(v, QMCP_DPP(id, v, 0x142, 0xA));
+    v = min(v, QMCP_DPP(id, v, 0x143, 0xC));
+    return v;
+}
+// exclusive min-scan across the 256 threads of a block (identity 0xFFFFFFFF)
+__device__ __forceinline__ uint32_t block_excl_minscan_256(uint32_t v, uint32_t* s_wave,
+                                                           uint32_t& block_min) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan_min_full(v);
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t before = 0xFFFFFFFFu, all = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = s_wave[k];
+        if (k < w) before = min(before, x);
+        all = min(all, x);
+    }
+    block_min = all;
+    __syncthreads();
+    uint32_t prev = QMCP_DPP(0xFFFFFFFFu, inc, 0x138, 0xF);  // wave_shr:1
+    return min(before, prev);
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_rmin_spine(uint32_t* __restrict__ spine,
+                                                              uint32_t n_tiles) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? spine[i] : 0xFFFFFFFFu;
+        uint32_t all;
+        const uint32_t ex = block_excl_minscan_256(v, s_wave, all);
+        if (i < n_tiles) spine[i] = min(carry, ex);
+        carry = min(carry, all);
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_rmin_tiles(uint32_t* __restrict__ data, uint32_t n,
+                                                              const uint32_t* __restrict__ spine) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t m = base + k;
+        v[k] = m < n ? data[n - 1 - m] : 0xFFFFFFFFu;
+        mn = min(mn, v[k]);
+    }
+    uint32_t all;
+    uint32_t run = min(spine[blockIdx.x], block_excl_minscan_256(mn, s_wave, all));
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t m = base + k;
+        run = min(run, v[k]);
+        if (m < n) data[n - 1 - m] = run;
+    }
+}
+
 // ------------------------------------------------------------------ uniform-span sweep
 // All reads of the call have span `ell`.  With W(p) = #dropped reads with start <= p the
 // canonical greedy (oracle/qmcp_oracle.c) is the pointwise-maximal W under
@@ -379,13 +595,144 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
 // i.e. single-source shortest paths on a line graph with edges p-1 -> p (c(p)),
 // p-ell -> p (ex(p)) and p -> p-1 (0).  Distances obey
 //     d(p) = min( d(p-1) + c(p),  min_{j in [p-ell, p-1]} ( d(j) + ex(j+ell) ) )
-// Positions are processed in blocks of `ell`; the window minimum splits into a suffix
-// minimum over the previous block (held in registers, same lane/slot) and a prefix minimum
-// inside the block, resolved by a short fixed-point iteration of wave-wide scans.
+// Positions are processed in blocks of `ell`.  The window minimum splits into
+//     A(p) = suffix minimum over the previous block of h(j) = d(j) + ex(j+ell)
+//            (held in registers: same lane, same slot as p), and
+//     m(p) = running minimum of h over the current block before p.
+// Carrying (d, m) turns one position into the min-plus map
+//     d' = min(d + c, m, A)          m' = min(m, d' + ex) = min(d + c + ex, m, A + ex)
+// and maps of the form  d' = min(d + a, m, u),  m' = min(d + b, m, v)  (b >= a, v >= u) are
+// closed under composition:
+//     a = min(a1 + a2, b1)   b = min(a1 + b2, b1)
+//     u = min(u1 + a2, v1, u2)   v = min(u1 + b2, v1, v2)
+// so a block is ONE wave-wide inclusive scan of 4-tuples (DPP row shifts + row broadcasts),
+// a lane-local replay, and a suffix-min for the next block -- no iteration, no LDS.
 // Selected count at p: S(p) = c(p) - (d(p) - d(p-1)); the kept reads of a start position are
 // its S(p) lowest read indices (all ends are equal, so the rule's tie-break is the index).
 //
-// One wave per contig; local index i = lane * E + r, valid while i < ell.
+// One wave per contig; local index i = lane * E + r, valid while i < ell.  Loads of block
+// b+1 are issued before block b is computed (the chain is latency-bound).
+struct Map4 { uint32_t a, b, u, v; };
+__device__ __forceinline__ Map4 map_identity() { return Map4{0u, kInf, kInf, kInf}; }
+__device__ __forceinline__ Map4 map_compose(const Map4& f, const Map4& g) {  // f first, then g
+    Map4 r;
+    r.a = min(f.a + g.a, f.b);
+    r.b = min(sat_add(f.a, g.b), f.b);
+    r.u = min(min(sat_add(f.u, g.a), f.v), g.u);
+    r.v = min(min(sat_add(f.u, g.b), f.v), g.v);
+    return r;
+}
+__device__ __forceinline__ Map4 wave_incl_scan_map(Map4 x) {
+#define QMCP_STEP(ctrl, rmask)                                  \
+    {                                                           \
+        Map4 p;                                                 \
+        p.a = QMCP_DPP(0u, x.a, ctrl, rmask);                   \
+        p.b = QMCP_DPP(kInf, x.b, ctrl, rmask);                 \
+        p.u = QMCP_DPP(kInf, x.u, ctrl, rmask);                 \
+        p.v = QMCP_DPP(kInf, x.v, ctrl, rmask);                 \
+        x = map_compose(p, x);                                  \
+    }
+    QMCP_STEP(0x111, 0xF)
+    QMCP_STEP(0x112, 0xF)
+    QMCP_STEP(0x114, 0xF)
+    QMCP_STEP(0x118, 0xF)
+    QMCP_STEP(0x142, 0xA)
+    QMCP_STEP(0x143, 0xC)
+#undef QMCP_STEP
+    return x;
+}
+// min over lanes strictly above this lane (kInf for lane 63)
+__device__ __forceinline__ uint32_t wave_excl_suffix_min(uint32_t t) {
+    uint32_t s = t;
+    s = min(s, QMCP_DPP(kInf, s, 0x101, 0xF));  // row_shl:1
+    s = min(s, QMCP_DPP(kInf, s, 0x102, 0xF));
+    s = min(s, QMCP_DPP(kInf, s, 0x104, 0xF));
+    s = min(s, QMCP_DPP(kInf, s, 0x108, 0xF));
+    const uint32_t r1 = __builtin_amdgcn_readlane(s, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane(s, 32);
+    const uint32_t r3 = __builtin_amdgcn_readlane(s, 48);
+    const uint32_t row = (threadIdx.x & 63) >> 4;
+    const uint32_t later = row == 0 ? min(r1, min(r2, r3)) : row == 1 ? min(r2, r3) : row == 2 ? r3 : kInf;
+    s = min(s, later);                           // inclusive suffix min
+    return QMCP_DPP(kInf, s, 0x130, 0xF);        // wave_shl:1 -> exclusive
+}
+
+template <int E>
+struct SweepLoads { uint32_t x0[E], x1[E], x2[E]; };
+
+// Unconditional loads with clamped addresses (boff has ltot + 1 entries, base + L is always
+// in range): every lane issues the same number of loads, so the compiler can keep the next
+// block's loads in flight behind a counted s_waitcnt instead of draining them.
+template <int E>
+__device__ __forceinline__ void sweep_load(const uint32_t* __restrict__ boff, uint32_t base,
+                                           uint32_t a, uint32_t ell, uint32_t L, uint32_t lane,
+                                           SweepLoads<E>& o) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t p = a + lane * E + r;
+        o.x0[r] = boff[base + min(p, L)];
+        o.x1[r] = boff[base + min(p + 1, L)];
+        o.x2[r] = boff[base + min(p + ell + 1, L)];
+    }
+}
+
+// One block of `ell` positions starting at contig position a.  State carried between blocks:
+// sufA (suffix-min of the previous block's h per slot) and d_last.
+template <int E>
+__device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a, uint32_t base,
+                                            uint32_t ell, uint32_t L, uint32_t M, uint32_t lane,
+                                            uint32_t last_lane, uint32_t last_r,
+                                            uint32_t (&sufA)[E], uint32_t& d_last,
+                                            uint32_t* __restrict__ selend) {
+    uint32_t cnt[E], exj[E];
+    Map4 acc = map_identity();
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t p = a + i;
+        const bool valid = i < ell && p < L;
+        const uint32_t cov = cur.x2[r] - cur.x1[r];
+        cnt[r] = valid ? cur.x1[r] - cur.x0[r] : 0u;
+        exj[r] = (valid && p + ell < L) ? (cov > M ? cov - M : 0u) : kInf;
+        Map4 e;
+        e.a = cnt[r];
+        e.b = sat_add(cnt[r], exj[r]);
+        e.u = sufA[r];
+        e.v = sat_add(sufA[r], exj[r]);
+        acc = map_compose(acc, e);
+    }
+    Map4 inc = wave_incl_scan_map(acc);
+    Map4 pre;  // composition of all lower lanes (identity for lane 0)
+    pre.a = QMCP_DPP(0u, inc.a, 0x138, 0xF);  // wave_shr:1
+    pre.b = QMCP_DPP(kInf, inc.b, 0x138, 0xF);
+    pre.u = QMCP_DPP(kInf, inc.u, 0x138, 0xF);
+    pre.v = QMCP_DPP(kInf, inc.v, 0x138, 0xF);
+    // state entering this lane: (d, m) = pre applied to (d_last, +inf)
+    uint32_t d = min(sat_add(d_last, pre.a), pre.u);
+    uint32_t m = min(sat_add(d_last, pre.b), pre.v);
+    uint32_t h[E];
+    uint32_t pick = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t p = a + i;
+        const uint32_t dn = min(min(sat_add(d, cnt[r]), m), sufA[r]);
+        h[r] = sat_add(dn, exj[r]);
+        m = min(m, h[r]);
+        if (i < ell && p < L) selend[base + p] = cur.x0[r] + (cnt[r] - (dn - d));
+        d = dn;
+        if ((uint32_t)r == last_r) pick = dn;
+    }
+    d_last = __builtin_amdgcn_readlane(pick, last_lane);
+    uint32_t run = kInf;
+    uint32_t hv[E];
+#pragma unroll
+    for (int r = E - 1; r >= 0; --r) { run = min(run, h[r]); hv[r] = run; }
+    const uint32_t after = wave_excl_suffix_min(run);
+#pragma unroll
+    for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
+}
+
 template <int E>
 __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict__ boff,
                                                       const uint64_t* __restrict__ contig_pos_off,
@@ -403,126 +750,37 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     // virtual block -1: d == 0 and the jump from j = i - ell lands on p = i
     {
         uint32_t hv[E];
+        const uint32_t b0 = boff[base];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const uint32_t i = lane * E + r;
-            hv[r] = kInf;
-            if (i < ell && i < L) {
-                const uint32_t cov = boff[base + i + 1] - boff[base];
-                hv[r] = cov > M ? cov - M : 0u;
-            }
+            const uint32_t cov = boff[base + min(i + 1, L)] - b0;
+            hv[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
         }
         uint32_t run = kInf;
 #pragma unroll
         for (int r = E - 1; r >= 0; --r) { run = min(run, hv[r]); hv[r] = run; }
-        // suffix over lanes: reverse, inclusive scan, reverse, then make it exclusive
-        uint32_t rev = (uint32_t)__shfl((int)run, 63 - (int)lane, kWave);
-        rev = wave_incl_scan_min(rev);
-        uint32_t after = (uint32_t)__shfl((int)rev, 63 - (int)lane - 1 < 0 ? 0 : 63 - (int)lane - 1, kWave);
-        if (lane == 63) after = kInf;
+        const uint32_t after = wave_excl_suffix_min(run);
 #pragma unroll
         for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
     }
     uint32_t d_last = 0;
-    uint32_t total_iters = 0;
+    const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
 
-    for (uint32_t b = 0; b < n_blocks; ++b) {
+    // Two register sets, alternated, so the loads of block b+1 stay in flight while block b
+    // is computed (no register copies between iterations; loads past the contig end clamp).
+    SweepLoads<E> A, B;
+    sweep_load<E>(boff, base, 0, ell, L, lane, A);
+    for (uint32_t b = 0; b < n_blocks; b += 2) {
         const uint32_t a = b * ell;
-        uint32_t cnt[E], exj[E], x0[E];
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint32_t i = lane * E + r;
-            const uint32_t p = a + i;
-            cnt[r] = 0; exj[r] = kInf; x0[r] = 0;
-            if (i < ell && p < L) {
-                const uint32_t v0 = boff[base + p];
-                const uint32_t v1 = boff[base + p + 1];
-                x0[r] = v0;
-                cnt[r] = v1 - v0;
-                const uint32_t t = p + ell;  // landing position of the jump from p
-                if (t < L) {
-                    const uint32_t cov = boff[base + t + 1] - v1;
-                    exj[r] = cov > M ? cov - M : 0u;
-                }
-            }
-        }
-        uint32_t intra[E], d[E], h[E];
-#pragma unroll
-        for (int r = 0; r < E; ++r) intra[r] = kInf;
-        uint32_t d_in = 0;
-        for (;;) {
-            ++total_iters;
-            // compose the lane's maps, scan across lanes, then replay inside the lane
-            uint32_t cs = 0, bs = kInf;
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const uint32_t bb = min(sufA[r], intra[r]);
-                bs = min(sat_add(bs, cnt[r]), bb);
-                cs += cnt[r];
-            }
-            uint32_t sc = cs, sb = bs;
-            wave_incl_scan_affine(sc, sb);
-            uint32_t pc = wave_shift_up1(sc, 0u);
-            uint32_t pb = wave_shift_up1(sb, kInf);
-            uint32_t x = min(sat_add(d_last, pc), pb);
-            d_in = x;
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const uint32_t bb = min(sufA[r], intra[r]);
-                x = min(sat_add(x, cnt[r]), bb);
-                d[r] = x;
-                h[r] = exj[r] >= kInf ? kInf : sat_add(x, exj[r]);
-            }
-            // exclusive prefix-min of h over the block
-            uint32_t lmin = kInf;
-#pragma unroll
-            for (int r = 0; r < E; ++r) lmin = min(lmin, h[r]);
-            uint32_t before = wave_shift_up1(wave_incl_scan_min(lmin), kInf);
-            bool changed = false;
-            uint32_t run = before;
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const uint32_t old_eff = min(sufA[r], intra[r]);
-                const uint32_t new_eff = min(sufA[r], run);
-                changed |= (new_eff != old_eff);
-                intra[r] = run;
-                run = min(run, h[r]);
-            }
-            if (!__any(changed)) break;
-        }
-        // emit selected counts, carry state to the next block
-        uint32_t prev = d_in;
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint32_t i = lane * E + r;
-            const uint32_t p = a + i;
-            if (i < ell && p < L) selend[base + p] = x0[r] + (cnt[r] - (d[r] - prev));
-            prev = d[r];
-        }
-        // d at local index ell-1
-        {
-            const uint32_t li = ell - 1;
-            const uint32_t src_lane = li / E, src_r = li % E;
-            uint32_t pick = 0;
-#pragma unroll
-            for (int r = 0; r < E; ++r) if ((uint32_t)r == src_r) pick = d[r];
-            d_last = (uint32_t)__shfl((int)pick, (int)src_lane, kWave);
-        }
-        {
-            uint32_t run = kInf;
-            uint32_t hv[E];
-#pragma unroll
-            for (int r = E - 1; r >= 0; --r) { run = min(run, h[r]); hv[r] = run; }
-            uint32_t rev = (uint32_t)__shfl((int)run, 63 - (int)lane, kWave);
-            rev = wave_incl_scan_min(rev);
-            uint32_t after = (uint32_t)__shfl((int)rev, lane == 63 ? 0 : 62 - (int)lane, kWave);
-            if (lane == 63) after = kInf;
-#pragma unroll
-            for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
-        }
+        sweep_load<E>(boff, base, a + ell, ell, L, lane, B);
+        sweep_block<E>(A, a, base, ell, L, M, lane, last_lane, last_r, sufA, d_last, selend);
+        sweep_load<E>(boff, base, a + 2 * ell, ell, L, lane, A);
+        if (b + 1 < n_blocks)
+            sweep_block<E>(B, a + ell, base, ell, L, M, lane, last_lane, last_r, sufA, d_last, selend);
     }
     if (iter_stats && lane == 0) {
-        atomicAdd(&iter_stats[0], total_iters);
+        atomicAdd(&iter_stats[0], n_blocks);
         atomicAdd(&iter_stats[1], n_blocks);
     }
 }
@@ -536,10 +794,13 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
 // LDS: the prefix pointer of every bucket still inside the window, and the number of
 // selected reads by end position (what stops covering when the sweep passes that end).
 // A bucket's pointer is flushed to selend (as an absolute offset) when its slot is recycled.
-template <typename KeyT>
+struct SortedRec { const Rec* r; __device__ uint64_t key(uint32_t j) const { return r[j].key; } };
+struct SortedK64 { const uint64_t* k; __device__ uint64_t key(uint32_t j) const { return k[j]; } };
+
+template <typename Sorted>
 __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict__ boff,
                                                       const uint32_t* __restrict__ eoff,
-                                                      const KeyT* __restrict__ skeys,
+                                                      Sorted skeys,
                                                       const uint64_t* __restrict__ contig_pos_off,
                                                       uint32_t span_bits, uint32_t max_span,
                                                       uint32_t M, uint32_t* __restrict__ selend,
@@ -552,7 +813,7 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
     const uint32_t base = (uint32_t)contig_pos_off[c_id];
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
     const uint32_t rmask = ring_size - 1;
-    const KeyT code_mask = (((KeyT)1) << span_bits) - 1;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
     for (uint32_t i = lane; i < 2 * ring_size; i += 64) s_ring[i] = 0;
     __syncthreads();
     uint32_t cur = 0;
@@ -578,7 +839,7 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
                 const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
                 const uint32_t ptr = s_ptr[q & rmask];
                 if (b0 + ptr < b1) {
-                    const KeyT key = skeys[b0 + ptr];
+                    const uint64_t key = skeys.key(b0 + ptr);
                     const uint32_t span = max_span - (uint32_t)(key & code_mask);
                     const uint32_t end = q + span - 1;
                     if (end >= p) {
@@ -599,7 +860,7 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
             bool same = false;
             const uint32_t j = b0 + ptr + lane;
             if (j < b1) {
-                const KeyT key = skeys[j];
+                const uint64_t key = skeys.key(j);
                 const uint32_t span = max_span - (uint32_t)(key & code_mask);
                 same = (bq + span - 1) == bend;
             }
@@ -626,27 +887,18 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
     const uint32_t first = L > ring_size ? L - ring_size : 0u;
     for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + s_ptr[q & rmask];
 }
-template __global__ void k_sweep_general<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
-                                                   const uint64_t*, uint32_t, uint32_t, uint32_t,
-                                                   uint32_t*, uint32_t);
-template __global__ void k_sweep_general<uint64_t>(const uint32_t*, const uint32_t*, const uint64_t*,
-                                                   const uint64_t*, uint32_t, uint32_t, uint32_t,
-                                                   uint32_t*, uint32_t);
-
 // ------------------------------------------------------------------ keep-mask emission
 // sorted entry j (bucket = its start position) is kept iff j < selend[bucket].
 // obtain_sequence counterpart (quasi_mcp_cpu_max_flow_solver.cpp:89-100).
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_mark(const KeyT* __restrict__ skeys,
-                                              const uint32_t* __restrict__ svals, uint32_t n,
-                                              uint32_t span_bits,
+template <typename Keys>
+__global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t n, uint32_t span_bits,
                                               const uint32_t* __restrict__ selend,
                                               uint32_t* __restrict__ mask32) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint32_t q = (uint32_t)(skeys[j] >> span_bits);
+        const uint32_t q = keys.pos(j, span_bits);
         if (j < selend[q]) {
-            const uint32_t idx = svals[j];
+            const uint32_t idx = keys.idx(j);
             atomicOr(&mask32[idx >> 5], 1u << (idx & 31));
         }
     }
@@ -832,31 +1084,76 @@ bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* 
 }
 
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
-                          const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
+                          const void* sorted, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
                           uint32_t ring_size) {
     const size_t lds = 2 * (size_t)ring_size * sizeof(uint32_t);
     if (wide) {
-        (void)hipFuncSetAttribute((const void*)k_sweep_general<uint64_t>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<uint64_t>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
-                           (const uint64_t*)skeys, d_poff, span_bits, max_span, M, selend, ring_size);
+        (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedK64>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general<SortedK64>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+                           SortedK64{(const uint64_t*)sorted}, d_poff, span_bits, max_span, M, selend,
+                           ring_size);
     } else {
-        (void)hipFuncSetAttribute((const void*)k_sweep_general<uint32_t>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<uint32_t>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
-                           (const uint32_t*)skeys, d_poff, span_bits, max_span, M, selend, ring_size);
+        (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedRec>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general<SortedRec>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+                           SortedRec{(const Rec*)sorted}, d_poff, span_bits, max_span, M, selend,
+                           ring_size);
     }
 }
 
-void launch_mark(hipStream_t st, bool wide, const void* skeys, const uint32_t* svals, uint32_t n,
+void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
                  uint32_t span_bits, const uint32_t* selend, uint64_t* mask) {
     if (wide)
-        hipLaunchKernelGGL(k_mark<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           (const uint64_t*)skeys, svals, n, span_bits, selend, (uint32_t*)mask);
+        hipLaunchKernelGGL(k_mark<KeysSplit64>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           KeysSplit64{(const uint64_t*)sorted, svals}, n, span_bits, selend,
+                           (uint32_t*)mask);
     else
-        hipLaunchKernelGGL(k_mark<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           (const uint32_t*)skeys, svals, n, span_bits, selend, (uint32_t*)mask);
+        hipLaunchKernelGGL(k_mark<KeysRec>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           KeysRec{(const Rec*)sorted}, n, span_bits, selend, (uint32_t*)mask);
+}
+
+void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
+                         uint32_t n, uint32_t span_bits, uint32_t ltot, uint32_t* boff) {
+    if (wide)
+        hipLaunchKernelGGL(k_bucket_heads<KeysSplit64>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           KeysSplit64{(const uint64_t*)sorted, svals}, n, span_bits, ltot, boff);
+    else
+        hipLaunchKernelGGL(k_bucket_heads<KeysRec>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           KeysRec{(const Rec*)sorted}, n, span_bits, ltot, boff);
+}
+
+void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_t* spine) {
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    if (n_tiles == 0) return;
+    hipLaunchKernelGGL(k_rmin_tile_mins, dim3(n_tiles), dim3(kScanThreads), 0, st, data, n, spine);
+    hipLaunchKernelGGL(k_rmin_spine, dim3(1), dim3(kScanThreads), 0, st, spine, n_tiles);
+    hipLaunchKernelGGL(k_rmin_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, data, n, spine);
+}
+
+void launch_radix_hist_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs,
+                           uint32_t n, uint32_t shift, uint32_t* hist) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    if (first)
+        hipLaunchKernelGGL(k_radix_hist_rec<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs, n, shift, n_tiles, hist);
+    else
+        hipLaunchKernelGGL(k_radix_hist_rec<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs, n, shift, n_tiles, hist);
+}
+
+void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
+                              uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    if (first)
+        hipLaunchKernelGGL(k_radix_scatter_rec<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs_in, n, shift, n_tiles, offs, (Rec*)recs_out);
+    else
+        hipLaunchKernelGGL(k_radix_scatter_rec<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs_in, n, shift, n_tiles, offs, (Rec*)recs_out);
 }
 
 void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
