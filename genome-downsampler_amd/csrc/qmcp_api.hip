@@ -54,8 +54,10 @@ struct qmcp_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t ev_in = nullptr;
+    hipStream_t stream2 = nullptr;  // counting + sweep run here, beside the radix passes
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // arena (grow-only, reused across solves like a reference solver instance's members)
-    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist;
+    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp;
     DevBuf scalars;  // popcount + sweep iteration counters
@@ -87,15 +89,17 @@ struct KernelSpan {
     qmcp_hip_ctx* c;
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
-    KernelSpan(qmcp_hip_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+    hipStream_t st;
+    KernelSpan(qmcp_hip_ctx* ctx, const char* nm, hipStream_t stream = nullptr)
+        : c(ctx), name(nm), st(stream ? stream : ctx->stream) {
         if (!c->profiling) return;
         a = pool_event(c);
         b = pool_event(c);
-        if (a) (void)hipEventRecord(a, c->stream);
+        if (a) (void)hipEventRecord(a, st);
     }
     ~KernelSpan() {
         if (!c->profiling || !a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->spans.push_back({name, a, b});
     }
 };
@@ -254,6 +258,9 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
+        TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
+        TRY(ensure(c, c->hist2, (size_t)256 * tiles * sizeof(uint32_t)));
+        TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->scalars, 64));
@@ -273,6 +280,11 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         return fail(QMCP_ERANGE, "mixed-span reads with span %u > %u are not supported by this build",
                     max_span, qmcp::kMaxGeneralSpan);
     local.path = uniform ? QMCP_PATH_UNIFORM : QMCP_PATH_GENERAL;
+    if (uniform)
+        for (uint32_t k = 0; k < n_contigs; ++k)
+            if (roff[k + 1] - roff[k] >= (1ull << 28))
+                return fail(QMCP_ERANGE, "contig %u holds %llu reads; the block sweep handles < 2^28 per contig",
+                            k, (unsigned long long)(roff[k + 1] - roff[k]));
 
     // bucketing keys.  gstart (global start position per read) sits in vals[1].
     const uint32_t pos_bits = bit_width(ltot - 1) == 0 ? 1u : bit_width(ltot - 1);
@@ -297,6 +309,55 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         d_key32 = (const uint32_t*)c->vals[0].p;
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
+
+    // Uniform span: the sweep needs only reads-per-position counts, not the sorted order, so
+    // counts are produced early (key partition + LDS histograms) and the sweep runs on a second
+    // stream beside the radix passes.  Worth it only for problems large enough to fill the chip.
+    const bool overlap = uniform && n >= (1u << 22) && qmcp::early_counts_supported(ltot);
+    uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
+    if (overlap) {
+        // counts first, alone on the main stream (bandwidth-bound, ~1/5 of the sort) ...
+        hipStream_t s1 = c->stream;
+        {
+            KernelSpan sp(c, "k_radix_hist_rec(count partition)");
+            qmcp::launch_count_partition_hist(s1, d_key32, n, (uint32_t*)c->hist2.p);
+        }
+        {
+            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
+                                        (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
+        }
+        {
+            KernelSpan sp(c, "k_radix_scatter_rec(count partition)");
+            qmcp::launch_count_partition_scatter(s1, d_key32, n, (const uint32_t*)c->hist2.p,
+                                                 (uint32_t*)c->vals[0].p);
+        }
+        {
+            KernelSpan sp(c, "k_lds_count");
+            qmcp::launch_lds_count(s1, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->hist2.p, n,
+                                   ltot, (uint32_t*)c->cstart.p);
+        }
+        {
+            KernelSpan sp(c, "scan_positions(3 kernels)");
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->cstart.p, ltot, (uint32_t*)c->boff.p,
+                                        (uint32_t*)c->spine2.p, true);
+        }
+        HIP_TRY(hipGetLastError());
+        // ... then the latency-bound sweep (one wave per contig) on the high-priority stream,
+        // beside the radix passes that follow on the main stream
+        hipStream_t s2 = c->stream2;
+        HIP_TRY(hipEventRecord(c->ev_fork, s1));
+        HIP_TRY(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        {
+            KernelSpan sp(c, "k_sweep_uniform", s2);
+            if (!qmcp::launch_sweep_uniform(s2, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
+                                            n_contigs, max_span, M, (uint32_t*)c->selend.p, d_iters))
+                return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_join, s2));
+    }
 
     // radix bucketing: stable LSD, 8-bit digits
     const uint32_t key_bits = pos_bits + span_bits;
@@ -356,6 +417,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         }
     }
     // bucket offsets straight from the sorted keys (no atomics)
+    if (!overlap) {
     HIP_TRY(hipMemsetAsync(c->boff.p, 0xFF, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
     {
         KernelSpan sp(c, "k_bucket_heads");
@@ -366,15 +428,14 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         KernelSpan sp(c, "reverse_min_scan(3 kernels)");
         qmcp::launch_reverse_min_scan(c->stream, (uint32_t*)c->boff.p, ltot + 1, (uint32_t*)c->spine.p);
     }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_SORT], c->stream));
 
     // selection sweep
-    TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
-    TRY(ensure(c, c->scalars, 64));
-    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
-    uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
-    if (uniform) {
+    if (overlap) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // sweep ran on stream2
+    } else if (uniform) {
         KernelSpan sp(c, "k_sweep_uniform");
         if (!qmcp::launch_sweep_uniform(c->stream, (const uint32_t*)c->boff.p,
                                         (const uint64_t*)c->poff.p, n_contigs, max_span, M,
@@ -517,6 +578,13 @@ int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < EV_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;  // numerically lower == higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         qmcp_hip_destroy(c);
         return fail(QMCP_EHIP, "context setup: %s", hipGetErrorString(e));
@@ -529,8 +597,9 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
-                      &c->selend, &c->spine, &c->hist, &c->keys[0], &c->keys[1], &c->vals[0],
+                      &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
                       &c->cov, &c->amp, &c->scalars};
     for (DevBuf* b : bufs)
@@ -540,6 +609,9 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -54,5 +54,13 @@ void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32
                             uint32_t n_amp, uint32_t min_length, uint32_t min_mapq,
                             uint64_t* pair_keep);
 
+// early counts (uniform path): reads per start position from a key partition + LDS histograms
+bool early_counts_supported(uint32_t ltot);
+void launch_count_partition_hist(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t* hist);
+void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
+                                    const uint32_t* offs, uint32_t* part_keys);
+void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,
+                      uint32_t ltot, uint32_t* cstart);
+
 }  // namespace qmcp
 #endif

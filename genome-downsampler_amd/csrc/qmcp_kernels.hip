@@ -18,7 +18,12 @@
 namespace qmcp {
 
 static constexpr int kWave = 64;
-static constexpr uint32_t kInf = 0x7FFFFFFFu;  // "no constraint"; real counts stay < 2^30
+// "no constraint".  Real counts stay < 2^28 per contig (checked by the host).  In the map
+// algebra below b, u and v never accumulate (a composite's b is <= its first element's b, its
+// u and v are <= its last element's), so the largest intermediate is u + b <= 2 kInf + 2^29
+// < 2^32: nothing wraps, no saturation is needed, and anything >= kInf just means "infinite"
+// (every finite value is < 2^29 < kInf).
+static constexpr uint32_t kInf = 0x40000000u;
 
 // ------------------------------------------------------------------ wave primitives
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -385,100 +390,142 @@ __device__ __forceinline__ uint32_t rec_key(const uint32_t* __restrict__ keys,
     return recs[i].key;
 }
 
+// A workgroup handles `tiles_per_block` consecutive tiles so that its accesses to the
+// digit-major table (stride n_tiles between digits) touch runs of consecutive entries.
 template <bool FIRST>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist_rec(const uint32_t* __restrict__ keys,
                                                                   const Rec* __restrict__ recs,
                                                                   uint32_t n, uint32_t shift,
                                                                   uint32_t n_tiles,
+                                                                  uint32_t tiles_per_block,
                                                                   uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_h[256];
-    s_h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * kSortTile;
+    const uint32_t t0 = blockIdx.x * tiles_per_block;
+    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t base = (t0 + g) * kSortTile;
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        uint32_t i = base + k * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[(rec_key<FIRST>(keys, recs, i) >> shift) & 255u], 1u);
+        for (int k = 0; k < kSortItems; ++k) {
+            uint32_t i = base + k * kSortThreads + threadIdx.x;
+            if (i < n) atomicAdd(&s_h[(rec_key<FIRST>(keys, recs, i) >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        hist[threadIdx.x * n_tiles + t0 + g] = s_h[threadIdx.x];  // digit-major
+        __syncthreads();
     }
-    __syncthreads();
-    hist[threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];  // digit-major
 }
 
-template <bool FIRST>
+// OUT_KEYS: emit bare keys (u32) instead of records -- used by the counting partition.
+template <bool FIRST, bool OUT_KEYS>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
     const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, uint32_t n, uint32_t shift,
-    uint32_t n_tiles, const uint32_t* __restrict__ offs, Rec* __restrict__ recs_out) {
+    uint32_t n_tiles, uint32_t tiles_per_block, const uint32_t* __restrict__ offs,
+    void* __restrict__ out) {
     __shared__ uint32_t s_cnt[4][256];
     __shared__ uint32_t s_gbase[256];
     __shared__ uint32_t s_wave[4];
     __shared__ Rec s_rec[kSortTile];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
-
-    const uint32_t tile_base = blockIdx.x * kSortTile;
-    const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
-    const uint32_t wbase = tile_base + w * (kSortItems * 64);
-    Rec rec[kSortItems];
-    uint32_t rank[kSortItems];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t t0 = blockIdx.x * tiles_per_block;
+    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
+        const uint32_t tile = t0 + g;
+        for (int i = threadIdx.x; i < 4 * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+
+        const uint32_t tile_base = tile * kSortTile;
+        const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
+        const uint32_t wbase = tile_base + w * (kSortItems * 64);
+        Rec rec[kSortItems];
+        uint32_t rank[kSortItems];
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t i = wbase + k * 64 + lane;
-        const bool valid = i < n;
-        if (FIRST) { rec[k].key = valid ? keys[i] : 0u; rec[k].val = i; }
-        else { rec[k] = valid ? recs_in[i] : Rec{0u, 0u}; }
-        const uint32_t d = (rec[k].key >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-        if (!valid) peers = ~peers;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const uint32_t in_group = __popcll(peers & lt_mask);
-        const int leader = __ffsll((long long)peers) - 1;
-        uint32_t old = 0;
-        if (valid && lane == leader) {
-            old = s_cnt[w][d];
-            s_cnt[w][d] = old + __popcll(peers);
-        }
-        old = (uint32_t)__shfl((int)old, leader, kWave);
-        rank[k] = old + in_group;
-    }
-    __syncthreads();
-    {
-        // digit = threadIdx.x: position of (wave, digit) inside the tile's digit-sorted order,
-        // and the global base of the digit's run
-        const uint32_t d = threadIdx.x;
-        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
-        uint32_t tot;
-        const uint32_t tile_off = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, tot);
-        s_cnt[0][d] = tile_off;
-        s_cnt[1][d] = tile_off + c0;
-        s_cnt[2][d] = tile_off + c0 + c1;
-        s_cnt[3][d] = tile_off + c0 + c1 + c2;
-        s_gbase[d] = offs[d * n_tiles + blockIdx.x] - tile_off;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t i = wbase + k * 64 + lane;
-        if (i < n) {
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t i = wbase + k * 64 + lane;
+            const bool valid = i < n;
+            if (FIRST) { rec[k].key = valid ? keys[i] : 0u; rec[k].val = i; }
+            else { rec[k] = valid ? recs_in[i] : Rec{0u, 0u}; }
             const uint32_t d = (rec[k].key >> shift) & 255u;
-            s_rec[s_cnt[w][d] + rank[k]] = rec[k];
-        }
-    }
-    __syncthreads();
+            uint64_t peers = __ballot(valid);
+            if (!valid) peers = ~peers;
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t j = k * kSortThreads + threadIdx.x;
-        if (j < tile_count) {
-            const Rec r = s_rec[j];
-            const uint32_t d = (r.key >> shift) & 255u;
-            recs_out[s_gbase[d] + j] = r;
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t in_group = __popcll(peers & lt_mask);
+            const int leader = __ffsll((long long)peers) - 1;
+            uint32_t old = 0;
+            if (valid && lane == leader) {
+                old = s_cnt[w][d];
+                s_cnt[w][d] = old + __popcll(peers);
+            }
+            old = (uint32_t)__shfl((int)old, leader, kWave);
+            rank[k] = old + in_group;
         }
+        __syncthreads();
+        {
+            // digit = threadIdx.x: position of (wave, digit) inside the tile's digit-sorted
+            // order, and the global base of the digit's run
+            const uint32_t d = threadIdx.x;
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+            uint32_t tot;
+            const uint32_t tile_off = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, tot);
+            s_cnt[0][d] = tile_off;
+            s_cnt[1][d] = tile_off + c0;
+            s_cnt[2][d] = tile_off + c0 + c1;
+            s_cnt[3][d] = tile_off + c0 + c1 + c2;
+            s_gbase[d] = offs[d * n_tiles + tile] - tile_off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t i = wbase + k * 64 + lane;
+            if (i < n) {
+                const uint32_t d = (rec[k].key >> shift) & 255u;
+                s_rec[s_cnt[w][d] + rank[k]] = rec[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t j = k * kSortThreads + threadIdx.x;
+            if (j < tile_count) {
+                const Rec r = s_rec[j];
+                const uint32_t d = (r.key >> shift) & 255u;
+                if (OUT_KEYS) ((uint32_t*)out)[s_gbase[d] + j] = r.key;
+                else ((Rec*)out)[s_gbase[d] + j] = r;
+            }
+        }
+        __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------ early counts
+// Reads-per-start-position without global atomics and without waiting for the full sort:
+// keys partitioned by (pos >> kCountShift) arrive grouped by a 32 Ki-position range, one
+// workgroup per range histograms it in LDS (128 KiB of counters) and stores the counts
+// coalesced.  Lets the selection sweep (which needs counts only) run beside the radix passes.
+static constexpr uint32_t kCountShift = 15;
+static constexpr uint32_t kCountRange = 1u << kCountShift;
+
+__global__ __launch_bounds__(1024) void k_lds_count(const uint32_t* __restrict__ part_keys,
+                                                    const uint32_t* __restrict__ part_offs,
+                                                    uint32_t n_tiles, uint32_t n, uint32_t n_parts,
+                                                    uint32_t ltot, uint32_t* __restrict__ cstart) {
+    extern __shared__ uint32_t s_cnt32[];  // [kCountRange]
+    const uint32_t part = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < kCountRange; i += blockDim.x) s_cnt32[i] = 0;
+    __syncthreads();
+    const uint32_t lo = part_offs[part * n_tiles];
+    const uint32_t hi = part + 1 < 256 ? part_offs[(part + 1) * n_tiles] : n;
+    const uint32_t pos0 = part << kCountShift;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x)
+        atomicAdd(&s_cnt32[part_keys[j] - pos0], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kCountRange; i += blockDim.x)
+        if (pos0 + i <= ltot) cstart[pos0 + i] = s_cnt32[i];
+    (void)n_parts;
 }
 
 // ------------------------------------------------------------------ bucket offsets from sorted keys
@@ -617,9 +664,9 @@ __device__ __forceinline__ Map4 map_identity() { return Map4{0u, kInf, kInf, kIn
 __device__ __forceinline__ Map4 map_compose(const Map4& f, const Map4& g) {  // f first, then g
     Map4 r;
     r.a = min(f.a + g.a, f.b);
-    r.b = min(sat_add(f.a, g.b), f.b);
-    r.u = min(min(sat_add(f.u, g.a), f.v), g.u);
-    r.v = min(min(sat_add(f.u, g.b), f.v), g.v);
+    r.b = min(f.a + g.b, f.b);
+    r.u = min(min(f.u + g.a, f.v), g.u);
+    r.v = min(min(f.u + g.b, f.v), g.v);
     return r;
 }
 __device__ __forceinline__ Map4 wave_incl_scan_map(Map4 x) {
@@ -696,9 +743,9 @@ __device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a
         exj[r] = (valid && p + ell < L) ? (cov > M ? cov - M : 0u) : kInf;
         Map4 e;
         e.a = cnt[r];
-        e.b = sat_add(cnt[r], exj[r]);
+        e.b = cnt[r] + exj[r];
         e.u = sufA[r];
-        e.v = sat_add(sufA[r], exj[r]);
+        e.v = sufA[r] + exj[r];
         acc = map_compose(acc, e);
     }
     Map4 inc = wave_incl_scan_map(acc);
@@ -708,16 +755,16 @@ __device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a
     pre.u = QMCP_DPP(kInf, inc.u, 0x138, 0xF);
     pre.v = QMCP_DPP(kInf, inc.v, 0x138, 0xF);
     // state entering this lane: (d, m) = pre applied to (d_last, +inf)
-    uint32_t d = min(sat_add(d_last, pre.a), pre.u);
-    uint32_t m = min(sat_add(d_last, pre.b), pre.v);
+    uint32_t d = min(d_last + pre.a, pre.u);
+    uint32_t m = min(d_last + pre.b, pre.v);
     uint32_t h[E];
     uint32_t pick = 0;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint32_t i = lane * E + r;
         const uint32_t p = a + i;
-        const uint32_t dn = min(min(sat_add(d, cnt[r]), m), sufA[r]);
-        h[r] = sat_add(dn, exj[r]);
+        const uint32_t dn = min(min(d + cnt[r], m), sufA[r]);
+        h[r] = dn + exj[r];
         m = min(m, h[r]);
         if (i < ell && p < L) selend[base + p] = cur.x0[r] + (cnt[r] - (dn - d));
         d = dn;
@@ -745,6 +792,9 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
     if (L == 0) return;
     const uint32_t n_blocks = (L + ell - 1) / ell;
+    // this wave is a serial dependency chain that may share its SIMD with streaming kernels:
+    // win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
 
     uint32_t sufA[E];  // suffix-min of the previous block's h, aligned with this block's slots
     // virtual block -1: d == 0 and the jump from j = i - ell lands on p = i
@@ -767,18 +817,27 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     uint32_t d_last = 0;
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
 
-    // Two register sets, alternated, so the loads of block b+1 stay in flight while block b
-    // is computed (no register copies between iterations; loads past the contig end clamp).
-    SweepLoads<E> A, B;
-    sweep_load<E>(boff, base, 0, ell, L, lane, A);
-    for (uint32_t b = 0; b < n_blocks; b += 2) {
+    // Four register sets in rotation: the loads of block b+3 are issued before block b is
+    // computed, so three blocks of work (~1.5 us) cover the load latency even when the radix
+    // passes on the other stream keep HBM busy.  No register copies between iterations; loads
+    // past the contig end clamp to a valid address.
+    SweepLoads<E> S0, S1, S2, S3;
+    sweep_load<E>(boff, base, 0, ell, L, lane, S0);
+    sweep_load<E>(boff, base, ell, ell, L, lane, S1);
+    sweep_load<E>(boff, base, 2 * ell, ell, L, lane, S2);
+#define QMCP_SWEEP_STEP(SET_LOAD, SET_USE, k)                                                      \
+    sweep_load<E>(boff, base, a + ((k) + 3) * ell, ell, L, lane, SET_LOAD);                         \
+    if (b + (k) < n_blocks)                                                                         \
+        sweep_block<E>(SET_USE, a + (k) * ell, base, ell, L, M, lane, last_lane, last_r, sufA,     \
+                       d_last, selend);
+    for (uint32_t b = 0; b < n_blocks; b += 4) {
         const uint32_t a = b * ell;
-        sweep_load<E>(boff, base, a + ell, ell, L, lane, B);
-        sweep_block<E>(A, a, base, ell, L, M, lane, last_lane, last_r, sufA, d_last, selend);
-        sweep_load<E>(boff, base, a + 2 * ell, ell, L, lane, A);
-        if (b + 1 < n_blocks)
-            sweep_block<E>(B, a + ell, base, ell, L, M, lane, last_lane, last_r, sufA, d_last, selend);
+        QMCP_SWEEP_STEP(S3, S0, 0)
+        QMCP_SWEEP_STEP(S0, S1, 1)
+        QMCP_SWEEP_STEP(S1, S2, 2)
+        QMCP_SWEEP_STEP(S2, S3, 3)
     }
+#undef QMCP_SWEEP_STEP
     if (iter_stats && lane == 0) {
         atomicAdd(&iter_stats[0], n_blocks);
         atomicAdd(&iter_stats[1], n_blocks);
@@ -1132,28 +1191,66 @@ void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_
     hipLaunchKernelGGL(k_rmin_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, data, n, spine);
 }
 
+static inline uint32_t tiles_per_block_for(uint32_t n_tiles) {
+    // keep >= ~2048 workgroups in flight; up to 8 consecutive tiles per workgroup
+    uint32_t g = n_tiles / 2048;
+    return g < 1 ? 1 : (g > 8 ? 8 : g);
+}
+
 void launch_radix_hist_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs,
                            uint32_t n, uint32_t shift, uint32_t* hist) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
+    const uint32_t g = tiles_per_block_for(n_tiles);
+    const uint32_t grid = (n_tiles + g - 1) / g;
     if (first)
-        hipLaunchKernelGGL(k_radix_hist_rec<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs, n, shift, n_tiles, hist);
+        hipLaunchKernelGGL(k_radix_hist_rec<true>, dim3(grid), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs, n, shift, n_tiles, g, hist);
     else
-        hipLaunchKernelGGL(k_radix_hist_rec<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs, n, shift, n_tiles, hist);
+        hipLaunchKernelGGL(k_radix_hist_rec<false>, dim3(grid), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs, n, shift, n_tiles, g, hist);
 }
 
 void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
                               uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
+    const uint32_t g = tiles_per_block_for(n_tiles);
+    const uint32_t grid = (n_tiles + g - 1) / g;
     if (first)
-        hipLaunchKernelGGL(k_radix_scatter_rec<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs_in, n, shift, n_tiles, offs, (Rec*)recs_out);
+        hipLaunchKernelGGL((k_radix_scatter_rec<true, false>), dim3(grid), dim3(kSortThreads), 0, st,
+                           keys, (const Rec*)recs_in, n, shift, n_tiles, g, offs, recs_out);
     else
-        hipLaunchKernelGGL(k_radix_scatter_rec<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs_in, n, shift, n_tiles, offs, (Rec*)recs_out);
+        hipLaunchKernelGGL((k_radix_scatter_rec<false, false>), dim3(grid), dim3(kSortThreads), 0, st,
+                           keys, (const Rec*)recs_in, n, shift, n_tiles, g, offs, recs_out);
+}
+
+// early counts: partition bare keys by (pos >> 15), then one LDS histogram per 32 Ki range
+bool early_counts_supported(uint32_t ltot) { return ((ltot + kCountRange) >> kCountShift) <= 256; }
+
+void launch_count_partition_hist(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t* hist) {
+    const uint32_t n_tiles = sort_tiles(n);
+    const uint32_t g = tiles_per_block_for(n_tiles);
+    hipLaunchKernelGGL(k_radix_hist_rec<true>, dim3((n_tiles + g - 1) / g), dim3(kSortThreads), 0, st,
+                       keys, (const Rec*)nullptr, n, kCountShift, n_tiles, g, hist);
+}
+void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
+                                    const uint32_t* offs, uint32_t* part_keys) {
+    const uint32_t n_tiles = sort_tiles(n);
+    const uint32_t g = tiles_per_block_for(n_tiles);
+    hipLaunchKernelGGL((k_radix_scatter_rec<true, true>), dim3((n_tiles + g - 1) / g),
+                       dim3(kSortThreads), 0, st, keys, (const Rec*)nullptr, n, kCountShift, n_tiles, g,
+                       offs, (void*)part_keys);
+}
+void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,
+                      uint32_t ltot, uint32_t* cstart) {
+    const uint32_t n_tiles = sort_tiles(n);
+    const uint32_t n_parts = (ltot + kCountRange) >> kCountShift;  // covers positions 0..ltot
+    const size_t lds = (size_t)kCountRange * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void*)k_lds_count, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(k_lds_count, dim3(n_parts), dim3(1024), lds, st, part_keys, part_offs, n_tiles,
+                       n, n_parts, ltot, cstart);
 }
 
 void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,

@@ -52,3 +52,19 @@ def test_solver_instance_reuse_across_cases(pkg, oracle, solver):
         s = rng.integers(0, max(L - 10, 1), size=n).astype(np.uint32)
         e = np.minimum(s + rng.integers(0, 10, size=n), L - 1).astype(np.uint32)
         assert np.array_equal(solver.solve(s, e, L, M), oracle.solve(s, e, L, M))
+
+
+def test_cfg4_shard_overlapped_sweep_path(pkg, oracle, solver):
+    """one contig of BASELINE.json configs[3] (12.5 M reads, L = 1e6, M = 100): large enough for the
+    two-stream path (early counts + sweep beside the radix passes); bit-identical to the oracle"""
+    s, e = pkg.reads_gen(0, 6_250_000, 1_000_000)
+    got = solver.solve(s, e, 1_000_000, 100)
+    assert solver.last_stats.path == pkg.PATH_UNIFORM
+    assert np.array_equal(got, oracle.solve(s, e, 1_000_000, 100))
+    # two contigs, different depths, same path
+    s2, e2 = pkg.reads_gen(1, 2_500_000, 400_000, seed=7)
+    S, E = np.concatenate([s, s2]), np.concatenate([e, e2])
+    offs = np.array([0, s.size, s.size + s2.size], np.uint64)
+    lens = np.array([1_000_000, 400_000], np.uint32)
+    got = solver.solve(S, E, lens, 60, contig_read_offsets=offs)
+    assert np.array_equal(got, oracle.solve(S, E, lens, 60, contig_read_offsets=offs))
