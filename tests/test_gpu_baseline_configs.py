@@ -1,0 +1,82 @@
+"""Parity cases for the BASELINE.json configs beyond the bench workload."""
+import numpy as np
+import pytest
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _valid(oracle, solver, s, e, lengths, offs, M, mask):
+    in_cov = solver.coverage(s, e, lengths, contig_read_offsets=offs)
+    out_cov = solver.coverage(s, e, lengths, contig_read_offsets=offs, keep_mask=mask)
+    return oracle.is_out_cover_valid(in_cov, out_cov, M)
+
+
+def test_cfg3_amplicon_filter_then_solve(pkg, oracle, solver):
+    """configs[2] at 1/10 scale (3 M reads): amplicon FILTER pre-pass (bam_api.cpp:311-319) on
+    the device, survivors solved at M = 200; every stage bit-identical to the oracle"""
+    n_pairs = 1_500_000
+    s, e, a0, a1, straddle = workloads.amplicon_reads(n_pairs)
+    keep_pairs = solver.amplicon_filter(s, e, a0, a1)
+    assert np.array_equal(keep_pairs, oracle.amplicon_filter(s, e, a0, a1))
+    kept = np.zeros(n_pairs, bool)
+    kept[pkg.mask_to_indices(keep_pairs, n_pairs).astype(np.int64)] = True
+    assert np.array_equal(kept, ~straddle)  # exactly the straddling pairs are filtered out
+    sel = np.repeat(kept, 2)
+    fs, fe = s[sel], e[sel]
+    got = solver.solve(fs, fe, 29_903, 200)
+    assert solver.last_stats.path == pkg.PATH_UNIFORM
+    assert np.array_equal(got, oracle.solve(fs, fe, 29_903, 200))
+    ok, _ = oracle.check_flow(fs, fe, 29_903, 200, got)
+    assert ok
+    # completing mates afterwards (src/app.cpp:141) keeps whole pairs only
+    paired = solver.complete_pairs(got, fs.size)
+    assert np.array_equal(paired, oracle.find_pairs(got, fs.size))
+    bits = np.unpackbits(paired.view(np.uint8), bitorder="little")[:fs.size]
+    assert np.array_equal(bits[0::2], bits[1::2])
+
+
+def test_cfg3_filters_min_length_and_mapq(pkg, oracle, solver):
+    s, e, a0, a1, _ = workloads.amplicon_reads(50_000, seed=3)
+    rng = np.random.default_rng(1)
+    lens = rng.integers(60, 151, size=s.size).astype(np.uint32)
+    mapq = rng.integers(0, 61, size=s.size).astype(np.uint32)
+    # reference defaults: -l 90, -q 30 (src/app.hpp:22-25)
+    got = solver.amplicon_filter(s, e, a0, a1, seq_lengths=lens, qualities=mapq, min_length=90, min_mapq=30)
+    assert np.array_equal(got, oracle.amplicon_filter(s, e, a0, a1, seq_lengths=lens, qualities=mapq,
+                                                      min_length=90, min_mapq=30))
+
+
+def test_cfg5_shape_sparse_multi_contig(pkg, oracle, solver):
+    """configs[4] shape at 1/100 scale: 24 contigs ~ GRCh38 proportions, 10 M reads over 15 Mb
+    (mean coverage 100x), M = 50 -- the sparse regime (most positions start no read)"""
+    s, e, offs, lengths = workloads.wgs_contigs(15_000_000, 5_000_000)
+    got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+    assert solver.last_stats.n_contigs == 24 and solver.last_stats.path == pkg.PATH_UNIFORM
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 50, contig_read_offsets=offs))
+    assert _valid(oracle, solver, s, e, lengths, offs, 50, got)
+
+
+def test_cfg4_full_size_properties(pkg, oracle, solver):
+    """configs[3] at full size (100 M reads, 8 contigs, M = 100): size-independent properties --
+    validity everywhere (device coverage probes), determinism, contig independence, and exact
+    oracle parity on the first contig"""
+    pairs, L, M = 6_250_000, 1_000_000, 100
+    ss, ee = zip(*[pkg.reads_gen(0, pairs, L, seed=12345 + c) for c in range(8)])
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.arange(9, dtype=np.uint64) * np.uint64(2 * pairs)
+    lengths = np.full(8, L, np.uint32)
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    n_kept = solver.last_stats.n_kept
+    assert np.array_equal(got, solver.solve(s, e, lengths, M, contig_read_offsets=offs))  # determinism
+    assert _valid(oracle, solver, s, e, lengths, offs, M, got)
+    bits = np.unpackbits(got.view(np.uint8), bitorder="little")
+    n_c = 2 * pairs
+    for c in (0, 5):  # contigs are independent solves
+        one = np.unpackbits(solver.solve(ss[c], ee[c], L, M).view(np.uint8), bitorder="little")[:n_c]
+        assert np.array_equal(one, bits[c * n_c:(c + 1) * n_c])
+    want0 = np.unpackbits(oracle.solve(ss[0], ee[0], L, M).view(np.uint8), bitorder="little")[:n_c]
+    assert np.array_equal(want0, bits[:n_c])
+    # minimum cardinality on deep uniform data: M reads per read length of genome, per contig
+    assert n_kept == int(bits.sum()) and abs(n_kept - 8 * M * L / 150) < 8 * 2 * M
