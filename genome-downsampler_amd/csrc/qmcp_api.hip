@@ -60,6 +60,9 @@ struct qmcp_hip_ctx {
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp;
+    uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
+    size_t h_tables_cap = 0;
+    uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
     DevBuf scalars;  // popcount + sweep iteration counters
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
@@ -168,13 +171,22 @@ int check_problem(const uint64_t* roff, const uint32_t* lengths, uint32_t n_cont
 }
 
 int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
-    const size_t bytes = ((size_t)pr.n_contigs + 1) * sizeof(uint64_t);
+    const size_t count = (size_t)pr.n_contigs + 1;
+    const size_t bytes = count * sizeof(uint64_t);
     TRY(ensure(c, c->roff, bytes));
     TRY(ensure(c, c->poff, bytes));
-    HIP_TRY(hipMemcpyAsync(c->roff.p, roff, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->poff.p, pr.poff.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    // the host vectors must outlive the copies
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // staged through pinned memory owned by the context: the copies are truly asynchronous and
+    // nothing has to wait for them on the host (the previous solve has fully completed)
+    if (c->h_tables_cap < 2 * count) {
+        if (c->h_tables) HIP_TRY(hipHostFree(c->h_tables));
+        c->h_tables = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->h_tables, 2 * bytes, hipHostMallocDefault));
+        c->h_tables_cap = 2 * count;
+    }
+    std::memcpy(c->h_tables, roff, bytes);
+    std::memcpy(c->h_tables + count, pr.poff.data(), bytes);
+    HIP_TRY(hipMemcpyAsync(c->roff.p, c->h_tables, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->poff.p, c->h_tables + count, bytes, hipMemcpyHostToDevice, c->stream));
     return QMCP_OK;
 }
 
@@ -352,7 +364,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         {
             KernelSpan sp(c, "k_sweep_uniform", s2);
             if (!qmcp::launch_sweep_uniform(s2, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
-                                            n_contigs, max_span, M, (uint32_t*)c->selend.p, d_iters))
+                                            n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p, d_iters))
                 return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
         }
         HIP_TRY(hipGetLastError());
@@ -438,7 +450,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     } else if (uniform) {
         KernelSpan sp(c, "k_sweep_uniform");
         if (!qmcp::launch_sweep_uniform(c->stream, (const uint32_t*)c->boff.p,
-                                        (const uint64_t*)c->poff.p, n_contigs, max_span, M,
+                                        (const uint64_t*)c->poff.p, n_contigs, max_span, M, ltot,
                                         (uint32_t*)c->selend.p, d_iters))
             return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
     } else {
@@ -457,13 +469,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     {
         KernelSpan sp(c, "k_mark");
         qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n,
-                          span_bits, (const uint32_t*)c->selend.p, d_mask);
-    }
-    HIP_TRY(hipGetLastError());
-    {
-        KernelSpan sp(c, "k_popcount");
-        qmcp::launch_popcount(c->stream, d_mask, (uint32_t)mask_words,
-                              (unsigned long long*)c->scalars.p);
+                          span_bits, (const uint32_t*)c->selend.p, d_mask,
+                          (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
@@ -609,6 +616,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->h_tables) (void)hipHostFree(c->h_tables);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);

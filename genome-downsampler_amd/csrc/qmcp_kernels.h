@@ -27,15 +27,16 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
                           uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
                           uint32_t* vals_out);
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
-                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t* selend,
-                          uint32_t* iter_stats);
+                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                          uint32_t* selend, uint32_t* iter_stats);
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
                           uint32_t ring_size);
 // `sorted` is a Rec{key,val} array (wide == false) or u64 keys with `svals` beside them
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
-                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask);
+                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask,
+                 unsigned long long* n_kept);
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
                          uint32_t n, uint32_t span_bits, uint32_t ltot, uint32_t* boff);
 void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_t* spine);

@@ -161,12 +161,27 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             if (on) atomicAdd(&cstart[gs], 1u);
         }
     }
+    // block reduction, then at most one atomic per statistic per workgroup -- and none when the
+    // global value already dominates (same-address atomics serialise; thousands of them cost
+    // more than streaming the reads)
+    __shared__ uint32_t s_red[3][4];
     mn = wave_min_u32(mn);
     mx = wave_max_u32(mx);
     bad = wave_max_u32(bad);
     if ((threadIdx.x & 63) == 0) {
-        if (mn != 0xFFFFFFFFu) atomicMin(&stats[0], mn);
-        if (mx != 0) atomicMax(&stats[1], mx);
+        s_red[0][threadIdx.x >> 6] = mn;
+        s_red[1][threadIdx.x >> 6] = mx;
+        s_red[2][threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_red[0][0], s_red[0][1]), min(s_red[0][2], s_red[0][3]));
+        mx = max(max(s_red[1][0], s_red[1][1]), max(s_red[1][2], s_red[1][3]));
+        bad = s_red[2][0] | s_red[2][1] | s_red[2][2] | s_red[2][3];
+        if (mn < __hip_atomic_load(&stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(&stats[0], mn);
+        if (mx > __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&stats[1], mx);
         if (bad) atomicOr(&stats[2], 1u);
     }
 }
@@ -711,26 +726,26 @@ struct SweepLoads { uint32_t x0[E], x1[E], x2[E]; };
 // in range): every lane issues the same number of loads, so the compiler can keep the next
 // block's loads in flight behind a counted s_waitcnt instead of draining them.
 template <int E>
-__device__ __forceinline__ void sweep_load(const uint32_t* __restrict__ boff, uint32_t base,
+__device__ __forceinline__ void sweep_load(const uint32_t* __restrict__ cb /* boff + base */,
                                            uint32_t a, uint32_t ell, uint32_t L, uint32_t lane,
                                            SweepLoads<E>& o) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint32_t p = a + lane * E + r;
-        o.x0[r] = boff[base + min(p, L)];
-        o.x1[r] = boff[base + min(p + 1, L)];
-        o.x2[r] = boff[base + min(p + ell + 1, L)];
+        o.x0[r] = cb[min(p, L)];
+        o.x1[r] = cb[min(p + 1, L)];
+        o.x2[r] = cb[min(p + ell + 1, L)];
     }
 }
 
 // One block of `ell` positions starting at contig position a.  State carried between blocks:
 // sufA (suffix-min of the previous block's h per slot) and d_last.
 template <int E>
-__device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a, uint32_t base,
+__device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a, uint32_t trash,
                                             uint32_t ell, uint32_t L, uint32_t M, uint32_t lane,
                                             uint32_t last_lane, uint32_t last_r,
                                             uint32_t (&sufA)[E], uint32_t& d_last,
-                                            uint32_t* __restrict__ selend) {
+                                            uint32_t* __restrict__ csel /* selend + base */) {
     uint32_t cnt[E], exj[E];
     Map4 acc = map_identity();
 #pragma unroll
@@ -766,7 +781,8 @@ __device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a
         const uint32_t dn = min(min(d + cnt[r], m), sufA[r]);
         h[r] = dn + exj[r];
         m = min(m, h[r]);
-        if (i < ell && p < L) selend[base + p] = cur.x0[r] + (cnt[r] - (dn - d));
+        // unconditional store: slots outside the contig write the spare entry selend[ltot]
+        csel[(i < ell && p < L) ? p : trash] = cur.x0[r] + (cnt[r] - (dn - d));
         d = dn;
         if ((uint32_t)r == last_r) pick = dn;
     }
@@ -783,7 +799,7 @@ __device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a
 template <int E>
 __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict__ boff,
                                                       const uint64_t* __restrict__ contig_pos_off,
-                                                      uint32_t ell, uint32_t M,
+                                                      uint32_t ell, uint32_t M, uint32_t ltot,
                                                       uint32_t* __restrict__ selend,
                                                       uint32_t* __restrict__ iter_stats) {
     const uint32_t lane = threadIdx.x;
@@ -821,15 +837,18 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     // computed, so three blocks of work (~1.5 us) cover the load latency even when the radix
     // passes on the other stream keep HBM busy.  No register copies between iterations; loads
     // past the contig end clamp to a valid address.
+    const uint32_t* __restrict__ cb = boff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    const uint32_t trash = ltot - base;  // csel[trash] == selend[ltot], the spare entry
     SweepLoads<E> S0, S1, S2, S3;
-    sweep_load<E>(boff, base, 0, ell, L, lane, S0);
-    sweep_load<E>(boff, base, ell, ell, L, lane, S1);
-    sweep_load<E>(boff, base, 2 * ell, ell, L, lane, S2);
+    sweep_load<E>(cb, 0, ell, L, lane, S0);
+    sweep_load<E>(cb, ell, ell, L, lane, S1);
+    sweep_load<E>(cb, 2 * ell, ell, L, lane, S2);
 #define QMCP_SWEEP_STEP(SET_LOAD, SET_USE, k)                                                      \
-    sweep_load<E>(boff, base, a + ((k) + 3) * ell, ell, L, lane, SET_LOAD);                         \
+    sweep_load<E>(cb, a + ((k) + 3) * ell, ell, L, lane, SET_LOAD);                                 \
     if (b + (k) < n_blocks)                                                                         \
-        sweep_block<E>(SET_USE, a + (k) * ell, base, ell, L, M, lane, last_lane, last_r, sufA,     \
-                       d_last, selend);
+        sweep_block<E>(SET_USE, a + (k) * ell, trash, ell, L, M, lane, last_lane, last_r, sufA,    \
+                       d_last, csel);
     for (uint32_t b = 0; b < n_blocks; b += 4) {
         const uint32_t a = b * ell;
         QMCP_SWEEP_STEP(S3, S0, 0)
@@ -952,15 +971,20 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
 template <typename Keys>
 __global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t n, uint32_t span_bits,
                                               const uint32_t* __restrict__ selend,
-                                              uint32_t* __restrict__ mask32) {
+                                              uint32_t* __restrict__ mask32,
+                                              unsigned long long* __restrict__ n_kept) {
     const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t mine = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t q = keys.pos(j, span_bits);
         if (j < selend[q]) {
             const uint32_t idx = keys.idx(j);
             atomicOr(&mask32[idx >> 5], 1u << (idx & 31));
+            ++mine;  // every read occurs once in the sorted order: this counts set bits
         }
     }
+    mine = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_kept, (unsigned long long)mine);
 }
 
 __global__ __launch_bounds__(256) void k_popcount(const uint64_t* __restrict__ mask,
@@ -1121,12 +1145,12 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
 }
 
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
-                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t* selend,
-                          uint32_t* iter_stats) {
+                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                          uint32_t* selend, uint32_t* iter_stats) {
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP(EE)                                                                          \
     hipLaunchKernelGGL(k_sweep_uniform<EE>, dim3(n_contigs), dim3(64), 0, st, boff, d_poff, ell, \
-                       M, selend, iter_stats)
+                       M, ltot, selend, iter_stats)
     switch (e) {
         case 1: QMCP_SWEEP(1); break;
         case 2: QMCP_SWEEP(2); break;
@@ -1163,14 +1187,15 @@ void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const
 }
 
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
-                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask) {
+                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask,
+                 unsigned long long* n_kept) {
     if (wide)
         hipLaunchKernelGGL(k_mark<KeysSplit64>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            KeysSplit64{(const uint64_t*)sorted, svals}, n, span_bits, selend,
-                           (uint32_t*)mask);
+                           (uint32_t*)mask, n_kept);
     else
         hipLaunchKernelGGL(k_mark<KeysRec>, dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           KeysRec{(const Rec*)sorted}, n, span_bits, selend, (uint32_t*)mask);
+                           KeysRec{(const Rec*)sorted}, n, span_bits, selend, (uint32_t*)mask, n_kept);
 }
 
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
