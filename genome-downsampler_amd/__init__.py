@@ -89,6 +89,7 @@ if _host is not None:
     _host.qmcp_host_solve.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.c_int, _u64p]
     _host.qmcp_host_solve.restype = C.c_int64
+    _host.qmcp_host_amplicons_from_files.argtypes = [C.c_char_p, C.c_char_p, _u32p, _u32p, C.c_size_t]
 
 
 def _p32(a):
@@ -272,6 +273,20 @@ def reads_gen(kind, pairs, genome_length, read_length=150, seed=12345, with_qual
     if rc != 0:
         raise ValueError(f"reads_gen failed ({rc})")
     return (s, e, q) if with_qualities else (s, e)
+
+
+def amplicons_from_files(bed_path, tsv_path=None):
+    """BED (+ optional TSV) -> (amp_starts, amp_ends), as BamApi::set_amplicon_filter builds them"""
+    _need_host()
+    cap = 1 << 16
+    a0 = np.empty(cap, dtype=np.uint32)
+    a1 = np.empty(cap, dtype=np.uint32)
+    n = _host.qmcp_host_amplicons_from_files(str(bed_path).encode(),
+                                             str(tsv_path).encode() if tsv_path else None,
+                                             _p32(a0), _p32(a1), cap)
+    if n < 0:
+        raise OSError(f"cannot build amplicon set from {bed_path} / {tsv_path} ({n})")
+    return a0[:n].copy(), a1[:n].copy()
 
 
 def solver_names():

@@ -7,6 +7,7 @@
 #include <random>
 #include <string>
 
+#include "bam-api/amplicon_set.hpp"
 #include "bam-api/bam_api.hpp"
 #include "reads_gen.hpp"
 #include "solver_manager.hpp"
@@ -77,6 +78,21 @@ int qmcp_host_reads_gen_aos(std::uint32_t seed, int kind, std::uint64_t pairs,
         if (r.reads[i].bam_id != i || r.reads[i].is_first_read != (i % 2 == 0)) return -2;
     }
     return 0;
+}
+
+// BED (+ optional TSV, may be NULL or "") -> amplicon intervals, as BamApi::set_amplicon_filter
+// builds them.  Returns the number of amplicons, -1 if a file cannot be opened, -2 if cap is
+// too small.
+int qmcp_host_amplicons_from_files(const char* bed_path, const char* tsv_path,
+                                   std::uint32_t* starts, std::uint32_t* ends, std::size_t cap) {
+    bam_api::AmpliconSet set;
+    if (!bam_api::amplicon_set_from_files(bed_path, tsv_path ? tsv_path : "", set)) return -1;
+    if (set.amplicons.size() > cap) return -2;
+    for (std::size_t i = 0; i < set.amplicons.size(); ++i) {
+        starts[i] = static_cast<std::uint32_t>(set.amplicons[i].start);
+        ends[i] = static_cast<std::uint32_t>(set.amplicons[i].end);
+    }
+    return static_cast<int>(set.amplicons.size());
 }
 
 // Names registered in the SolverManager, '\n'-separated, into buf.

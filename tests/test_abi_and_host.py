@@ -75,3 +75,33 @@ def test_contig_sharding_helpers():
     loads = [sum([10, 50, 20, 20, 5][c] for c in o) for o in owned]
     assert abs(loads[0] - loads[1]) <= 10
     assert sh.assign_contigs([7] * 8, 8) == [[c] for c in range(8)]
+
+
+def test_amplicon_set_from_bed_and_tsv(pkg, tmp_path):
+    """BamApi::set_amplicon_filter restated (bam_api.cpp:53-95,101-186)"""
+    bed = tmp_path / "primers.bed"
+    bed.write_text(
+        "MN908947.3\t30\t54\tnCoV_1_LEFT\tpool1\t+\n"
+        "MN908947.3\t385\t410\tnCoV_1_RIGHT\tpool1\t-\n"
+        "MN908947.3\t320\t342\tnCoV_2_LEFT\tpool2\t+\n"
+        "MN908947.3\t704\t726\tnCoV_2_RIGHT\tpool2\t-\n"
+        "MN908947.3\t999\t1020\tnCoV_2_RIGHT\tpool2\t-\n"   # duplicate name: first one is kept
+        "MN908947.3\tabc\t10\tbroken\n"                        # unparsable: skipped
+        "MN908947.3\t5\t9\t\n")                                 # empty name: skipped
+    tsv = tmp_path / "pairs.tsv"
+    tsv.write_text("nCoV_1_LEFT\tnCoV_1_RIGHT\n"
+                   "nCoV_2_RIGHT\tnCoV_2_LEFT\n"   # listed right-first: ordered by start
+                   "only_one\t\n")                  # invalid line: skipped
+    a0, a1 = pkg.amplicons_from_files(bed, tsv)
+    assert a0.tolist() == [30, 320] and a1.tolist() == [410, 726]
+    # without a TSV: consecutive primers in name-sorted order
+    a0, a1 = pkg.amplicons_from_files(bed)
+    assert a0.tolist() == [30, 320] and a1.tolist() == [410, 726]
+    # the start-ordering swap acts on the map entries (visible to later pairs), unknown names are (0, 0)
+    tsv.write_text("nCoV_2_RIGHT\tnCoV_1_LEFT\n"    # swaps the two entries: 2_RIGHT := (30,54), 1_LEFT := (704,726)
+                   "nCoV_1_LEFT\tnCoV_1_RIGHT\n"    # now (704,726) vs (385,410) -> swapped again -> [385, 726]
+                   "ghost\tnCoV_2_LEFT\n")          # (0,0) and (320,342) -> [0, 342]
+    a0, a1 = pkg.amplicons_from_files(bed, tsv)
+    assert a0.tolist() == [30, 385, 0] and a1.tolist() == [726, 726, 342]
+    with pytest.raises(OSError):
+        pkg.amplicons_from_files(tmp_path / "missing.bed")
