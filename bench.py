@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal knobs (not used by the driver): run several ranks on ONE GPU over gloo to
+    # exercise the N > 1 plumbing on a single-GPU box
+    ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -85,11 +89,16 @@ def main():
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("genome-downsampler_amd")
     n_contigs, pairs, L, rl, M = WORKLOADS[args.workload]

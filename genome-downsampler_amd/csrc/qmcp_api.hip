@@ -195,7 +195,7 @@ int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
 // want_counts -- the solve derives its bucket offsets from the sorted keys instead.
 int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                 const Problem& pr, const uint64_t* d_keep_mask, bool want_keys, bool want_counts,
-                uint32_t host_stats[3]) {
+                bool want_part_hist, uint32_t host_stats[3]) {
     const uint32_t n = (uint32_t)pr.n;
     TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     if (want_counts) TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
@@ -209,7 +209,8 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
         qmcp::launch_prepare(c->stream, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
                              (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
                              want_keys ? (uint32_t*)c->vals[1].p : nullptr,
-                             want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p);
+                             want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p,
+                             want_part_hist ? (uint32_t*)c->hist2.p : nullptr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -282,7 +283,10 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     TRY(upload_tables(c, roff, pr));
 
     uint32_t hs[3];
-    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, hs));
+    // the counting partition's per-tile histogram is produced by the same pass when the
+    // two-stream path can be taken (uniformity is only known afterwards; the table is cheap)
+    const bool may_overlap = n >= (1u << 22) && qmcp::early_counts_supported(ltot);
+    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_overlap, hs));
     HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
@@ -325,23 +329,19 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // Uniform span: the sweep needs only reads-per-position counts, not the sorted order, so
     // counts are produced early (key partition + LDS histograms) and the sweep runs on a second
     // stream beside the radix passes.  Worth it only for problems large enough to fill the chip.
-    const bool overlap = uniform && n >= (1u << 22) && qmcp::early_counts_supported(ltot);
+    const bool overlap = uniform && may_overlap;
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     if (overlap) {
         // counts first, alone on the main stream (bandwidth-bound, ~1/5 of the sort) ...
         hipStream_t s1 = c->stream;
         {
-            KernelSpan sp(c, "k_radix_hist_rec(count partition)");
-            qmcp::launch_count_partition_hist(s1, d_key32, n, (uint32_t*)c->hist2.p);
-        }
-        {
             KernelSpan sp(c, "scan_radix_hist(3 kernels)");
             qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
         {
-            KernelSpan sp(c, "k_radix_scatter_rec(count partition)");
+            KernelSpan sp(c, "k_count_partition");
             qmcp::launch_count_partition_scatter(s1, d_key32, n, (const uint32_t*)c->hist2.p,
                                                  (uint32_t*)c->vals[0].p);
         }
@@ -533,7 +533,7 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     TRY(upload_tables(c, roff, pr));
     uint32_t hs[3];
     TRY(run_prepare(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, pr, d_keep,
-                    true, true, hs));
+                    true, true, false, hs));
     TRY(scan_counts(c, c->cstart, c->boff, ltot));
     TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));

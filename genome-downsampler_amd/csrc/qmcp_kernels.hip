@@ -114,9 +114,13 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  const uint64_t* __restrict__ keep_mask,
                                                  uint32_t* __restrict__ gstart_out,
                                                  uint32_t* __restrict__ cstart,
-                                                 uint32_t* __restrict__ stats) {
+                                                 uint32_t* __restrict__ stats,
+                                                 uint32_t n_tiles, uint32_t tiles_per_block,
+                                                 uint32_t part_shift,
+                                                 uint32_t* __restrict__ part_hist) {
     __shared__ uint64_t s_roff[65];
     __shared__ uint64_t s_poff[65];
+    __shared__ uint32_t s_h[256];
     const uint32_t nc = min(n_contigs, 64u);
     for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
         s_roff[i] = contig_read_off[i];
@@ -124,41 +128,57 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     __syncthreads();
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t s = starts[i], e = ends[i];
-        uint32_t c = 0;
-        if (n_contigs > 1) {
-            if (n_contigs <= 64) {
+    // Work is laid out in the radix tiles (4096 reads) so that the per-tile histogram of the
+    // counting partition (digit = global start >> part_shift) falls out of the same pass.
+    const uint32_t t0 = blockIdx.x * tiles_per_block;
+    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
+        const uint32_t tile = t0 + g;
+        if (part_hist) {
+            s_h[threadIdx.x] = 0;
+            __syncthreads();
+        }
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t i = tile * 4096u + k * 256u + threadIdx.x;
+            if (i >= n) break;
+            const uint32_t s = starts[i], e = ends[i];
+            uint32_t c = 0;
+            if (n_contigs > 1) {
                 uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
-                while (hi - lo > 1) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (s_roff[mid] <= i) lo = mid; else hi = mid;
-                }
-                c = lo;
-            } else {
-                uint32_t lo = 0, hi = n_contigs;
-                while (hi - lo > 1) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+                if (n_contigs <= 64) {
+                    while (hi - lo > 1) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (s_roff[mid] <= i) lo = mid; else hi = mid;
+                    }
+                } else {
+                    while (hi - lo > 1) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+                    }
                 }
                 c = lo;
             }
+            uint64_t p0, p1;
+            if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
+            else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
+            const uint32_t len_c = (uint32_t)(p1 - p0);
+            if (s > e || e >= len_c) { bad = 1; if (gstart_out) gstart_out[i] = 0; continue; }
+            const uint32_t span = e - s + 1;
+            mn = min(mn, span);
+            mx = max(mx, span);
+            const uint32_t gs = (uint32_t)p0 + s;
+            if (gstart_out) gstart_out[i] = gs;
+            if (part_hist) atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+            if (cstart) {
+                bool on = true;
+                if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
+                if (on) atomicAdd(&cstart[gs], 1u);
+            }
         }
-        uint64_t p0, p1;
-        if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
-        else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
-        const uint32_t len_c = (uint32_t)(p1 - p0);
-        if (s > e || e >= len_c) { bad = 1; if (gstart_out) gstart_out[i] = 0; continue; }
-        const uint32_t span = e - s + 1;
-        mn = min(mn, span);
-        mx = max(mx, span);
-        const uint32_t gs = (uint32_t)p0 + s;
-        if (gstart_out) gstart_out[i] = gs;
-        if (cstart) {
-            bool on = true;
-            if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
-            if (on) atomicAdd(&cstart[gs], 1u);
+        if (part_hist) {
+            __syncthreads();
+            part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
+            __syncthreads();
         }
     }
     // block reduction, then at most one atomic per statistic per workgroup -- and none when the
@@ -523,6 +543,58 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
 // coalesced.  Lets the selection sweep (which needs counts only) run beside the radix passes.
 static constexpr uint32_t kCountShift = 15;
 static constexpr uint32_t kCountRange = 1u << kCountShift;
+
+// Counting partition: order inside a partition is irrelevant (the keys are only counted), so
+// ranks come from LDS returning atomics instead of the stable ballot matching.  The tile is
+// staged through LDS and leaves as one contiguous run per partition.
+__global__ __launch_bounds__(kSortThreads) void k_count_partition(
+    const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_tiles,
+    uint32_t tiles_per_block, const uint32_t* __restrict__ offs, uint32_t* __restrict__ part_keys) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_off[256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_key[kSortTile];
+    const uint32_t t0 = blockIdx.x * tiles_per_block;
+    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
+        const uint32_t tile = t0 + g;
+        s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile_base = tile * kSortTile;
+        const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
+        uint32_t key[kSortItems], rank[kSortItems];
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t j = k * kSortThreads + threadIdx.x;
+            key[k] = j < tile_count ? keys[tile_base + j] : 0u;
+            rank[k] = j < tile_count ? atomicAdd(&s_cnt[(key[k] >> shift) & 255u], 1u) : 0u;
+        }
+        __syncthreads();
+        {
+            const uint32_t d = threadIdx.x;
+            uint32_t tot;
+            const uint32_t off = block_excl_scan_256(s_cnt[d], s_wave, tot);
+            s_off[d] = off;
+            s_gbase[d] = offs[d * n_tiles + tile] - off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t j = k * kSortThreads + threadIdx.x;
+            if (j < tile_count) s_key[s_off[(key[k] >> shift) & 255u] + rank[k]] = key[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t j = k * kSortThreads + threadIdx.x;
+            if (j < tile_count) {
+                const uint32_t kk = s_key[j];
+                part_keys[s_gbase[(kk >> shift) & 255u] + j] = kk;
+            }
+        }
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(1024) void k_lds_count(const uint32_t* __restrict__ part_keys,
                                                     const uint32_t* __restrict__ part_offs,
@@ -1084,12 +1156,18 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 *
     return (uint32_t)g;
 }
 
+static inline uint32_t tiles_per_block_for(uint32_t n_tiles);
+
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats) {
-    hipLaunchKernelGGL(k_prepare, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, d_roff,
-                       d_poff, n_contigs, keep_mask, gstart, cstart, stats);
+                    uint32_t* stats, uint32_t* part_hist) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    const uint32_t g = tiles_per_block_for(n_tiles);
+    hipLaunchKernelGGL(k_prepare, dim3((n_tiles + g - 1) / g), dim3(256), 0, st, starts, ends, n,
+                       d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
+                       kCountShift, part_hist);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
@@ -1263,9 +1341,8 @@ void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32
                                     const uint32_t* offs, uint32_t* part_keys) {
     const uint32_t n_tiles = sort_tiles(n);
     const uint32_t g = tiles_per_block_for(n_tiles);
-    hipLaunchKernelGGL((k_radix_scatter_rec<true, true>), dim3((n_tiles + g - 1) / g),
-                       dim3(kSortThreads), 0, st, keys, (const Rec*)nullptr, n, kCountShift, n_tiles, g,
-                       offs, (void*)part_keys);
+    hipLaunchKernelGGL(k_count_partition, dim3((n_tiles + g - 1) / g), dim3(kSortThreads), 0, st,
+                       keys, n, kCountShift, n_tiles, g, offs, part_keys);
 }
 void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,
                       uint32_t ltot, uint32_t* cstart) {
