@@ -80,25 +80,6 @@ __device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v, uint32_t id) {
 }
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return min(a + b, kInf); }
 
-// Inclusive scan of "x -> min(x + c, b)" maps under composition (apply lower lanes first):
-// (c1,b1) then (c2,b2) = (c1 + c2, min(b1 + c2, b2)).
-__device__ __forceinline__ void wave_incl_scan_affine(uint32_t& c, uint32_t& b) {
-#define QMCP_STEP(ctrl, rmask)                                   \
-    {                                                            \
-        uint32_t pc = QMCP_DPP(0u, c, ctrl, rmask);              \
-        uint32_t pb = QMCP_DPP(kInf, b, ctrl, rmask);            \
-        b = min(sat_add(pb, c), b);                              \
-        c = c + pc;                                              \
-    }
-    QMCP_STEP(0x111, 0xF)
-    QMCP_STEP(0x112, 0xF)
-    QMCP_STEP(0x114, 0xF)
-    QMCP_STEP(0x118, 0xF)
-    QMCP_STEP(0x142, 0xA)
-    QMCP_STEP(0x143, 0xC)
-#undef QMCP_STEP
-}
-
 // ------------------------------------------------------------------ prepare
 // One pass over the reads: validate (start <= end < contig length), reduce min/max span,
 // write the global start position of every read (the bucketing key of the uniform path) and
@@ -775,7 +756,9 @@ __device__ __forceinline__ Map4 wave_incl_scan_map(Map4 x) {
 #undef QMCP_STEP
     return x;
 }
-// min over lanes strictly above this lane (kInf for lane 63)
+// min over lanes strictly above this lane (>= kInf for lane 63).  Row totals are read
+// with v_readlane and merged with per-lane masks (all-ones = "row does not count"), so there
+// is no divergent control flow.
 __device__ __forceinline__ uint32_t wave_excl_suffix_min(uint32_t t) {
     uint32_t s = t;
     s = min(s, QMCP_DPP(kInf, s, 0x101, 0xF));  // row_shl:1
@@ -786,9 +769,11 @@ __device__ __forceinline__ uint32_t wave_excl_suffix_min(uint32_t t) {
     const uint32_t r2 = __builtin_amdgcn_readlane(s, 32);
     const uint32_t r3 = __builtin_amdgcn_readlane(s, 48);
     const uint32_t row = (threadIdx.x & 63) >> 4;
-    const uint32_t later = row == 0 ? min(r1, min(r2, r3)) : row == 1 ? min(r2, r3) : row == 2 ? r3 : kInf;
-    s = min(s, later);                           // inclusive suffix min
-    return QMCP_DPP(kInf, s, 0x130, 0xF);        // wave_shl:1 -> exclusive
+    const uint32_t off1 = row < 1 ? 0u : 0xFFFFFFFFu;  // rows that lie above this lane's row
+    const uint32_t off2 = row < 2 ? 0u : 0xFFFFFFFFu;
+    const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
+    s = min(min(s, r1 | off1), min(r2 | off2, r3 | off3));  // inclusive suffix min
+    return QMCP_DPP(kInf, s, 0x130, 0xF);                   // wave_shl:1 -> exclusive
 }
 
 template <int E>
@@ -810,62 +795,178 @@ __device__ __forceinline__ void sweep_load(const uint32_t* __restrict__ cb /* bo
     }
 }
 
+// signed wave scans for the (h - C) terms of the fast block form
+__device__ __forceinline__ int32_t wave_incl_scan_min_i32(int32_t v) {
+#define QMCP_SDPP(x, ctrl, rmask) \
+    __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)(x), (ctrl), (rmask), 0xF, false)
+    v = min(v, QMCP_SDPP(v, 0x111, 0xF));
+    v = min(v, QMCP_SDPP(v, 0x112, 0xF));
+    v = min(v, QMCP_SDPP(v, 0x114, 0xF));
+    v = min(v, QMCP_SDPP(v, 0x118, 0xF));
+    v = min(v, QMCP_SDPP(v, 0x142, 0xA));
+    v = min(v, QMCP_SDPP(v, 0x143, 0xC));
+    return v;
+}
+
 // One block of `ell` positions starting at contig position a.  State carried between blocks:
-// sufA (suffix-min of the previous block's h per slot) and d_last.
+// h (the previous block's h(j) = d(j) + ex(j + ell), slot-aligned) and d_last.
+//
+// Fast form.  Without intra-block jumps the block recurrence is
+//     d'(i) = min( d'(i-1) + c(i), A(i) ),   A(i) = min_{j >= i} h(j)   (previous block)
+// Unrolling it and using that the inclusive count prefix C(i) is non-decreasing gives
+//     d'(i) = min( d_last + C(i),  C(i) + min_{j <= i} (h(j) - C(j)),  min_{j > i} h(j) )
+// i.e. two INDEPENDENT wave scans over the previous block's h (a prefix-min and a suffix-min,
+// one value each) plus a prefix sum of counts that does not depend on the chain at all.
+// Then the block's own running minimum m(i) = min_{j<i} h'(j) is compared with d'(i): if it
+// never undercuts, d' also satisfies the full recurrence (with intra-block jumps) position by
+// position and is exact.  The function returns whether some lane saw an undercut; the caller
+// then redoes the group with sweep_block_full.  On deep data the binding jumps come from the
+// previous block, so that is rare; either way the result is the same distances.
 template <int E>
-__device__ __forceinline__ void sweep_block(const SweepLoads<E>& cur, uint32_t a, uint32_t trash,
-                                            uint32_t ell, uint32_t L, uint32_t M, uint32_t lane,
-                                            uint32_t last_lane, uint32_t last_r,
-                                            uint32_t (&sufA)[E], uint32_t& d_last,
-                                            uint32_t* __restrict__ csel /* selend + base */) {
-    uint32_t cnt[E], exj[E];
-    Map4 acc = map_identity();
+struct BlockTerms { uint32_t cnt[E], exj[E]; };
+
+template <int E>
+__device__ __forceinline__ void block_terms(const SweepLoads<E>& cur, uint32_t a, uint32_t ell,
+                                            uint32_t L, uint32_t M, uint32_t lane, BlockTerms<E>& t) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint32_t i = lane * E + r;
         const uint32_t p = a + i;
         const bool valid = i < ell && p < L;
         const uint32_t cov = cur.x2[r] - cur.x1[r];
-        cnt[r] = valid ? cur.x1[r] - cur.x0[r] : 0u;
-        exj[r] = (valid && p + ell < L) ? (cov > M ? cov - M : 0u) : kInf;
-        Map4 e;
-        e.a = cnt[r];
-        e.b = cnt[r] + exj[r];
-        e.u = sufA[r];
-        e.v = sufA[r] + exj[r];
-        acc = map_compose(acc, e);
+        t.cnt[r] = valid ? cur.x1[r] - cur.x0[r] : 0u;
+        t.exj[r] = (valid && p + ell < L) ? (cov > M ? cov - M : 0u) : kInf;
     }
-    Map4 inc = wave_incl_scan_map(acc);
-    Map4 pre;  // composition of all lower lanes (identity for lane 0)
-    pre.a = QMCP_DPP(0u, inc.a, 0x138, 0xF);  // wave_shr:1
-    pre.b = QMCP_DPP(kInf, inc.b, 0x138, 0xF);
-    pre.u = QMCP_DPP(kInf, inc.u, 0x138, 0xF);
-    pre.v = QMCP_DPP(kInf, inc.v, 0x138, 0xF);
-    // state entering this lane: (d, m) = pre applied to (d_last, +inf)
-    uint32_t d = min(d_last + pre.a, pre.u);
-    uint32_t m = min(d_last + pre.b, pre.v);
-    uint32_t h[E];
-    uint32_t pick = 0;
+}
+
+template <int E>
+__device__ __forceinline__ void block_emit(const SweepLoads<E>& cur, const BlockTerms<E>& t,
+                                           const uint32_t (&dn)[E], const uint32_t (&hn)[E],
+                                           uint32_t d_in, uint32_t a, uint32_t trash, uint32_t ell,
+                                           uint32_t L, uint32_t lane, uint32_t last_lane,
+                                           uint32_t last_r, uint32_t (&h)[E], uint32_t& d_last,
+                                           uint32_t* __restrict__ csel) {
+    uint32_t prev = d_in, pick = 0;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint32_t i = lane * E + r;
         const uint32_t p = a + i;
-        const uint32_t dn = min(min(d + cnt[r], m), sufA[r]);
-        h[r] = dn + exj[r];
-        m = min(m, h[r]);
         // unconditional store: slots outside the contig write the spare entry selend[ltot]
-        csel[(i < ell && p < L) ? p : trash] = cur.x0[r] + (cnt[r] - (dn - d));
-        d = dn;
-        if ((uint32_t)r == last_r) pick = dn;
+        csel[(i < ell && p < L) ? p : trash] = cur.x0[r] + (t.cnt[r] - (dn[r] - prev));
+        prev = dn[r];
+        if ((uint32_t)r == last_r) pick = dn[r];
+        h[r] = hn[r];
     }
     d_last = __builtin_amdgcn_readlane(pick, last_lane);
-    uint32_t run = kInf;
-    uint32_t hv[E];
+}
+
+template <int E>
+__device__ __forceinline__ bool sweep_block_fast(const SweepLoads<E>& cur, uint32_t a,
+                                                 uint32_t trash, uint32_t ell, uint32_t L,
+                                                 uint32_t M, uint32_t lane, uint32_t last_lane,
+                                                 uint32_t last_r, uint32_t (&h)[E],
+                                                 uint32_t& d_last, uint32_t* __restrict__ csel) {
+    BlockTerms<E> t;
+    block_terms<E>(cur, a, ell, L, M, lane, t);
+    uint32_t C[E], dn[E], hn[E];
+    // inclusive prefix of the counts over the block (independent of the chain)
+    uint32_t lsum = 0;
 #pragma unroll
-    for (int r = E - 1; r >= 0; --r) { run = min(run, h[r]); hv[r] = run; }
-    const uint32_t after = wave_excl_suffix_min(run);
+    for (int r = 0; r < E; ++r) { lsum += t.cnt[r]; C[r] = lsum; }
+    const uint32_t before = QMCP_DPP(0u, wave_incl_scan_add(lsum), 0x138, 0xF);  // lower lanes
 #pragma unroll
-    for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
+    for (int r = 0; r < E; ++r) C[r] += before;
+
+    // prefix-min of (h - C) and exclusive suffix-min of h over the previous block.
+    // h < 2^31 and (h - C) >= -2^28, so the signed arithmetic cannot overflow.
+    int32_t lp[E];
+    int32_t lrun = 0x7FFFFFFF;
+    uint32_t sx[E];
+    uint32_t srun = kInf;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        lrun = min(lrun, (int32_t)h[r] - (int32_t)C[r]);
+        lp[r] = lrun;
+    }
+#pragma unroll
+    for (int r = E - 1; r >= 0; --r) {
+        sx[r] = srun;  // min over slots r' > r of this lane
+        srun = min(srun, h[r]);
+    }
+    const int32_t pp = __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)wave_incl_scan_min_i32(lrun),
+                                                   0x138, 0xF, 0xF, false);
+    const uint32_t after = wave_excl_suffix_min(srun);
+
+    // d entering the lane = d' at the last slot of the lane below (C = before, prefix-min = pp,
+    // suffix = everything from this lane's first slot on); for lane 0 it is d_last.
+    uint32_t d_in = min(min(d_last + before, (uint32_t)(pp + (int32_t)before)), min(srun, after));
+    d_in = lane == 0 ? d_last : d_in;
+    uint32_t lmin = kInf;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t viaP = (uint32_t)((int32_t)C[r] + min(pp, lp[r]));
+        dn[r] = min(min(d_last + C[r], viaP), min(sx[r], after));
+        hn[r] = dn[r] + t.exj[r];
+        lmin = min(lmin, hn[r]);
+    }
+    // m entering this lane = min of h' over all lower lanes
+    uint32_t run = QMCP_DPP(kInf, wave_incl_scan_min(lmin), 0x138, 0xF);
+    bool undercut = false;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        undercut |= run < dn[r];
+        run = min(run, hn[r]);
+    }
+    block_emit<E>(cur, t, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+    return __any(undercut);
+}
+
+// General form of the same block: maps carrying (d, m) -- see Map4 above.
+template <int E>
+__device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint32_t a,
+                                                 uint32_t trash, uint32_t ell, uint32_t L,
+                                                 uint32_t M, uint32_t lane, uint32_t last_lane,
+                                                 uint32_t last_r, uint32_t (&h)[E],
+                                                 uint32_t& d_last, uint32_t* __restrict__ csel) {
+    BlockTerms<E> t;
+    block_terms<E>(cur, a, ell, L, M, lane, t);
+    uint32_t sufA[E], dn[E], hn[E];
+    {
+        uint32_t srun = kInf;
+#pragma unroll
+        for (int r = E - 1; r >= 0; --r) { srun = min(srun, h[r]); sufA[r] = srun; }
+        const uint32_t after = wave_excl_suffix_min(srun);
+#pragma unroll
+        for (int r = 0; r < E; ++r) sufA[r] = min(sufA[r], after);  // min_{j >= i} h(j)
+    }
+    Map4 acc = map_identity();
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        Map4 e;
+        e.a = t.cnt[r];
+        e.b = t.cnt[r] + t.exj[r];
+        e.u = sufA[r];
+        e.v = sufA[r] + t.exj[r];
+        acc = map_compose(acc, e);
+    }
+    Map4 inc = wave_incl_scan_map(acc);
+    Map4 pre;  // composition of all lower lanes (identity for lane 0)
+    pre.a = QMCP_DPP(0u, inc.a, 0x138, 0xF);
+    pre.b = QMCP_DPP(kInf, inc.b, 0x138, 0xF);
+    pre.u = QMCP_DPP(kInf, inc.u, 0x138, 0xF);
+    pre.v = QMCP_DPP(kInf, inc.v, 0x138, 0xF);
+    // state entering this lane: (d, m) = pre applied to (d_last, +inf)
+    const uint32_t d_in = min(d_last + pre.a, pre.u);
+    uint32_t dd = d_in;
+    uint32_t m = min(d_last + pre.b, pre.v);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        dd = min(min(dd + t.cnt[r], m), sufA[r]);
+        dn[r] = dd;
+        hn[r] = dd + t.exj[r];
+        m = min(m, hn[r]);
+    }
+    block_emit<E>(cur, t, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
 }
 
 template <int E>
@@ -884,25 +985,19 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     // win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
 
-    uint32_t sufA[E];  // suffix-min of the previous block's h, aligned with this block's slots
+    uint32_t h[E];  // previous block's h(j) = d(j) + ex(j + ell), aligned with this block's slots
     // virtual block -1: d == 0 and the jump from j = i - ell lands on p = i
     {
-        uint32_t hv[E];
         const uint32_t b0 = boff[base];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const uint32_t i = lane * E + r;
             const uint32_t cov = boff[base + min(i + 1, L)] - b0;
-            hv[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
+            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
         }
-        uint32_t run = kInf;
-#pragma unroll
-        for (int r = E - 1; r >= 0; --r) { run = min(run, hv[r]); hv[r] = run; }
-        const uint32_t after = wave_excl_suffix_min(run);
-#pragma unroll
-        for (int r = 0; r < E; ++r) sufA[r] = min(hv[r], after);
     }
     uint32_t d_last = 0;
+    uint32_t n_full = 0;  // blocks that needed the 4-component form
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
 
     // Four register sets in rotation: the loads of block b+3 are issued before block b is
@@ -912,25 +1007,62 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     const uint32_t* __restrict__ cb = boff + base;
     uint32_t* __restrict__ csel = selend + base;
     const uint32_t trash = ltot - base;  // csel[trash] == selend[ltot], the spare entry
-    SweepLoads<E> S0, S1, S2, S3;
-    sweep_load<E>(cb, 0, ell, L, lane, S0);
-    sweep_load<E>(cb, ell, ell, L, lane, S1);
-    sweep_load<E>(cb, 2 * ell, ell, L, lane, S2);
-#define QMCP_SWEEP_STEP(SET_LOAD, SET_USE, k)                                                      \
-    sweep_load<E>(cb, a + ((k) + 3) * ell, ell, L, lane, SET_LOAD);                                 \
-    if (b + (k) < n_blocks)                                                                         \
-        sweep_block<E>(SET_USE, a + (k) * ell, trash, ell, L, M, lane, last_lane, last_r, sufA,    \
-                       d_last, csel);
-    for (uint32_t b = 0; b < n_blocks; b += 4) {
-        const uint32_t a = b * ell;
-        QMCP_SWEEP_STEP(S3, S0, 0)
-        QMCP_SWEEP_STEP(S0, S1, 1)
-        QMCP_SWEEP_STEP(S1, S2, 2)
-        QMCP_SWEEP_STEP(S2, S3, 3)
+    // Steady state: groups of four blocks in the fast form, four register sets in rotation
+    // (loads of block b+3 are issued before block b is computed), no branch around any load
+    // or store so the compiler keeps counted waits.  A group in which some block reports an
+    // undercut leaves the loop, is redone from the saved state in the general form, and the
+    // pipeline restarts behind it.
+    const uint32_t n_groups = n_blocks / 4;
+    uint32_t g = 0;
+    while (g < n_groups) {
+        SweepLoads<E> S0, S1, S2, S3;
+        sweep_load<E>(cb, g * 4 * ell, ell, L, lane, S0);
+        sweep_load<E>(cb, (g * 4 + 1) * ell, ell, L, lane, S1);
+        sweep_load<E>(cb, (g * 4 + 2) * ell, ell, L, lane, S2);
+        uint32_t h_save[E];
+        uint32_t d_save = d_last;
+        bool bad = false;
+        for (; g < n_groups; ++g) {
+            const uint32_t a = g * 4 * ell;
+#pragma unroll
+            for (int r = 0; r < E; ++r) h_save[r] = h[r];
+            d_save = d_last;
+#define QMCP_FAST(SET_USE, pos) \
+    sweep_block_fast<E>(SET_USE, pos, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel)
+            sweep_load<E>(cb, a + 3 * ell, ell, L, lane, S3);
+            bad = QMCP_FAST(S0, a);
+            sweep_load<E>(cb, a + 4 * ell, ell, L, lane, S0);
+            bad |= QMCP_FAST(S1, a + ell);
+            sweep_load<E>(cb, a + 5 * ell, ell, L, lane, S1);
+            bad |= QMCP_FAST(S2, a + 2 * ell);
+            sweep_load<E>(cb, a + 6 * ell, ell, L, lane, S2);
+            bad |= QMCP_FAST(S3, a + 3 * ell);
+#undef QMCP_FAST
+            if (bad) break;
+        }
+        if (bad) {
+            // redo group g in the general form (its stores overwrite the speculative ones)
+#pragma unroll
+            for (int r = 0; r < E; ++r) h[r] = h_save[r];
+            d_last = d_save;
+            for (uint32_t k = 0; k < 4; ++k) {
+                SweepLoads<E> T;
+                sweep_load<E>(cb, (g * 4 + k) * ell, ell, L, lane, T);
+                sweep_block_full<E>(T, (g * 4 + k) * ell, trash, ell, L, M, lane, last_lane, last_r, h,
+                                    d_last, csel);
+            }
+            n_full += 4;
+            ++g;
+        }
     }
-#undef QMCP_SWEEP_STEP
+    // tail: at most three blocks, general form
+    for (uint32_t b = n_groups * 4; b < n_blocks; ++b) {
+        SweepLoads<E> T;
+        sweep_load<E>(cb, b * ell, ell, L, lane, T);
+        sweep_block_full<E>(T, b * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+    }
     if (iter_stats && lane == 0) {
-        atomicAdd(&iter_stats[0], n_blocks);
+        atomicAdd(&iter_stats[0], n_full);
         atomicAdd(&iter_stats[1], n_blocks);
     }
 }

@@ -1,0 +1,9 @@
+import sys, importlib, numpy as np
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg=importlib.import_module('genome-downsampler_amd')
+sv=pkg.Solver(0)
+s,e=pkg.reads_gen(0,1500000,1000000)   # 3M reads, L=1M -> non-overlapped path, 6667 sweep blocks
+for _ in range(4):
+    sv.solve(s,e,1000000,30)
+st=sv.last_stats.as_dict()
+print({k:(round(v,3) if isinstance(v,float) else v) for k,v in st.items()})
