@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
+# separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction), keyed by workload
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic_{workload}.json")
 
 WORKLOADS = {
     # name: (contigs per GPU, pairs per contig, contig length, read length, M)
@@ -160,6 +163,12 @@ def main():
         dom_avg_ms = dom_ms / dom_launches
         achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9
         dev_ms = float(st.ms_total)  # HIP events around the whole solve (kernels overlap on two streams)
+        traffic = None
+        try:
+            pmc = json.load(open(PMC_TRAFFIC_FILE.format(workload=args.workload)))
+            traffic = pmc.get(dom_name, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "Mreads/s selected at target coverage M=100",
             "value": round(value, 2), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -178,7 +187,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": b_alg,
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_launches,
                 "whole_solve": {
