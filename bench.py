@@ -119,19 +119,33 @@ def main():
 
     d_starts = torch.from_numpy(starts.view(np.int32)).to(dev)
     d_ends = torch.from_numpy(ends.view(np.int32)).to(dev)
-    d_mask = torch.zeros(words, dtype=torch.int64, device=dev)
-    d_all = torch.zeros(words * world, dtype=torch.int64, device=dev) if world > 1 else None
+    # two mask buffers: the gather of step k (RCCL, its own stream) overlaps the solve of step k+1
+    d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
+    d_alls = [torch.zeros(words * world, dtype=torch.int64, device=dev) for _ in range(2)] \
+        if world > 1 else None
+    d_mask = d_masks[0]
     solver = pkg.Solver(local_rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    pending = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if pending[k] is not None:  # buffer k is being gathered from two steps ago
+            pending[k].wait()
+            pending[k] = None
         solver.solve_device(d_starts.data_ptr(), d_ends.data_ptr(), n_reads, lengths, M,
-                            d_mask.data_ptr(), contig_read_offsets=offs, stream=stream)
+                            d_masks[k].data_ptr(), contig_read_offsets=offs, stream=stream)
         if world > 1:
             # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
-            dist.all_gather_into_tensor(d_all, d_mask)
+            pending[k] = dist.all_gather_into_tensor(d_alls[k], d_masks[k], async_op=True)
 
     def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -179,7 +193,9 @@ def main():
                 "workload": f"{args.workload} per GPU: {n_contigs} contigs x rand_reads_uniform("
                             f"{pairs} pairs, L={L}, len={rl}), {n_reads} reads, M={M}; "
                             "device-resident reads -> device keep bitmask"
-                            + ("; + RCCL all_gather of keep masks" if world > 1 else ""),
+                            + ("; + RCCL all_gather of the keep masks, overlapped with the next "
+                               "step's solve (all completed inside the timed region)"
+                               if world > 1 else ""),
                 "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
                 "path": {1: "uniform-span block sweep", 2: "mixed-span event sweep"}.get(st.path),
                 "kept_reads_per_gpu": int(st.n_kept),

@@ -44,8 +44,6 @@ void launch_radix_hist_rec(hipStream_t st, bool first, const uint32_t* keys, con
                            uint32_t n, uint32_t shift, uint32_t* hist);
 void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
                               uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out);
-void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
-                     unsigned long long* out);
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
                      uint32_t* cov);
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads);
@@ -57,7 +55,6 @@ void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32
 
 // early counts (uniform path): reads per start position from a key partition + LDS histograms
 bool early_counts_supported(uint32_t ltot);
-void launch_count_partition_hist(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t* hist);
 void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
                                     const uint32_t* offs, uint32_t* part_keys);
 void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,

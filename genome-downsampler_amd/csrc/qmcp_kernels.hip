@@ -1191,18 +1191,6 @@ __global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t n, uint32_t sp
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_kept, (unsigned long long)mine);
 }
 
-__global__ __launch_bounds__(256) void k_popcount(const uint64_t* __restrict__ mask,
-                                                  uint32_t n_words,
-                                                  unsigned long long* __restrict__ out) {
-    unsigned long long acc = 0;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
-        acc += __popcll(mask[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o, kWave);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
-}
-
 // cov[p] = #reads started at or before p - #reads ended before p
 // (what BamApi::find_input_cover builds with per-base increments, bam_api.cpp:275-286)
 __global__ __launch_bounds__(256) void k_coverage(const uint32_t* __restrict__ boff,
@@ -1463,12 +1451,6 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
 // early counts: partition bare keys by (pos >> 15), then one LDS histogram per 32 Ki range
 bool early_counts_supported(uint32_t ltot) { return ((ltot + kCountRange) >> kCountShift) <= 256; }
 
-void launch_count_partition_hist(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t* hist) {
-    const uint32_t n_tiles = sort_tiles(n);
-    const uint32_t g = tiles_per_block_for(n_tiles);
-    hipLaunchKernelGGL(k_radix_hist_rec<true>, dim3((n_tiles + g - 1) / g), dim3(kSortThreads), 0, st,
-                       keys, (const Rec*)nullptr, n, kCountShift, n_tiles, g, hist);
-}
 void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
                                     const uint32_t* offs, uint32_t* part_keys) {
     const uint32_t n_tiles = sort_tiles(n);
@@ -1485,11 +1467,6 @@ void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t*
                               (int)lds);
     hipLaunchKernelGGL(k_lds_count, dim3(n_parts), dim3(1024), lds, st, part_keys, part_offs, n_tiles,
                        n, n_parts, ltot, cstart);
-}
-
-void launch_popcount(hipStream_t st, const uint64_t* mask, uint32_t n_words,
-                     unsigned long long* out) {
-    hipLaunchKernelGGL(k_popcount, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask, n_words, out);
 }
 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
