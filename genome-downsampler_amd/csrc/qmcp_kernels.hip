@@ -795,18 +795,13 @@ __device__ __forceinline__ void sweep_load(const uint32_t* __restrict__ cb /* bo
     }
 }
 
-// signed wave scans for the (h - C) terms of the fast block form
-__device__ __forceinline__ int32_t wave_incl_scan_min_i32(int32_t v) {
-#define QMCP_SDPP(x, ctrl, rmask) \
-    __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)(x), (ctrl), (rmask), 0xF, false)
-    v = min(v, QMCP_SDPP(v, 0x111, 0xF));
-    v = min(v, QMCP_SDPP(v, 0x112, 0xF));
-    v = min(v, QMCP_SDPP(v, 0x114, 0xF));
-    v = min(v, QMCP_SDPP(v, 0x118, 0xF));
-    v = min(v, QMCP_SDPP(v, 0x142, 0xA));
-    v = min(v, QMCP_SDPP(v, 0x143, 0xC));
-    return v;
-}
+// DPP reads whose `old` operand is the operator's TRUE identity (INT32_MAX for signed min,
+// 0xFFFFFFFF for unsigned min, 0 for add): LLVM's DPP combiner then folds the move into the
+// operation (v_min_i32_dpp / v_min_u32_dpp / v_add_u32_dpp), one instruction per scan step.
+#define QMCP_DPP_IMIN(v, ctrl, rmask) \
+    __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)(v), (ctrl), (rmask), 0xF, false)
+#define QMCP_DPP_UMIN(v, ctrl, rmask) \
+    (uint32_t) __builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(v), (ctrl), (rmask), 0xF, false)
 
 // One block of `ell` positions starting at contig position a.  State carried between blocks:
 // h (the previous block's h(j) = d(j) + ex(j + ell), slot-aligned) and d_last.
@@ -822,8 +817,21 @@ __device__ __forceinline__ int32_t wave_incl_scan_min_i32(int32_t v) {
 // position and is exact.  The function returns whether some lane saw an undercut; the caller
 // then redoes the group with sweep_block_full.  On deep data the binding jumps come from the
 // previous block, so that is rare; either way the result is the same distances.
+//
+// A lone wave pays two wait states between dependent DPP operations, so the scans are written
+// pairwise interleaved (prefix-min with suffix-min; the verification scan with the NEXT block's
+// count prefix, which is why the per-block terms are prepared one block ahead).
 template <int E>
 struct BlockTerms { uint32_t cnt[E], exj[E]; };
+
+template <int E>
+struct BlockPrep {       // everything about a block that does not depend on the chain
+    uint32_t x0[E];      // bucket offset of each slot (for the store)
+    uint32_t cnt[E];     // reads starting at the slot
+    uint32_t exj[E];     // ex at the landing position of the slot's jump (kInf: none)
+    uint32_t C[E];       // inclusive prefix of cnt over the block
+    uint32_t before;     // sum of cnt over all lower lanes
+};
 
 template <int E>
 __device__ __forceinline__ void block_terms(const SweepLoads<E>& cur, uint32_t a, uint32_t ell,
@@ -839,8 +847,40 @@ __device__ __forceinline__ void block_terms(const SweepLoads<E>& cur, uint32_t a
     }
 }
 
+// chain-independent part of a block, up to (not including) the wave scan of the lane sums
 template <int E>
-__device__ __forceinline__ void block_emit(const SweepLoads<E>& cur, const BlockTerms<E>& t,
+__device__ __forceinline__ uint32_t prep_local(const SweepLoads<E>& ld, uint32_t a, uint32_t ell,
+                                               uint32_t L, uint32_t M, uint32_t lane,
+                                               BlockPrep<E>& pr) {
+    uint32_t lsum = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t p = a + i;
+        const bool valid = i < ell && p < L;
+        const uint32_t cov = ld.x2[r] - ld.x1[r];
+        pr.x0[r] = ld.x0[r];
+        pr.cnt[r] = valid ? ld.x1[r] - ld.x0[r] : 0u;
+        pr.exj[r] = (valid && p + ell < L) ? (cov > M ? cov - M : 0u) : kInf;
+        lsum += pr.cnt[r];
+        pr.C[r] = lsum;
+    }
+    return lsum;
+}
+template <int E>
+__device__ __forceinline__ void prep_finish(BlockPrep<E>& pr, uint32_t incl_lane_sums) {
+    pr.before = QMCP_DPP(0u, incl_lane_sums, 0x138, 0xF);  // wave_shr:1, lane 0 gets 0
+#pragma unroll
+    for (int r = 0; r < E; ++r) pr.C[r] += pr.before;
+}
+template <int E>
+__device__ __forceinline__ void prep_block(const SweepLoads<E>& ld, uint32_t a, uint32_t ell,
+                                           uint32_t L, uint32_t M, uint32_t lane, BlockPrep<E>& pr) {
+    prep_finish<E>(pr, wave_incl_scan_add(prep_local<E>(ld, a, ell, L, M, lane, pr)));
+}
+
+template <int E>
+__device__ __forceinline__ void block_emit(const uint32_t (&x0)[E], const uint32_t (&cnt)[E],
                                            const uint32_t (&dn)[E], const uint32_t (&hn)[E],
                                            uint32_t d_in, uint32_t a, uint32_t trash, uint32_t ell,
                                            uint32_t L, uint32_t lane, uint32_t last_lane,
@@ -852,7 +892,7 @@ __device__ __forceinline__ void block_emit(const SweepLoads<E>& cur, const Block
         const uint32_t i = lane * E + r;
         const uint32_t p = a + i;
         // unconditional store: slots outside the contig write the spare entry selend[ltot]
-        csel[(i < ell && p < L) ? p : trash] = cur.x0[r] + (t.cnt[r] - (dn[r] - prev));
+        csel[(i < ell && p < L) ? p : trash] = x0[r] + (cnt[r] - (dn[r] - prev));
         prev = dn[r];
         if ((uint32_t)r == last_r) pick = dn[r];
         h[r] = hn[r];
@@ -860,64 +900,85 @@ __device__ __forceinline__ void block_emit(const SweepLoads<E>& cur, const Block
     d_last = __builtin_amdgcn_readlane(pick, last_lane);
 }
 
+// `pr` describes the block being solved; `nxt_ld` / `a_next` the block after it, whose terms
+// are prepared here (into `nx`) in the shadow of this block's verification scan.
 template <int E>
-__device__ __forceinline__ bool sweep_block_fast(const SweepLoads<E>& cur, uint32_t a,
-                                                 uint32_t trash, uint32_t ell, uint32_t L,
-                                                 uint32_t M, uint32_t lane, uint32_t last_lane,
-                                                 uint32_t last_r, uint32_t (&h)[E],
-                                                 uint32_t& d_last, uint32_t* __restrict__ csel) {
-    BlockTerms<E> t;
-    block_terms<E>(cur, a, ell, L, M, lane, t);
-    uint32_t C[E], dn[E], hn[E];
-    // inclusive prefix of the counts over the block (independent of the chain)
-    uint32_t lsum = 0;
-#pragma unroll
-    for (int r = 0; r < E; ++r) { lsum += t.cnt[r]; C[r] = lsum; }
-    const uint32_t before = QMCP_DPP(0u, wave_incl_scan_add(lsum), 0x138, 0xF);  // lower lanes
-#pragma unroll
-    for (int r = 0; r < E; ++r) C[r] += before;
-
+__device__ __forceinline__ bool sweep_block_fast(const BlockPrep<E>& pr, uint32_t a,
+                                                 const SweepLoads<E>& nxt_ld, uint32_t a_next,
+                                                 BlockPrep<E>& nx, uint32_t trash, uint32_t ell,
+                                                 uint32_t L, uint32_t M, uint32_t lane,
+                                                 uint32_t last_lane, uint32_t last_r,
+                                                 uint32_t (&h)[E], uint32_t& d_last,
+                                                 uint32_t* __restrict__ csel) {
+    uint32_t dn[E], hn[E];
     // prefix-min of (h - C) and exclusive suffix-min of h over the previous block.
     // h < 2^31 and (h - C) >= -2^28, so the signed arithmetic cannot overflow.
     int32_t lp[E];
-    int32_t lrun = 0x7FFFFFFF;
+    int32_t pm = 0x7FFFFFFF;
     uint32_t sx[E];
-    uint32_t srun = kInf;
+    uint32_t sm = 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        lrun = min(lrun, (int32_t)h[r] - (int32_t)C[r]);
-        lp[r] = lrun;
+        pm = min(pm, (int32_t)h[r] - (int32_t)pr.C[r]);
+        lp[r] = pm;
     }
 #pragma unroll
     for (int r = E - 1; r >= 0; --r) {
-        sx[r] = srun;  // min over slots r' > r of this lane
-        srun = min(srun, h[r]);
+        sx[r] = sm;  // min over slots r' > r of this lane
+        sm = min(sm, h[r]);
     }
-    const int32_t pp = __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)wave_incl_scan_min_i32(lrun),
-                                                   0x138, 0xF, 0xF, false);
-    const uint32_t after = wave_excl_suffix_min(srun);
+    const uint32_t srun = sm;
+    // interleaved: inclusive prefix-min of pm (row_shr ...) and inclusive suffix-min of sm (row_shl ...)
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x111, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x101, 0xF));
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x112, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x102, 0xF));
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x114, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x104, 0xF));
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x118, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x108, 0xF));
+    const uint32_t r1 = __builtin_amdgcn_readlane(sm, 16);
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x142, 0xA));
+    const uint32_t r2 = __builtin_amdgcn_readlane(sm, 32);
+    const uint32_t r3 = __builtin_amdgcn_readlane(sm, 48);
+    pm = min(pm, QMCP_DPP_IMIN(pm, 0x143, 0xC));
+    {
+        const uint32_t row = lane >> 4;
+        const uint32_t off1 = row < 1 ? 0u : 0xFFFFFFFFu;  // rows that lie above this lane's row
+        const uint32_t off2 = row < 2 ? 0u : 0xFFFFFFFFu;
+        const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
+        sm = min(min(sm, r1 | off1), min(r2 | off2, r3 | off3));  // inclusive suffix min
+    }
+    const int32_t pp = __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false);
+    const uint32_t after = QMCP_DPP(0xFFFFFFFFu, sm, 0x130, 0xF);  // lanes above (all-ones: none)
 
     // d entering the lane = d' at the last slot of the lane below (C = before, prefix-min = pp,
     // suffix = everything from this lane's first slot on); for lane 0 it is d_last.
-    uint32_t d_in = min(min(d_last + before, (uint32_t)(pp + (int32_t)before)), min(srun, after));
+    uint32_t d_in = min(min(d_last + pr.before, (uint32_t)(pp + (int32_t)pr.before)), min(srun, after));
     d_in = lane == 0 ? d_last : d_in;
-    uint32_t lmin = kInf;
+    uint32_t vm = 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const uint32_t viaP = (uint32_t)((int32_t)C[r] + min(pp, lp[r]));
-        dn[r] = min(min(d_last + C[r], viaP), min(sx[r], after));
-        hn[r] = dn[r] + t.exj[r];
-        lmin = min(lmin, hn[r]);
+        const uint32_t viaP = (uint32_t)((int32_t)pr.C[r] + min(pp, lp[r]));
+        dn[r] = min(min(d_last + pr.C[r], viaP), min(sx[r], after));
+        hn[r] = dn[r] + pr.exj[r];
+        vm = min(vm, hn[r]);
     }
+    // interleaved: verification scan (inclusive prefix-min of the lanes' min h') and the next
+    // block's count prefix (inclusive prefix-sum of its lane sums)
+    uint32_t cs = prep_local<E>(nxt_ld, a_next, ell, L, M, lane, nx);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x111, 0xF));  cs += QMCP_DPP(0u, cs, 0x111, 0xF);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x112, 0xF));  cs += QMCP_DPP(0u, cs, 0x112, 0xF);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x114, 0xF));  cs += QMCP_DPP(0u, cs, 0x114, 0xF);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x118, 0xF));  cs += QMCP_DPP(0u, cs, 0x118, 0xF);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x142, 0xA));  cs += QMCP_DPP(0u, cs, 0x142, 0xA);
+    vm = min(vm, QMCP_DPP_UMIN(vm, 0x143, 0xC));  cs += QMCP_DPP(0u, cs, 0x143, 0xC);
+    prep_finish<E>(nx, cs);
     // m entering this lane = min of h' over all lower lanes
-    uint32_t run = QMCP_DPP(kInf, wave_incl_scan_min(lmin), 0x138, 0xF);
+    uint32_t run = QMCP_DPP(0xFFFFFFFFu, vm, 0x138, 0xF);
     bool undercut = false;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         undercut |= run < dn[r];
         run = min(run, hn[r]);
     }
-    block_emit<E>(cur, t, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+    block_emit<E>(pr.x0, pr.cnt, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
     return __any(undercut);
 }
 
@@ -935,7 +996,7 @@ __device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint3
         uint32_t srun = kInf;
 #pragma unroll
         for (int r = E - 1; r >= 0; --r) { srun = min(srun, h[r]); sufA[r] = srun; }
-        const uint32_t after = wave_excl_suffix_min(srun);
+        const uint32_t after = min(wave_excl_suffix_min(srun), kInf);
 #pragma unroll
         for (int r = 0; r < E; ++r) sufA[r] = min(sufA[r], after);  // min_{j >= i} h(j)
     }
@@ -966,7 +1027,26 @@ __device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint3
         hn[r] = dd + t.exj[r];
         m = min(m, hn[r]);
     }
-    block_emit<E>(cur, t, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+    block_emit<E>(cur.x0, t.cnt, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+}
+
+// blocks [b_begin, b_end) in the general form, loads of block b+1 in flight under block b
+template <int E>
+__device__ __forceinline__ void sweep_full_run(const uint32_t* __restrict__ cb, uint32_t b_begin,
+                                               uint32_t b_end, uint32_t trash, uint32_t ell,
+                                               uint32_t L, uint32_t M, uint32_t lane,
+                                               uint32_t last_lane, uint32_t last_r,
+                                               uint32_t (&h)[E], uint32_t& d_last,
+                                               uint32_t* __restrict__ csel) {
+    SweepLoads<E> T0, T1;
+    sweep_load<E>(cb, b_begin * ell, ell, L, lane, T0);
+    for (uint32_t b = b_begin; b < b_end; b += 2) {
+        sweep_load<E>(cb, (b + 1) * ell, ell, L, lane, T1);
+        sweep_block_full<E>(T0, b * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+        sweep_load<E>(cb, (b + 2) * ell, ell, L, lane, T0);
+        if (b + 1 < b_end)
+            sweep_block_full<E>(T1, (b + 1) * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+    }
 }
 
 template <int E>
@@ -1014,53 +1094,68 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     // pipeline restarts behind it.
     const uint32_t n_groups = n_blocks / 4;
     uint32_t g = 0;
+    uint32_t penalty = 0;  // groups to run in the general form after a failed fast attempt
     while (g < n_groups) {
+        if (penalty > 0) {
+            // sparse / low-coverage stretch: the fast form keeps failing here, do not try it
+            const uint32_t run = min(penalty, n_groups - g);
+            sweep_full_run<E>(cb, g * 4, (g + run) * 4, trash, ell, L, M, lane, last_lane, last_r, h,
+                              d_last, csel);
+            n_full += run * 4;
+            g += run;
+            if (g >= n_groups) break;
+        }
+        // pipeline start: loads for the group's first four blocks, terms of its first block
         SweepLoads<E> S0, S1, S2, S3;
+        BlockPrep<E> PA, PB;
         sweep_load<E>(cb, g * 4 * ell, ell, L, lane, S0);
         sweep_load<E>(cb, (g * 4 + 1) * ell, ell, L, lane, S1);
         sweep_load<E>(cb, (g * 4 + 2) * ell, ell, L, lane, S2);
+        sweep_load<E>(cb, (g * 4 + 3) * ell, ell, L, lane, S3);
+        prep_block<E>(S0, g * 4 * ell, ell, L, M, lane, PA);
         uint32_t h_save[E];
         uint32_t d_save = d_last;
         bool bad = false;
+        uint32_t good = 0;
         for (; g < n_groups; ++g) {
             const uint32_t a = g * 4 * ell;
 #pragma unroll
             for (int r = 0; r < E; ++r) h_save[r] = h[r];
             d_save = d_last;
-#define QMCP_FAST(SET_USE, pos) \
-    sweep_block_fast<E>(SET_USE, pos, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel)
-            sweep_load<E>(cb, a + 3 * ell, ell, L, lane, S3);
-            bad = QMCP_FAST(S0, a);
+            // block k solves with terms prepared during block k-1 and prepares block k+1 from
+            // loads issued three blocks earlier; S_k is re-loaded for block k+4 once consumed
+#define QMCP_FAST(PR, pos, LD_NEXT, PR_NEXT)                                                        \
+    sweep_block_fast<E>(PR, pos, LD_NEXT, (pos) + ell, PR_NEXT, trash, ell, L, M, lane, last_lane,  \
+                        last_r, h, d_last, csel)
             sweep_load<E>(cb, a + 4 * ell, ell, L, lane, S0);
-            bad |= QMCP_FAST(S1, a + ell);
+            bad = QMCP_FAST(PA, a, S1, PB);
             sweep_load<E>(cb, a + 5 * ell, ell, L, lane, S1);
-            bad |= QMCP_FAST(S2, a + 2 * ell);
+            bad |= QMCP_FAST(PB, a + ell, S2, PA);
             sweep_load<E>(cb, a + 6 * ell, ell, L, lane, S2);
-            bad |= QMCP_FAST(S3, a + 3 * ell);
+            bad |= QMCP_FAST(PA, a + 2 * ell, S3, PB);
+            sweep_load<E>(cb, a + 7 * ell, ell, L, lane, S3);
+            bad |= QMCP_FAST(PB, a + 3 * ell, S0, PA);
 #undef QMCP_FAST
             if (bad) break;
+            ++good;
         }
         if (bad) {
-            // redo group g in the general form (its stores overwrite the speculative ones)
+            // redo group g in the general form (its stores overwrite the speculative ones);
+            // back off from the fast form: 1, 3, 7, ... 63 groups, reset by a fast success
 #pragma unroll
             for (int r = 0; r < E; ++r) h[r] = h_save[r];
             d_last = d_save;
-            for (uint32_t k = 0; k < 4; ++k) {
-                SweepLoads<E> T;
-                sweep_load<E>(cb, (g * 4 + k) * ell, ell, L, lane, T);
-                sweep_block_full<E>(T, (g * 4 + k) * ell, trash, ell, L, M, lane, last_lane, last_r, h,
-                                    d_last, csel);
-            }
+            sweep_full_run<E>(cb, g * 4, g * 4 + 4, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
             n_full += 4;
             ++g;
+            penalty = good > 0 ? 1u : min(2 * penalty + 1, 63u);
+        } else {
+            penalty = 0;
         }
     }
     // tail: at most three blocks, general form
-    for (uint32_t b = n_groups * 4; b < n_blocks; ++b) {
-        SweepLoads<E> T;
-        sweep_load<E>(cb, b * ell, ell, L, lane, T);
-        sweep_block_full<E>(T, b * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
-    }
+    if (n_groups * 4 < n_blocks)
+        sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
     if (iter_stats && lane == 0) {
         atomicAdd(&iter_stats[0], n_full);
         atomicAdd(&iter_stats[1], n_blocks);

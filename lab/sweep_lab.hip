@@ -1,0 +1,43 @@
+// Timing lab for the uniform sweep (not part of the product): runs the production kernel on
+// synthetic bucket offsets.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I<csrc>
+#include "../genome-downsampler_amd/csrc/qmcp_kernels.hip"
+#include <cstdio>
+#include <random>
+#include <vector>
+using namespace qmcp;
+
+static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, uint32_t M, int contigs) {
+    std::mt19937 g(1);
+    std::poisson_distribution<int> pd(mean);
+    const uint64_t Lt = (uint64_t)L * contigs;
+    std::vector<uint32_t> boff(Lt + 1, 0);
+    for (uint64_t p = 0; p < Lt; ++p) boff[p + 1] = boff[p] + ((p % L) + ell <= L ? pd(g) : 0);
+    std::vector<uint64_t> poff(contigs + 1);
+    for (int c = 0; c <= contigs; ++c) poff[c] = (uint64_t)c * L;
+    uint32_t *d_boff, *d_sel, *d_it; uint64_t* d_poff;
+    hipMalloc(&d_boff, (Lt + 1) * 4); hipMalloc(&d_sel, (Lt + 2) * 4); hipMalloc(&d_it, 64);
+    hipMalloc(&d_poff, (contigs + 1) * 8);
+    hipMemcpy(d_boff, boff.data(), (Lt + 1) * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_poff, poff.data(), (contigs + 1) * 8, hipMemcpyHostToDevice);
+    hipMemset(d_it, 0, 64);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); float best = 1e9;
+    const int reps = 5;
+    for (int it = 0; it < reps; ++it) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it);
+        hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    uint32_t it2[2]; hipMemcpy(it2, d_it, 8, hipMemcpyDeviceToHost);
+    const uint32_t nb = (L + ell - 1) / ell;
+    printf("%-34s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form blocks %u of %u)\n", name, best,
+           best * 1e6 / nb, best * 1e6 / nb * 2.4, it2[0] / reps, it2[1] / reps);
+    hipFree(d_boff); hipFree(d_sel); hipFree(d_it); hipFree(d_poff);
+}
+
+int main() {
+    run_case("deep 12.5/pos, 1 contig", 12.5, 1000000, 150, 100, 1);
+    run_case("deep 12.5/pos, 8 contigs", 12.5, 1000000, 150, 100, 8);
+    run_case("sparse 0.67/pos M=50, 1 contig", 0.67, 1000000, 150, 50, 1);
+    run_case("shallow 0.3/pos M=50 (cut points)", 0.3, 1000000, 150, 50, 1);
+    return 0;
+}
