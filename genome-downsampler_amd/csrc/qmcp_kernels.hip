@@ -1162,6 +1162,277 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------ uniform sweep, three waves
+// Same algorithm as k_sweep_uniform, with the work of a group of four blocks split over three
+// waves of one workgroup (one workgroup per contig) that advance in lockstep, one
+// __syncthreads() per group, all hand-offs through LDS (no spinning, uniform control flow):
+//   wave 0  PREP    loads bucket offsets and prepares the chain-independent terms of group t
+//   wave 1  CHAIN   solves group t-1 in the fast form: only the two min-scans and the combine
+//                   remain on the serial path
+//   wave 2  CHECK   verifies group t-2 (running-minimum test) and stores its results
+// If CHECK finds an undercut in group f, every wave sees the flag after the barrier; the chain
+// wave restores its state from the start of group f, redoes f (and, while the fast form keeps
+// failing, a growing run of following groups) alone in the general form, and the pipeline
+// restarts behind it.  Nothing of a failed group is stored by CHECK (it verifies all four blocks
+// before storing), and the chain wave is at most one group ahead of it, so no speculative value
+// ever reaches memory.
+// LDS: three group slots x four blocks x (6E + 2) words x 64 lanes, word-major (conflict-free).
+template <int E>
+struct MwLayout {
+    static constexpr int kC = 0;            // [E]  inclusive count prefix       PREP -> CHAIN
+    static constexpr int kEx = E;           // [E]  ex at the jump landing       PREP -> CHAIN
+    static constexpr int kBefore = 2 * E;   // [1]  counts of lower lanes        PREP -> CHAIN
+    static constexpr int kX0 = 2 * E + 1;   // [E]  bucket offsets               PREP -> CHECK
+    static constexpr int kCnt = 3 * E + 1;  // [E]  counts                       PREP -> CHECK
+    static constexpr int kDn = 4 * E + 1;   // [E]  distances                    CHAIN -> CHECK
+    static constexpr int kHn = 5 * E + 1;   // [E]  h'                           CHAIN -> CHECK
+    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the lane          CHAIN -> CHECK
+    static constexpr int kWords = 6 * E + 2;
+    static constexpr int kSlots = 3;
+    static constexpr size_t kBytes = (size_t)kSlots * 4 * kWords * 64 * sizeof(uint32_t) + 64;
+};
+
+template <int E>
+__global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
+                                                          const uint64_t* __restrict__ contig_pos_off,
+                                                          uint32_t ell, uint32_t M, uint32_t ltot,
+                                                          uint32_t* __restrict__ selend,
+                                                          uint32_t* __restrict__ iter_stats) {
+    using Ly = MwLayout<E>;
+    extern __shared__ uint32_t s_mw[];
+    uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * 4 * Ly::kWords * 64;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t role = threadIdx.x >> 6;  // 0 PREP, 1 CHAIN, 2 CHECK
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    if (L == 0) return;
+    const uint32_t n_blocks = (L + ell - 1) / ell;
+    const uint32_t n_groups = n_blocks / 4;
+    const uint32_t* __restrict__ cb = boff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    const uint32_t trash = ltot - base;
+    const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
+    if (role == 1) __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) s_flag[0] = 0;
+
+    // chain state (meaningful in the CHAIN wave only)
+    uint32_t h[E];
+    {
+        const uint32_t b0 = cb[0];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            const uint32_t cov = cb[min(i + 1, L)] - b0;
+            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
+        }
+    }
+    uint32_t d_last = 0;
+    uint32_t h_prev[E], h_cur[E];  // state at the start of the previous / current chain group
+    uint32_t d_prev = 0, d_cur = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) { h_prev[r] = h[r]; h_cur[r] = h[r]; }
+    uint32_t n_full = 0;
+    uint32_t penalty = 0;
+    uint32_t g0 = 0;
+    __syncthreads();
+
+#define MW_AT(slot, k, w) s_mw[(((slot) * 4 + (k)) * Ly::kWords + (w)) * 64 + lane]
+
+    while (g0 < n_groups) {
+        if (penalty > 0) {
+            const uint32_t run = min(penalty, n_groups - g0);
+            if (role == 1) {
+                sweep_full_run<E>(cb, g0 * 4, (g0 + run) * 4, trash, ell, L, M, lane, last_lane, last_r,
+                                  h, d_last, csel);
+                n_full += run * 4;
+            }
+            g0 += run;
+            if (g0 >= n_groups) break;
+        }
+        // pipeline over groups g0, g0+1, ...: stage t has PREP on g0+t, CHAIN on g0+t-1, CHECK on g0+t-2
+        const uint32_t n_left = n_groups - g0;
+        uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
+        SweepLoads<E> ld[4];
+        if (role == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sweep_load<E>(cb, (g0 * 4 + k) * ell, ell, L, lane, ld[k]);
+        }
+        if (role == 1) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) { h_prev[r] = h[r]; h_cur[r] = h[r]; }
+            d_prev = d_last; d_cur = d_last;
+        }
+        for (uint32_t t = 0; t < n_left + 2; ++t) {
+            if (role == 0) {
+                if (t < n_left) {
+                    const uint32_t g = g0 + t;
+                    const uint32_t slot = g % Ly::kSlots;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        BlockPrep<E> pr;
+                        prep_block<E>(ld[k], (g * 4 + k) * ell, ell, L, M, lane, pr);
+                        // loads of the same block of the NEXT group: a whole stage to land
+                        sweep_load<E>(cb, ((g + 1) * 4 + k) * ell, ell, L, lane, ld[k]);
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            MW_AT(slot, k, Ly::kC + r) = pr.C[r];
+                            MW_AT(slot, k, Ly::kEx + r) = pr.exj[r];
+                            MW_AT(slot, k, Ly::kX0 + r) = pr.x0[r];
+                            MW_AT(slot, k, Ly::kCnt + r) = pr.cnt[r];
+                        }
+                        MW_AT(slot, k, Ly::kBefore) = pr.before;
+                    }
+                }
+            } else if (role == 1) {
+                if (t >= 1 && t <= n_left) {
+                    const uint32_t g = g0 + t - 1;
+                    const uint32_t slot = g % Ly::kSlots;
+#pragma unroll
+                    for (int r = 0; r < E; ++r) { h_prev[r] = h_cur[r]; h_cur[r] = h[r]; }
+                    d_prev = d_cur; d_cur = d_last;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t C[E], exj[E];
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            C[r] = MW_AT(slot, k, Ly::kC + r);
+                            exj[r] = MW_AT(slot, k, Ly::kEx + r);
+                        }
+                        const uint32_t before = MW_AT(slot, k, Ly::kBefore);
+                        // the two chain scans, interleaved (see sweep_block_fast)
+                        int32_t lp[E];
+                        int32_t pm = 0x7FFFFFFF;
+                        uint32_t sx[E];
+                        uint32_t sm = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int r = 0; r < E; ++r) { pm = min(pm, (int32_t)h[r] - (int32_t)C[r]); lp[r] = pm; }
+#pragma unroll
+                        for (int r = E - 1; r >= 0; --r) { sx[r] = sm; sm = min(sm, h[r]); }
+                        const uint32_t srun = sm;
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x111, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x101, 0xF));
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x112, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x102, 0xF));
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x114, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x104, 0xF));
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x118, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x108, 0xF));
+                        const uint32_t r1 = __builtin_amdgcn_readlane(sm, 16);
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x142, 0xA));
+                        const uint32_t r2 = __builtin_amdgcn_readlane(sm, 32);
+                        const uint32_t r3 = __builtin_amdgcn_readlane(sm, 48);
+                        pm = min(pm, QMCP_DPP_IMIN(pm, 0x143, 0xC));
+                        {
+                            const uint32_t row = lane >> 4;
+                            const uint32_t off1 = row < 1 ? 0u : 0xFFFFFFFFu;
+                            const uint32_t off2 = row < 2 ? 0u : 0xFFFFFFFFu;
+                            const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
+                            sm = min(min(sm, r1 | off1), min(r2 | off2, r3 | off3));
+                        }
+                        const int32_t pp = __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false);
+                        const uint32_t after = QMCP_DPP(0xFFFFFFFFu, sm, 0x130, 0xF);
+                        uint32_t d_in = min(min(d_last + before, (uint32_t)(pp + (int32_t)before)), min(srun, after));
+                        d_in = lane == 0 ? d_last : d_in;
+                        uint32_t pick = 0;
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            const uint32_t viaP = (uint32_t)((int32_t)C[r] + min(pp, lp[r]));
+                            const uint32_t dnr = min(min(d_last + C[r], viaP), min(sx[r], after));
+                            const uint32_t hnr = dnr + exj[r];
+                            MW_AT(slot, k, Ly::kDn + r) = dnr;
+                            MW_AT(slot, k, Ly::kHn + r) = hnr;
+                            if ((uint32_t)r == last_r) pick = dnr;
+                            h[r] = hnr;
+                        }
+                        MW_AT(slot, k, Ly::kDin) = d_in;
+                        d_last = __builtin_amdgcn_readlane(pick, last_lane);
+                    }
+                }
+            } else {
+                if (t >= 2) {
+                    const uint32_t g = g0 + t - 2;
+                    const uint32_t slot = g % Ly::kSlots;
+                    uint32_t sel[4][E];
+                    bool undercut = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t dn[E], hn[E];
+                        uint32_t vm = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            dn[r] = MW_AT(slot, k, Ly::kDn + r);
+                            hn[r] = MW_AT(slot, k, Ly::kHn + r);
+                            vm = min(vm, hn[r]);
+                        }
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x111, 0xF));
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x112, 0xF));
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x114, 0xF));
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x118, 0xF));
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x142, 0xA));
+                        vm = min(vm, QMCP_DPP_UMIN(vm, 0x143, 0xC));
+                        uint32_t run = QMCP_DPP(0xFFFFFFFFu, vm, 0x138, 0xF);
+                        uint32_t prev = MW_AT(slot, k, Ly::kDin);
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            undercut |= run < dn[r];
+                            run = min(run, hn[r]);
+                            sel[k][r] = MW_AT(slot, k, Ly::kX0 + r) + (MW_AT(slot, k, Ly::kCnt + r) - (dn[r] - prev));
+                            prev = dn[r];
+                        }
+                    }
+                    if (__any(undercut)) {
+                        if (lane == 0) s_flag[0] = 1;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                            for (int r = 0; r < E; ++r) {
+                                const uint32_t i = lane * E + r;
+                                const uint32_t p = (g * 4 + k) * ell + i;
+                                csel[(i < ell && p < L) ? p : trash] = sel[k][r];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (t >= 2 && s_flag[0] != 0) { failed = g0 + t - 2; break; }
+        }
+        if (failed == 0xFFFFFFFFu) { g0 = n_groups; break; }
+        // group `failed` needs the general form.  CHAIN was working on failed+1 (or had finished):
+        // its state at the start of `failed` is h_prev when it had moved on to failed+1, else h_cur
+        __syncthreads();  // everyone has read the flag
+        if (threadIdx.x == 0) s_flag[0] = 0;
+        if (role == 1) {
+            const bool moved_on = (failed + 1 < n_groups) && (failed + 1 - g0 + 1 <= n_left);
+            // CHAIN solved group (g0 + t - 1) at the failing stage t = failed - g0 + 2, i.e. failed + 1,
+            // provided that group exists in this pipeline
+            if (moved_on) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) h[r] = h_prev[r];
+                d_last = d_prev;
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) h[r] = h_cur[r];
+                d_last = d_cur;
+            }
+            sweep_full_run<E>(cb, failed * 4, failed * 4 + 4, trash, ell, L, M, lane, last_lane, last_r, h,
+                              d_last, csel);
+            n_full += 4;
+        }
+        penalty = failed > g0 ? 1u : min(2 * penalty + 1, 63u);
+        g0 = failed + 1;
+        __syncthreads();
+    }
+#undef MW_AT
+    if (role == 1) {
+        if (n_groups * 4 < n_blocks)
+            sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
+                              csel);
+        if (iter_stats && lane == 0) {
+            atomicAdd(&iter_stats[0], n_full);
+            atomicAdd(&iter_stats[1], n_blocks);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ general (mixed-span) sweep
 // Event-driven form of the canonical rule for arbitrary spans.  Reads are bucketed by start
 // and ordered (end desc, index asc) inside a bucket, so the selected reads of a bucket are
@@ -1435,6 +1706,29 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
         hipLaunchKernelGGL(k_radix_scatter<uint32_t>, dim3(n_tiles), dim3(kSortThreads), 0, st,
                            (const uint32_t*)keys_in, vals_in, n, shift, n_tiles, offs,
                            (uint32_t*)keys_out, vals_out);
+}
+
+bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                             uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                             uint32_t* selend, uint32_t* iter_stats) {
+    const uint32_t e = (ell + 63) / 64;
+#define QMCP_SWEEP_MW(EE)                                                                              \
+    {                                                                                                   \
+        const size_t lds = MwLayout<EE>::kBytes;                                                        \
+        (void)hipFuncSetAttribute((const void*)k_sweep_uniform_mw<EE>,                                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(192), lds, st, boff, d_poff,   \
+                           ell, M, ltot, selend, iter_stats);                                           \
+    }
+    switch (e) {
+        case 1: QMCP_SWEEP_MW(1); break;
+        case 2: QMCP_SWEEP_MW(2); break;
+        case 3: QMCP_SWEEP_MW(3); break;
+        case 4: QMCP_SWEEP_MW(4); break;
+        default: return false;  // wider spans: single-wave kernel
+    }
+#undef QMCP_SWEEP_MW
+    return true;
 }
 
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,

@@ -31,6 +31,28 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
     const uint32_t nb = (L + ell - 1) / ell;
     printf("%-34s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form blocks %u of %u)\n", name, best,
            best * 1e6 / nb, best * 1e6 / nb * 2.4, it2[0] / reps, it2[1] / reps);
+    // three-wave kernel on the same data: must produce identical selend
+    {
+        std::vector<uint32_t> ref(Lt + 1), got(Lt + 1);
+        hipMemcpy(ref.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
+        hipMemset(d_sel, 0xEE, (Lt + 1) * 4);
+        hipMemset(d_it, 0, 64);
+        float best2 = 1e9;
+        bool ok = true;
+        for (int it = 0; it < reps; ++it) {
+            hipEventRecord(a);
+            ok = launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it);
+            hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best2) best2 = ms;
+        }
+        hipError_t e = hipDeviceSynchronize();
+        hipMemcpy(got.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(it2, d_it, 8, hipMemcpyDeviceToHost);
+        size_t diff = 0, first = 0;
+        for (uint64_t i = 0; i < Lt; ++i) if (ref[i] != got[i]) { if (!diff) first = i; ++diff; }
+        printf("   three-wave: %s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form %u) mismatches %zu (first at %zu) %s\n",
+               ok ? "" : "(unsupported span)", best2, best2 * 1e6 / nb, best2 * 1e6 / nb * 2.4, it2[0] / reps, diff, first,
+               hipGetErrorString(e));
+    }
     hipFree(d_boff); hipFree(d_sel); hipFree(d_it); hipFree(d_poff);
 }
 
@@ -39,5 +61,7 @@ int main() {
     run_case("deep 12.5/pos, 8 contigs", 12.5, 1000000, 150, 100, 8);
     run_case("sparse 0.67/pos M=50, 1 contig", 0.67, 1000000, 150, 50, 1);
     run_case("shallow 0.3/pos M=50 (cut points)", 0.3, 1000000, 150, 50, 1);
+    run_case("mixed: deep with sparse holes", 12.5, 100003, 150, 100, 3);
+    run_case("tiny contigs", 5.0, 1000, 150, 20, 5);
     return 0;
 }
