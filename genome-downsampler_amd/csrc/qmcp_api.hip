@@ -59,7 +59,7 @@ struct qmcp_hip_ctx {
     // arena (grow-only, reused across solves like a reference solver instance's members)
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
-    DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp;
+    DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
@@ -461,11 +461,34 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     } else {
         uint32_t ring = 64;
         while (ring <= max_span) ring <<= 1;
-        KernelSpan sp(c, "k_sweep_general");
-        qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
-                                   (const uint32_t*)c->eoff.p, c->keys[kin].p,
-                                   (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
-                                   (uint32_t*)c->selend.p, ring);
+        if (max_span <= qmcp::kMaxCachedSpan) {
+            ring = 64;
+            while (ring < max_span + 64) ring <<= 1;  // 64 buckets enter per chunk
+            // run lengths of equal (start, end) groups: heads + reverse min-scan -> next_head[]
+            TRY(ensure(c, c->next_head, ((size_t)n + 2) * sizeof(uint32_t)));
+            TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries(n + 1) + 1) * sizeof(uint32_t) + 16));
+            {
+                KernelSpan sp(c, "k_group_heads");
+                qmcp::launch_group_heads(c->stream, wide, c->keys[kin].p, n, (uint32_t*)c->next_head.p);
+            }
+            {
+                KernelSpan sp(c, "reverse_min_scan(3 kernels)");
+                qmcp::launch_reverse_min_scan(c->stream, (uint32_t*)c->next_head.p, n + 1,
+                                              (uint32_t*)c->spine.p);
+            }
+            KernelSpan sp(c, "k_sweep_general_cached");
+            qmcp::launch_sweep_general_cached(c->stream, wide, (const uint32_t*)c->boff.p,
+                                              (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                              (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
+                                              n_contigs, span_bits, max_span, M,
+                                              (uint32_t*)c->selend.p, ring);
+        } else {
+            KernelSpan sp(c, "k_sweep_general");
+            qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
+                                       (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                       (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
+                                       (uint32_t*)c->selend.p, ring);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], c->stream));
@@ -613,7 +636,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -9,6 +9,8 @@ namespace qmcp {
 
 static constexpr uint32_t kMaxGeneralSpan = 16383;  // two LDS rings of 16384 u32 = 128 KiB
 static constexpr uint32_t kMaxUniformSpan = 512;    // 8 positions per lane in the block sweep
+static constexpr uint32_t kMaxCachedSpan = 4032;    // LDS-cached mixed-span sweep: 8 words x 4096 slots,
+                                                    // ring >= max_span + 64 (a chunk enters 64 buckets at once)
 
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
@@ -37,6 +39,12 @@ void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
                           uint32_t ring_size);
+void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t n,
+                        uint32_t* next_head /* n + 1 entries; reverse-min-scan it afterwards */);
+void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff,
+                                 const uint32_t* eoff, const void* sorted, const uint32_t* next_head,
+                                 const uint64_t* d_poff, uint32_t n_contigs, uint32_t span_bits,
+                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring);
 // `sorted` is a Rec{key,val} array (wide == false) or u64 keys with `svals` beside them
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
                  uint32_t span_bits, const uint32_t* selend, uint64_t* mask,

@@ -1535,6 +1535,173 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
     const uint32_t first = L > ring_size ? L - ring_size : 0u;
     for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + s_ptr[q & rmask];
 }
+// ------------------------------------------------------------------ mixed-span sweep, LDS-cached
+// Same rule as k_sweep_general, organised so that the serial loop touches LDS only:
+//   * a preprocessing pass marks run heads of equal composite keys (a "group": reads with the
+//     same start and end) and a reverse min-scan turns them into next_head[], so the length of
+//     the run starting at j is next_head[j + 1] - j;
+//   * positions are taken 64 at a time: bucket bounds, coverage and the first TWO groups of
+//     every entering bucket are loaded with wave-wide (not serially dependent) loads into an LDS
+//     ring of `ring` slots (power of two >= max_span + 64, so that a slot is only recycled once
+//     its previous bucket is dead even for the last position of a chunk), and the previous
+//     occupants of those slots flush their selected counts to selend;
+//   * a selection event is a wave-wide maximum over the cached bucket heads, key
+//     (end - p + 1) << 16 | (0xFFFF - (p - q)): largest end, then largest start; it takes
+//     min(deficit, run) reads from the winning group.  Only when a bucket has used up both cached
+//     groups is its next group fetched from memory.
+// One wave per contig; spans up to kMaxCachedSpan.
+struct GenSlots {  // layout of the LDS ring, in 32-bit words per slot
+    // G0 / G1: (end + 1, run) of the bucket's head group and of the cached second group,
+    // 8 bytes each so one ds_read_b64 fetches both fields
+    enum { kG0 = 0, kG1 = 2, kNextJ = 4, kB1 = 5, kTaken = 6, kExp = 7, kWords = 8 };
+};
+
+template <typename Sorted>
+__global__ __launch_bounds__(256) void k_group_heads(Sorted skeys, uint32_t n,
+                                                     uint32_t* __restrict__ next_head) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += stride) {
+        uint32_t v = 0xFFFFFFFFu;
+        if (j == n) v = n;
+        else if (j == 0 || skeys.key(j - 1) != skeys.key(j)) v = j;
+        next_head[j] = v;
+    }
+}
+
+template <typename Sorted>
+__global__ __launch_bounds__(64) void k_sweep_general_cached(
+    const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
+    const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend, uint32_t ring) {
+    extern __shared__ uint32_t s_gen[];
+    uint2* s_g0 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG0 * ring);
+    uint2* s_g1 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG1 * ring);
+    uint32_t* s_nextj = s_gen + GenSlots::kNextJ * ring;
+    uint32_t* s_b1 = s_gen + GenSlots::kB1 * ring;
+    uint32_t* s_taken = s_gen + GenSlots::kTaken * ring;
+    uint32_t* s_exp = s_gen + GenSlots::kExp * ring;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    const uint32_t rmask = ring - 1;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    for (uint32_t i = lane; i < GenSlots::kWords * ring; i += 64) s_gen[i] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ cb = boff + base;
+    const uint32_t* __restrict__ ce = eoff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    uint32_t cur = 0;
+    // One wave per workgroup: its LDS operations execute in program order, so lane-0 updates
+    // are visible to every lane's next read without barriers.
+    for (uint32_t p0 = 0; p0 < L; p0 += 64) {
+        // ---- enter the chunk's 64 buckets (lane = position p0 + lane)
+        const uint32_t q = p0 + lane;
+        const uint32_t slot = q & rmask;
+        uint32_t need = 0;
+        uint32_t exp_c = 0;  // selected reads ending at position p0 + lane
+        if (q < L) {
+            if (q >= ring) csel[q - ring] = cb[q - ring] + s_taken[slot];  // recycled slot
+            exp_c = s_exp[slot];
+            s_exp[slot] = 0;
+            const uint32_t b0 = cb[q], b1 = cb[q + 1];
+            need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
+            uint2 g0 = make_uint2(0, 0), g1 = make_uint2(0, 0);
+            uint32_t nj = b1;
+            if (b0 < b1) {
+                const uint64_t k0 = skeys.key(b0);
+                g0.y = min(next_head[b0 + 1], b1) - b0;
+                g0.x = q + (max_span - (uint32_t)(k0 & code_mask));  // end + 1
+                const uint32_t j1 = b0 + g0.y;
+                nj = j1;
+                if (j1 < b1) {
+                    const uint64_t k1 = skeys.key(j1);
+                    g1.y = min(next_head[j1 + 1], b1) - j1;
+                    g1.x = q + (max_span - (uint32_t)(k1 & code_mask));
+                    nj = j1 + g1.y;
+                }
+            }
+            s_g0[slot] = g0;
+            s_g1[slot] = g1;
+            s_nextj[slot] = nj;
+            s_b1[slot] = b1;
+            s_taken[slot] = 0;
+        }
+        // ---- walk the chunk's positions; per-position need / expiry come from lane registers
+        const uint32_t chunk = min(64u, L - p0);
+        for (uint32_t j = 0; j < chunk; ++j) {
+            const uint32_t p = p0 + j;
+            const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
+            uint32_t k = need_p > cur ? need_p - cur : 0u;
+            while (k > 0) {
+                // best live head among buckets q' in (p - max_span, p]:
+                // key = (end + 1 - p) << 16 | (0xFFFF - (p - q')): largest end, then largest start
+                uint32_t best = 0, my_run = 0;
+                for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
+                    const uint2 g = s_g0[(p - t) & rmask];
+                    if (g.x > p) {
+                        const uint32_t key = ((g.x - p) << 16) | (0xFFFFu - t);
+                        if (key > best) { best = key; my_run = g.y; }
+                    }
+                }
+                uint32_t top = best;
+                top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+                top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+                top = __builtin_amdgcn_readlane(top, 63);
+                if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+                const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
+                const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
+                const uint32_t bq = p - (0xFFFFu - (top & 0xFFFFu));
+                const uint32_t bslot = bq & rmask;
+                const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group
+                const uint32_t take = min(k, run);
+                // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+                if (bend < p0 + 64) {
+                    exp_c += (lane == bend - p0) ? take : 0u;
+                } else if (lane == 0) {
+                    atomicAdd(&s_exp[bend & rmask], take);
+                }
+                if (lane == 0) {
+                    atomicAdd(&s_taken[bslot], take);
+                    if (take < run) {
+                        s_g0[bslot].y = run - take;
+                    } else {
+                        const uint2 g1 = s_g1[bslot];
+                        if (g1.y != 0) {
+                            // group used up: promote the cached second group (refilled lazily)
+                            s_g0[bslot] = g1;
+                            s_g1[bslot].y = 0;
+                        } else {
+                            // both cached groups used: fetch the bucket's next group, if any
+                            const uint32_t nj = s_nextj[bslot];
+                            const uint32_t b1 = s_b1[bslot];
+                            uint2 g0 = make_uint2(0, 0);
+                            if (nj < b1) {
+                                const uint64_t kk = skeys.key(nj);
+                                g0.y = min(next_head[nj + 1], b1) - nj;
+                                g0.x = bq + (max_span - (uint32_t)(kk & code_mask));
+                                s_nextj[bslot] = nj + g0.y;
+                            }
+                            s_g0[bslot] = g0;
+                        }
+                    }
+                }
+                cur += take;
+                k -= take;
+            }
+            // reads ending at p stop covering p + 1
+            cur -= __builtin_amdgcn_readlane(exp_c, j);
+        }
+    }
+    // flush the buckets still in the ring
+    const uint32_t first = L > ring ? L - ring : 0u;
+    for (uint32_t qq = first + lane; qq < L; qq += 64) csel[qq] = cb[qq] + s_taken[qq & rmask];
+}
+
 // ------------------------------------------------------------------ keep-mask emission
 // sorted entry j (bucket = its start position) is kept iff j < selend[bucket].
 // obtain_sequence counterpart (quasi_mcp_cpu_max_flow_solver.cpp:89-100).
@@ -1770,6 +1937,36 @@ void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const
         hipLaunchKernelGGL(k_sweep_general<SortedRec>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
                            SortedRec{(const Rec*)sorted}, d_poff, span_bits, max_span, M, selend,
                            ring_size);
+    }
+}
+
+void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t n,
+                        uint32_t* next_head) {
+    if (wide)
+        hipLaunchKernelGGL(k_group_heads<SortedK64>, dim3(grid_for((uint64_t)n + 1, 256)), dim3(256), 0, st,
+                           SortedK64{(const uint64_t*)sorted}, n, next_head);
+    else
+        hipLaunchKernelGGL(k_group_heads<SortedRec>, dim3(grid_for((uint64_t)n + 1, 256)), dim3(256), 0, st,
+                           SortedRec{(const Rec*)sorted}, n, next_head);
+}
+
+void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff,
+                                 const uint32_t* eoff, const void* sorted, const uint32_t* next_head,
+                                 const uint64_t* d_poff, uint32_t n_contigs, uint32_t span_bits,
+                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring) {
+    const size_t lds = (size_t)GenSlots::kWords * ring * sizeof(uint32_t);
+    if (wide) {
+        (void)hipFuncSetAttribute((const void*)k_sweep_general_cached<SortedK64>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general_cached<SortedK64>, dim3(n_contigs), dim3(64), lds, st, boff,
+                           eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,
+                           max_span, M, selend, ring);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_sweep_general_cached<SortedRec>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sweep_general_cached<SortedRec>, dim3(n_contigs), dim3(64), lds, st, boff,
+                           eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span,
+                           M, selend, ring);
     }
 }
 

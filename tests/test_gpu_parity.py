@@ -137,3 +137,24 @@ def test_cfg1_and_determinism(pkg, oracle, solver):
     assert np.array_equal(a, b)
     ok, val = oracle.check_flow(s, e, 3000, 100, a)
     assert ok and val == 100
+
+
+@pytest.mark.parametrize("max_span", [150, 1000, 4032, 4033, 6000])
+def test_mixed_span_both_sweep_kernels(pkg, oracle, solver, max_span):
+    """spans up to 4032 use the LDS-cached mixed-span sweep, wider ones the plain one"""
+    rng = np.random.default_rng(max_span)
+    L = 40_000
+    s, e = random_reads(rng, 60_000, L, max(1, max_span // 3), max_span)
+    s[0], e[0] = 100, 100 + max_span - 1  # make sure the maximum span occurs
+    _check(pkg, oracle, solver, s, e, L, 12, expect_path=pkg.PATH_GENERAL)
+
+
+def test_mixed_span_deep_amplicon_like(pkg, oracle, solver):
+    """deep coverage, a dominant span plus a tail of shorter ones (clipped reads)"""
+    rng = np.random.default_rng(77)
+    L, n = 30_000, 400_000
+    span = np.where(rng.random(n) < 0.85, 150, rng.integers(60, 150, size=n))
+    st = (rng.random(n) * (L - span + 1)).astype(np.int64)
+    s, e = st.astype(np.uint32), (st + span - 1).astype(np.uint32)
+    _check(pkg, oracle, solver, s, e, L, 200, expect_path=pkg.PATH_GENERAL)
+    _check(pkg, oracle, solver, s, e, L, 3, expect_path=pkg.PATH_GENERAL)
