@@ -210,7 +210,8 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
                              (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
                              want_keys ? (uint32_t*)c->vals[1].p : nullptr,
                              want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p,
-                             want_part_hist ? (uint32_t*)c->hist2.p : nullptr);
+                             want_part_hist ? (uint32_t*)c->hist2.p : nullptr,
+                             want_part_hist ? (uint32_t*)c->hist.p : nullptr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -385,7 +386,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         for (uint32_t p = 0; p < passes; ++p) {
             const bool first = p == 0;
             const int kout = first ? 0 : (kin ^ 1);
-            {
+            // (the first pass's histogram was produced by k_prepare on the two-stream path)
+            if (!(first && overlap)) {
                 KernelSpan sp(c, "k_radix_hist_rec");
                 qmcp::launch_radix_hist_rec(c->stream, first, d_key32, recs_in, n, 8 * p,
                                             (uint32_t*)c->hist.p);

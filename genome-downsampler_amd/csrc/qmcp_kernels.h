@@ -15,7 +15,8 @@ static constexpr uint32_t kMaxCachedSpan = 4032;    // LDS-cached mixed-span swe
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats, uint32_t* part_hist /* digit-major [256][tiles] or null */);
+                    uint32_t* stats, uint32_t* part_hist /* digit-major [256][tiles] or null */,
+                    uint32_t* digit0_hist /* same shape; written iff part_hist is */);
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
                          const uint64_t* keep_mask, void* keys, uint32_t* ecnt);

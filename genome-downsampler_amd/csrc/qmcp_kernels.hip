@@ -98,10 +98,12 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  uint32_t* __restrict__ stats,
                                                  uint32_t n_tiles, uint32_t tiles_per_block,
                                                  uint32_t part_shift,
-                                                 uint32_t* __restrict__ part_hist) {
+                                                 uint32_t* __restrict__ part_hist,
+                                                 uint32_t* __restrict__ digit0_hist) {
     __shared__ uint64_t s_roff[65];
     __shared__ uint64_t s_poff[65];
     __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_h0[256];
     const uint32_t nc = min(n_contigs, 64u);
     for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
         s_roff[i] = contig_read_off[i];
@@ -109,13 +111,15 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     __syncthreads();
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
-    // Work is laid out in the radix tiles (4096 reads) so that the per-tile histogram of the
-    // counting partition (digit = global start >> part_shift) falls out of the same pass.
+    // Work is laid out in the radix tiles (4096 reads) so that two per-tile histograms fall out
+    // of the same pass: the counting partition's (digit = global start >> part_shift) and the
+    // first radix pass's (digit = low byte of the global start, the uniform path's key).
     const uint32_t t0 = blockIdx.x * tiles_per_block;
     for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
         const uint32_t tile = t0 + g;
         if (part_hist) {
             s_h[threadIdx.x] = 0;
+            s_h0[threadIdx.x] = 0;
             __syncthreads();
         }
 #pragma unroll 4
@@ -149,7 +153,10 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             mx = max(mx, span);
             const uint32_t gs = (uint32_t)p0 + s;
             if (gstart_out) gstart_out[i] = gs;
-            if (part_hist) atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+            if (part_hist) {
+                atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+                atomicAdd(&s_h0[gs & 255u], 1u);
+            }
             if (cstart) {
                 bool on = true;
                 if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
         if (part_hist) {
             __syncthreads();
             part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
+            digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
             __syncthreads();
         }
     }
@@ -1814,13 +1822,13 @@ static inline uint32_t tiles_per_block_for(uint32_t n_tiles);
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats, uint32_t* part_hist) {
+                    uint32_t* stats, uint32_t* part_hist, uint32_t* digit0_hist) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const uint32_t g = tiles_per_block_for(n_tiles);
     hipLaunchKernelGGL(k_prepare, dim3((n_tiles + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       kCountShift, part_hist);
+                       kCountShift, part_hist, digit0_hist);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,

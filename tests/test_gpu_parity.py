@@ -158,3 +158,24 @@ def test_mixed_span_deep_amplicon_like(pkg, oracle, solver):
     s, e = st.astype(np.uint32), (st + span - 1).astype(np.uint32)
     _check(pkg, oracle, solver, s, e, L, 200, expect_path=pkg.PATH_GENERAL)
     _check(pkg, oracle, solver, s, e, L, 3, expect_path=pkg.PATH_GENERAL)
+
+
+def test_many_small_contigs(pkg, oracle, solver):
+    """300 contigs (more than the 64 the prepare kernel caches in LDS), some empty, some tiny"""
+    rng = np.random.default_rng(2024)
+    lens, counts, ss, ee = [], [], [], []
+    for c in range(300):
+        L = int(rng.integers(150, 3000))
+        n = 0 if c % 7 == 0 else int(rng.integers(1, 4000))
+        a, b = random_reads(rng, n, L, 150, 150)
+        lens.append(L); counts.append(n); ss.append(a); ee.append(b)
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    _check(pkg, oracle, solver, s, e, np.array(lens, np.uint32), 10, offs=offs, expect_path=pkg.PATH_UNIFORM)
+    # same layout with mixed spans
+    ss, ee = [], []
+    for L, n in zip(lens, counts):
+        a, b = random_reads(rng, n, L, 30, 150)
+        ss.append(a); ee.append(b)
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    _check(pkg, oracle, solver, s, e, np.array(lens, np.uint32), 10, offs=offs, expect_path=pkg.PATH_GENERAL)
