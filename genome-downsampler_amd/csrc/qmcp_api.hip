@@ -334,32 +334,35 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     if (overlap) {
-        // second stream (high priority): counts (key partition + LDS histograms), scan, sweep.
-        // The main stream goes straight on to the radix passes; both only need k_prepare.
-        hipStream_t s2 = c->stream2;
-        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        // Counts first, alone on the main stream: k_lds_count needs a whole CU's LDS per
+        // workgroup and crawls when it has to wait for radix workgroups to drain (0.9 ms beside
+        // them, 0.2 ms alone).  Then fork: scan + sweep on the high-priority stream, the radix
+        // passes on the main stream.
+        hipStream_t s1 = c->stream;
         {
-            KernelSpan sp(c, "scan_radix_hist(3 kernels)", s2);
-            qmcp::launch_exclusive_scan(s2, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
+            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
         {
-            KernelSpan sp(c, "k_count_partition", s2);
-            qmcp::launch_count_partition_scatter(s2, d_key32, n, (const uint32_t*)c->hist2.p,
+            KernelSpan sp(c, "k_count_partition");
+            qmcp::launch_count_partition_scatter(s1, d_key32, n, (const uint32_t*)c->hist2.p,
                                                  (uint32_t*)c->vals[0].p);
         }
         {
-            KernelSpan sp(c, "k_lds_count", s2);
-            qmcp::launch_lds_count(s2, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->hist2.p, n,
+            KernelSpan sp(c, "k_lds_count");
+            qmcp::launch_lds_count(s1, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->hist2.p, n,
                                    ltot, (uint32_t*)c->cstart.p);
         }
+        HIP_TRY(hipGetLastError());
+        hipStream_t s2 = c->stream2;
+        HIP_TRY(hipEventRecord(c->ev_fork, s1));
+        HIP_TRY(hipStreamWaitEvent(s2, c->ev_fork, 0));
         {
             KernelSpan sp(c, "scan_positions(3 kernels)", s2);
             qmcp::launch_exclusive_scan(s2, (const uint32_t*)c->cstart.p, ltot, (uint32_t*)c->boff.p,
                                         (uint32_t*)c->spine2.p, true);
         }
-        HIP_TRY(hipGetLastError());
         {
             // three waves per contig where the span allows it, else the single-wave kernel
             KernelSpan sp(c, "k_sweep_uniform", s2);
