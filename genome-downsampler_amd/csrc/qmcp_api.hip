@@ -365,7 +365,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         }
         {
             // three waves per contig where the span allows it, else the single-wave kernel
-            KernelSpan sp(c, "k_sweep_uniform", s2);
+            KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
+                                                                       : "k_sweep_uniform", s2);
             if (!qmcp::launch_sweep_uniform_mw(s2, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
                                                n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p,
                                                d_iters) &&
@@ -455,7 +456,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     if (overlap) {
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // sweep ran on stream2
     } else if (uniform) {
-        KernelSpan sp(c, "k_sweep_uniform");
+        KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
+                                                                   : "k_sweep_uniform");
         if (!qmcp::launch_sweep_uniform_mw(c->stream, (const uint32_t*)c->boff.p,
                                            (const uint64_t*)c->poff.p, n_contigs, max_span, M, ltot,
                                            (uint32_t*)c->selend.p, d_iters) &&

@@ -30,6 +30,7 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
                           uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
                           uint32_t* vals_out);
 // three-wave pipelined form (spans <= 256); false if the span needs the single-wave kernel
+bool sweep_uniform_mw_supported(uint32_t ell);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats);

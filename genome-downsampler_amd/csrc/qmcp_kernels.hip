@@ -1883,6 +1883,8 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
                            (uint32_t*)keys_out, vals_out);
 }
 
+bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
+
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats) {
