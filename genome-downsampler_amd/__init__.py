@@ -89,6 +89,9 @@ if _host is not None:
     _host.qmcp_host_solve.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.c_int, _u64p]
     _host.qmcp_host_solve.restype = C.c_int64
+    _host.qmcp_host_bamapi_probe.argtypes = [_u32p, _u32p, C.c_uint64, C.c_uint32, C.c_int, _u64p,
+                                             C.c_uint64, _u32p, _u32p, _u64p]
+    _host.qmcp_host_bamapi_probe.restype = C.c_int64
     _host.qmcp_host_amplicons_from_files.argtypes = [C.c_char_p, C.c_char_p, _u32p, _u32p, C.c_size_t]
 
 
@@ -287,6 +290,22 @@ def amplicons_from_files(bed_path, tsv_path=None):
     if n < 0:
         raise OSError(f"cannot build amplicon set from {bed_path} / {tsv_path} ({n})")
     return a0[:n].copy(), a1[:n].copy()
+
+
+def bamapi_probe(starts, ends, ref_genome_length, ids, layout=0):
+    """in-memory BamApi of the host mirror: (find_input_cover, find_filtered_cover(ids), find_pairs(ids))"""
+    _need_host()
+    starts, ends = _u32(starts), _u32(ends)
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    cin = np.zeros(max(ref_genome_length, 1), dtype=np.uint32)
+    cout = np.zeros(max(ref_genome_length, 1), dtype=np.uint32)
+    paired = np.zeros(max(starts.size, 1), dtype=np.uint64)
+    n = _host.qmcp_host_bamapi_probe(_p32(starts), _p32(ends), starts.size, int(ref_genome_length),
+                                     int(layout), _p64(ids), ids.size, _p32(cin), _p32(cout),
+                                     _p64(paired))
+    if n < 0:
+        raise RuntimeError("bamapi probe failed")
+    return cin[:ref_genome_length], cout[:ref_genome_length], paired[:n].copy()
 
 
 def solver_names():

@@ -95,6 +95,35 @@ int qmcp_host_amplicons_from_files(const char* bed_path, const char* tsv_path,
     return static_cast<int>(set.amplicons.size());
 }
 
+// In-memory BamApi helpers as the reference's tests use them (src/tests/coverage_tester.cpp:
+// find_input_cover / find_filtered_cover; src/app.cpp:141: find_pairs).  `layout` 0 builds the
+// BamApi from an AoS container, 1 from an SoA one (both constructors exist in the reference).
+// cover_in / cover_out have ref_genome_length entries; paired_out capacity n; returns the
+// number of paired ids.
+std::int64_t qmcp_host_bamapi_probe(const std::uint32_t* starts, const std::uint32_t* ends,
+                                    std::uint64_t n, std::uint32_t ref_genome_length, int layout,
+                                    const std::uint64_t* ids, std::uint64_t n_ids,
+                                    std::uint32_t* cover_in, std::uint32_t* cover_out,
+                                    std::uint64_t* paired_out) {
+    bam_api::AOSPairedReads aos;
+    aos.ref_genome_length = ref_genome_length;
+    for (std::uint64_t i = 0; i < n; ++i)
+        aos.push_back(bam_api::Read(i, starts[i], ends[i], 0, ends[i] - starts[i] + 1, i % 2 == 0));
+    bam_api::SOAPairedReads soa;
+    soa.from(aos);
+    bam_api::BamApi api = layout == 0 ? bam_api::BamApi(aos) : bam_api::BamApi(soa);
+    // exercise the lazy layout conversion both ways
+    if (api.get_paired_reads_aos().reads.size() != n || api.get_paired_reads_soa().ids.size() != n)
+        return -1;
+    const std::vector<bam_api::ReadIndex> idv(ids, ids + n_ids);
+    const auto in = api.find_input_cover();
+    const auto out = api.find_filtered_cover(idv);
+    for (std::size_t p = 0; p < in.size(); ++p) { cover_in[p] = in[p]; cover_out[p] = out[p]; }
+    const auto paired = api.find_pairs(idv);
+    for (std::size_t i = 0; i < paired.size(); ++i) paired_out[i] = paired[i];
+    return static_cast<std::int64_t>(paired.size());
+}
+
 // Names registered in the SolverManager, '\n'-separated, into buf.
 int qmcp_host_solver_names(char* buf, std::size_t cap) {
     std::string all;

@@ -1,5 +1,5 @@
 import sys, importlib, time, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'oracle')
+import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'oracle'))
 pkg=importlib.import_module('genome-downsampler_amd')
 sv=pkg.Solver(0)
 def run(name, s,e,lengths,M,offs=None,reps=3):

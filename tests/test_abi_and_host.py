@@ -105,3 +105,23 @@ def test_amplicon_set_from_bed_and_tsv(pkg, tmp_path):
     assert a0.tolist() == [30, 385, 0] and a1.tolist() == [726, 726, 342]
     with pytest.raises(OSError):
         pkg.amplicons_from_files(tmp_path / "missing.bed")
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_host_bamapi_mirror_matches_oracle(pkg, layout):
+    """BamApi::find_input_cover / find_filtered_cover / find_pairs of the host mirror
+    (bam_api.cpp:239-301) against the oracle's restatements"""
+    import oracle_py
+    rng = np.random.default_rng(5 + layout)
+    n, L = 2000, 700
+    s = rng.integers(0, L - 60, size=n).astype(np.uint32)
+    e = (s + rng.integers(0, 60, size=n)).astype(np.uint32)
+    ids = np.unique(rng.integers(0, n, size=300)).astype(np.uint64)
+    cin, cout, paired = pkg.bamapi_probe(s, e, L, ids, layout=layout)
+    mask = pkg.indices_to_mask(ids, n)
+    assert np.array_equal(cin, oracle_py.cover(s, e, L))
+    assert np.array_equal(cout, oracle_py.cover(s, e, L, keep_mask=mask))
+    want = pkg.mask_to_indices(oracle_py.find_pairs(mask, n), n)
+    assert np.array_equal(np.sort(paired), want)
+    # reference order: each id followed by its mate, first occurrence only (bam_api.cpp:251-263)
+    assert paired[0] == ids[0] and paired[1] == (ids[0] ^ 1)
