@@ -12,6 +12,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -60,6 +61,10 @@ struct qmcp_hip_ctx {
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
+    DevBuf lookback;   // chained radix: (tile, digit) status granules, zeroed when (re)allocated
+    DevBuf radixctl;   // [4][256] digit counts, [4][256] digit bases, 4 tickets, timeout flag
+    uint32_t radix_epoch = 0;      // unique per chained pass for the life of the context
+    bool chained_radix_ok = true;  // cleared for good if a look-back ever times out
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
@@ -195,7 +200,7 @@ int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
 // want_counts -- the solve derives its bucket offsets from the sorted keys instead.
 int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                 const Problem& pr, const uint64_t* d_keep_mask, bool want_keys, bool want_counts,
-                bool want_part_hist, uint32_t host_stats[3]) {
+                bool want_part_hist, uint32_t* d_global_digit_hist, uint32_t host_stats[3]) {
     const uint32_t n = (uint32_t)pr.n;
     TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     if (want_counts) TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
@@ -211,7 +216,7 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
                              want_keys ? (uint32_t*)c->vals[1].p : nullptr,
                              want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p,
                              want_part_hist ? (uint32_t*)c->hist2.p : nullptr,
-                             want_part_hist ? (uint32_t*)c->hist.p : nullptr);
+                             want_part_hist ? (uint32_t*)c->hist.p : nullptr, d_global_digit_hist);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -287,7 +292,25 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // the counting partition's per-tile histogram is produced by the same pass when the
     // two-stream path can be taken (uniformity is only known afterwards; the table is cheap)
     const bool may_overlap = n >= (1u << 22) && qmcp::early_counts_supported(ltot);
-    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_overlap, hs));
+    // Chained radix passes (one kernel per digit, decoupled look-back) are an opt-in experiment:
+    // on cfg4 they measured 1.02 ms per pass against 1.13 ms for histogram + scan + scatter, and
+    // the whole-call digit histograms they need cost k_prepare 0.2 ms -- no net gain until the
+    // look-back is made wave-parallel.  QMCP_HIP_CHAINED_RADIX=1 enables them.
+    const bool try_chained = c->chained_radix_ok && n >= (1u << 16) &&
+                             std::getenv("QMCP_HIP_CHAINED_RADIX") != nullptr;
+    uint32_t* d_ctl = nullptr;
+    if (try_chained) {
+        const uint32_t tiles = qmcp::sort_tiles(n);
+        const size_t lb_bytes = (size_t)tiles * 256 * sizeof(unsigned long long);
+        if (c->lookback.cap < lb_bytes) {
+            TRY(ensure(c, c->lookback, lb_bytes));
+            HIP_TRY(hipMemsetAsync(c->lookback.p, 0, c->lookback.cap, c->stream));
+        }
+        TRY(ensure(c, c->radixctl, (2 * 4 * 256 + 16) * sizeof(uint32_t)));
+        d_ctl = (uint32_t*)c->radixctl.p;
+        HIP_TRY(hipMemsetAsync(d_ctl, 0, (2 * 4 * 256 + 16) * sizeof(uint32_t), c->stream));
+    }
+    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_overlap, d_ctl, hs));
     HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
@@ -384,7 +407,29 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     local.sort_passes = passes;
     const uint32_t n_tiles = qmcp::sort_tiles(n);
     int kin = 0, vin = 0;  // buffers holding the sorted output at the end
-    if (!wide) {
+    const bool chained = try_chained && uniform;
+    if (chained) {
+        // one kernel per digit: decoupled look-back over per-tile digit counts
+        uint32_t* d_base = d_ctl + 4 * 256;
+        uint32_t* d_ticket = d_ctl + 8 * 256;
+        uint32_t* d_timeout = d_ctl + 8 * 256 + 8;
+        {
+            KernelSpan sp(c, "k_digit_bases");
+            qmcp::launch_digit_bases(c->stream, d_ctl, d_base);
+        }
+        const void* recs_in = nullptr;
+        for (uint32_t p = 0; p < passes; ++p) {
+            const bool first = p == 0;
+            const int kout = first ? 0 : (kin ^ 1);
+            KernelSpan sp(c, "k_radix_onesweep");
+            qmcp::launch_radix_onesweep(c->stream, first, d_key32, recs_in, n, 8 * p, d_base + p * 256,
+                                        (unsigned long long*)c->lookback.p, ++c->radix_epoch,
+                                        d_ticket + p, d_timeout, c->keys[kout].p);
+            HIP_TRY(hipGetLastError());
+            kin = kout;
+            recs_in = c->keys[kin].p;
+        }
+    } else if (!wide) {
         // records {key, read index}: keys[0] <-> keys[1]; the first pass reads bare keys
         const void* recs_in = nullptr;
         for (uint32_t p = 0; p < passes; ++p) {
@@ -514,6 +559,16 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_spans(c);
+    if (chained) {
+        uint32_t timed_out = 0;
+        HIP_TRY(hipMemcpy(&timed_out, d_ctl + 8 * 256 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (timed_out != 0) {
+            // a look-back spin expired: never trust the chained pass on this context again and
+            // redo the solve with the three-kernel passes
+            c->chained_radix_ok = false;
+            return solve_on_device(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask, st);
+        }
+    }
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
@@ -568,7 +623,7 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     TRY(upload_tables(c, roff, pr));
     uint32_t hs[3];
     TRY(run_prepare(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, pr, d_keep,
-                    true, true, false, hs));
+                    true, true, false, nullptr, hs));
     TRY(scan_counts(c, c->cstart, c->boff, ltot));
     TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
@@ -643,7 +698,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -16,7 +16,8 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
                     uint32_t* stats, uint32_t* part_hist /* digit-major [256][tiles] or null */,
-                    uint32_t* digit0_hist /* same shape; written iff part_hist is */);
+                    uint32_t* digit0_hist /* same shape; written iff part_hist is */,
+                    uint32_t* global_digit_hist /* [4][256] whole-call digit counts of gstart, or null */);
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
                          const uint64_t* keep_mask, void* keys, uint32_t* ecnt);
@@ -67,6 +68,12 @@ void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32
                             uint32_t n_amp, uint32_t min_length, uint32_t min_mapq,
                             uint64_t* pair_keep);
 
+// chained ("onesweep"-style) radix pass on records: one kernel per digit
+void launch_digit_bases(hipStream_t st, const uint32_t* hist4, uint32_t* base4);
+void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
+                           uint32_t n, uint32_t shift, const uint32_t* digit_base,
+                           unsigned long long* status, uint32_t epoch, uint32_t* ticket,
+                           uint32_t* timeout_flag, void* recs_out);
 // early counts (uniform path): reads per start position from a key partition + LDS histograms
 bool early_counts_supported(uint32_t ltot);
 void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,

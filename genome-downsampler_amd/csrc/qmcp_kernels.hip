@@ -99,7 +99,12 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  uint32_t n_tiles, uint32_t tiles_per_block,
                                                  uint32_t part_shift,
                                                  uint32_t* __restrict__ part_hist,
-                                                 uint32_t* __restrict__ digit0_hist) {
+                                                 uint32_t* __restrict__ digit0_hist,
+                                                 uint32_t* __restrict__ global_digit_hist) {
+    __shared__ uint32_t s_gh[4][256];  // whole-call digit histograms of the start key (all 4 bytes)
+    if (global_digit_hist) {
+        for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_gh[0][0])[i] = 0;
+    }
     __shared__ uint64_t s_roff[65];
     __shared__ uint64_t s_poff[65];
     __shared__ uint32_t s_h[256];
@@ -157,6 +162,13 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
                 atomicAdd(&s_h0[gs & 255u], 1u);
             }
+            if (global_digit_hist) {
+                // digit 0 is taken from s_h0 below when it exists; otherwise count it here too
+                if (!part_hist) atomicAdd(&s_gh[0][gs & 255u], 1u);
+                atomicAdd(&s_gh[1][(gs >> 8) & 255u], 1u);
+                atomicAdd(&s_gh[2][(gs >> 16) & 255u], 1u);
+                atomicAdd(&s_gh[3][(gs >> 24) & 255u], 1u);
+            }
             if (cstart) {
                 bool on = true;
                 if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
@@ -167,7 +179,15 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             __syncthreads();
             part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
             digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
+            if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
             __syncthreads();
+        }
+    }
+    if (global_digit_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) {
+            const uint32_t v = (&s_gh[0][0])[i];
+            if (v) atomicAdd(&global_digit_hist[i], v);
         }
     }
     // block reduction, then at most one atomic per statistic per workgroup -- and none when the
@@ -602,6 +622,141 @@ __global__ __launch_bounds__(1024) void k_lds_count(const uint32_t* __restrict__
     for (uint32_t i = threadIdx.x; i < kCountRange; i += blockDim.x)
         if (pos0 + i <= ltot) cstart[pos0 + i] = s_cnt32[i];
     (void)n_parts;
+}
+
+// ------------------------------------------------------------------ chained radix pass
+// One kernel per digit instead of histogram + scan + scatter: a tile publishes its digit counts
+// and obtains its base by looking back over its predecessors' published values (decoupled
+// look-back).  Inter-workgroup protocol (cdna_hip_programming.md, Guideline 16, recipe R2): every
+// (tile, digit) status is ONE aligned 8-byte granule {epoch << 2 | state, value}, written by one
+// relaxed agent-scope atomic store and polled with relaxed agent-scope atomic loads -- the data
+// is the flag, no fence, no separate flag word.  state 1 = this tile's own count ("aggregate"),
+// 2 = inclusive prefix over all tiles up to this one.  The epoch (unique per pass for the life of
+// the context) makes stale granules of earlier passes read as "not published", so the table is
+// zeroed only when it is (re)allocated.
+// Forward progress: tile numbers are drawn from an atomic ticket in the order workgroups start,
+// so every predecessor of a running tile is itself running or finished; predecessors never wait
+// on successors.  Every spin is bounded; on expiry the tile raises `timeout_flag` and the host
+// redoes the bucketing with the three-kernel passes.
+// `digit_base` = exclusive scan of this pass's whole-call digit histogram (from k_prepare).
+static constexpr uint32_t kSpinLimit = 1u << 22;
+
+__global__ __launch_bounds__(256) void k_digit_bases(const uint32_t* __restrict__ hist4,
+                                                     uint32_t* __restrict__ base4) {
+    __shared__ uint32_t s_wave[4];
+    for (int p = 0; p < 4; ++p) {
+        uint32_t tot;
+        const uint32_t v = hist4[p * 256 + threadIdx.x];
+        base4[p * 256 + threadIdx.x] = block_excl_scan_256(v, s_wave, tot);
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(
+    const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, uint32_t n, uint32_t shift,
+    uint32_t n_tiles, const uint32_t* __restrict__ digit_base, unsigned long long* __restrict__ status,
+    uint32_t epoch, uint32_t* __restrict__ ticket, uint32_t* __restrict__ timeout_flag,
+    Rec* __restrict__ recs_out) {
+    __shared__ uint32_t s_cnt[4][256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_tile;
+    __shared__ Rec s_rec[kSortTile];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < 4 * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= n_tiles) return;  // uniform
+
+    const uint32_t tile_base = tile * kSortTile;
+    const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
+    const uint32_t wbase = tile_base + w * (kSortItems * 64);
+    Rec rec[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < n;
+        if (FIRST) { rec[k].key = valid ? keys[i] : 0u; rec[k].val = i; }
+        else { rec[k] = valid ? recs_in[i] : Rec{0u, 0u}; }
+        const uint32_t d = (rec[k].key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t in_group = __popcll(peers & lt_mask);
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = s_cnt[w][d];
+            s_cnt[w][d] = old + __popcll(peers);
+        }
+        old = (uint32_t)__shfl((int)old, leader, kWave);
+        rank[k] = old + in_group;
+    }
+    __syncthreads();
+    {
+        const uint32_t d = threadIdx.x;  // one thread per digit from here to the next barrier
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+        const uint32_t mine = c0 + c1 + c2 + c3;
+        unsigned long long* row = status + (size_t)tile * 256;
+        const unsigned long long tag_agg = ((unsigned long long)((epoch << 2) | 1u)) << 32;
+        const unsigned long long tag_pre = ((unsigned long long)((epoch << 2) | 2u)) << 32;
+        if (tile > 0)
+            __hip_atomic_store(&row[d], tag_agg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // look back: sum aggregates until a tile with a published inclusive prefix is met
+        uint32_t excl = 0;
+        uint32_t spins = 0;
+        bool failed = false;
+        for (uint32_t t = tile; t > 0 && !failed;) {
+            const unsigned long long g = __hip_atomic_load(&status[(size_t)(t - 1) * 256 + d],
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t hi = (uint32_t)(g >> 32);
+            if ((hi >> 2) != epoch || (hi & 3u) == 0u) {  // not published yet in this pass
+                if (++spins > kSpinLimit) failed = true;
+                else __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += (uint32_t)g;
+            if ((hi & 3u) == 2u) break;
+            --t;
+        }
+        if (failed) atomicOr(timeout_flag, 1u);
+        __hip_atomic_store(&row[d], tag_pre | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t tot;
+        const uint32_t tile_off = block_excl_scan_256(mine, s_wave, tot);
+        s_cnt[0][d] = tile_off;
+        s_cnt[1][d] = tile_off + c0;
+        s_cnt[2][d] = tile_off + c0 + c1;
+        s_cnt[3][d] = tile_off + c0 + c1 + c2;
+        s_gbase[d] = digit_base[d] + excl - tile_off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (rec[k].key >> shift) & 255u;
+            s_rec[s_cnt[w][d] + rank[k]] = rec[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t j = k * kSortThreads + threadIdx.x;
+        if (j < tile_count) {
+            const Rec r = s_rec[j];
+            const uint32_t d = (r.key >> shift) & 255u;
+            // a timed-out look-back leaves a wrong base: keep the store inside the buffer
+            const uint32_t dst = s_gbase[d] + j;
+            if (dst < n) recs_out[dst] = r;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ bucket offsets from sorted keys
@@ -1221,7 +1376,9 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
     uint32_t* __restrict__ csel = selend + base;
     const uint32_t trash = ltot - base;
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
-    if (role == 1) __builtin_amdgcn_s_setprio(3);
+    // all three waves form one serial pipeline: each must win issue arbitration against the
+    // streaming kernels that share their SIMDs
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) s_flag[0] = 0;
 
     // chain state (meaningful in the CHAIN wave only)
@@ -1822,13 +1979,14 @@ static inline uint32_t tiles_per_block_for(uint32_t n_tiles);
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats, uint32_t* part_hist, uint32_t* digit0_hist) {
+                    uint32_t* stats, uint32_t* part_hist, uint32_t* digit0_hist,
+                    uint32_t* global_digit_hist) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const uint32_t g = tiles_per_block_for(n_tiles);
     hipLaunchKernelGGL(k_prepare, dim3((n_tiles + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       kCountShift, part_hist, digit0_hist);
+                       kCountShift, part_hist, digit0_hist, global_digit_hist);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
@@ -2042,6 +2200,26 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
     else
         hipLaunchKernelGGL((k_radix_scatter_rec<false, false>), dim3(grid), dim3(kSortThreads), 0, st,
                            keys, (const Rec*)recs_in, n, shift, n_tiles, g, offs, recs_out);
+}
+
+void launch_digit_bases(hipStream_t st, const uint32_t* hist4, uint32_t* base4) {
+    hipLaunchKernelGGL(k_digit_bases, dim3(1), dim3(256), 0, st, hist4, base4);
+}
+
+void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
+                           uint32_t n, uint32_t shift, const uint32_t* digit_base,
+                           unsigned long long* status, uint32_t epoch, uint32_t* ticket,
+                           uint32_t* timeout_flag, void* recs_out) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    if (first)
+        hipLaunchKernelGGL(k_radix_onesweep<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs_in, n, shift, n_tiles, digit_base, status, epoch, ticket,
+                           timeout_flag, (Rec*)recs_out);
+    else
+        hipLaunchKernelGGL(k_radix_onesweep<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
+                           (const Rec*)recs_in, n, shift, n_tiles, digit_base, status, epoch, ticket,
+                           timeout_flag, (Rec*)recs_out);
 }
 
 // early counts: partition bare keys by (pos >> 15), then one LDS histogram per 32 Ki range
