@@ -548,8 +548,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // keep mask
     {
         KernelSpan sp(c, "k_mark");
-        qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, n,
-                          span_bits, (const uint32_t*)c->selend.p, d_mask,
+        qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, ltot,
+                          (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p, d_mask,
                           (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());

@@ -1870,20 +1870,24 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
 // ------------------------------------------------------------------ keep-mask emission
 // sorted entry j (bucket = its start position) is kept iff j < selend[bucket].
 // obtain_sequence counterpart (quasi_mcp_cpu_max_flow_solver.cpp:89-100).
+// One thread per start position walks that bucket's selected prefix [boff[q], selend[q]) --
+// at most M entries, usually 0..2 -- and sets the kept reads' bits: the sorted records of the
+// other ~95 % of the reads are never touched.
 template <typename Keys>
-__global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t n, uint32_t span_bits,
+__global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t ltot,
+                                              const uint32_t* __restrict__ boff,
                                               const uint32_t* __restrict__ selend,
                                               uint32_t* __restrict__ mask32,
                                               unsigned long long* __restrict__ n_kept) {
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t mine = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint32_t q = keys.pos(j, span_bits);
-        if (j < selend[q]) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ltot; q += stride) {
+        const uint32_t j0 = boff[q], j1 = selend[q];
+        for (uint32_t j = j0; j < j1; ++j) {
             const uint32_t idx = keys.idx(j);
             atomicOr(&mask32[idx >> 5], 1u << (idx & 31));
-            ++mine;  // every read occurs once in the sorted order: this counts set bits
         }
+        mine += j1 - j0;
     }
     mine = wave_sum_u32(mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_kept, (unsigned long long)mine);
@@ -2138,16 +2142,16 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
     }
 }
 
-void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t n,
-                 uint32_t span_bits, const uint32_t* selend, uint64_t* mask,
+void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
+                 const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
                  unsigned long long* n_kept) {
     if (wide)
-        hipLaunchKernelGGL(k_mark<KeysSplit64>, dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           KeysSplit64{(const uint64_t*)sorted, svals}, n, span_bits, selend,
+        hipLaunchKernelGGL(k_mark<KeysSplit64>, dim3(grid_for(ltot, 256)), dim3(256), 0, st,
+                           KeysSplit64{(const uint64_t*)sorted, svals}, ltot, boff, selend,
                            (uint32_t*)mask, n_kept);
     else
-        hipLaunchKernelGGL(k_mark<KeysRec>, dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           KeysRec{(const Rec*)sorted}, n, span_bits, selend, (uint32_t*)mask, n_kept);
+        hipLaunchKernelGGL(k_mark<KeysRec>, dim3(grid_for(ltot, 256)), dim3(256), 0, st,
+                           KeysRec{(const Rec*)sorted}, ltot, boff, selend, (uint32_t*)mask, n_kept);
 }
 
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
