@@ -1,0 +1,46 @@
+"""Device-resident entry point (qmcp_hip_solve_device) driven the way bench.py drives it: torch
+owns the buffers, the solver is ordered after the caller's stream."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_solve_device_after_producer_stream(pkg, oracle):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test without a GPU")
+    dev = torch.device("cuda", 0)
+    s, e = pkg.reads_gen(pkg.KIND_LOW_BOTH_SIDES, 300_000, 50_000)
+    want = oracle.solve(s, e, 50_000, 40)
+    words = pkg.mask_words(s.size)
+    with pkg.Solver(0) as sv:
+        for use_side_stream in (False, True):
+            stream = torch.cuda.Stream(dev) if use_side_stream else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(stream):
+                # producer work on the caller's stream: the reads arrive through a chain of device
+                # ops (copy, arithmetic round trip) the solve must wait for
+                d_s = torch.from_numpy(s.view(np.int32)).to(dev, non_blocking=True)
+                d_e = torch.from_numpy(e.view(np.int32)).to(dev, non_blocking=True)
+                d_s = (d_s + 7) - 7
+                d_e = (d_e * 3) // 3
+                d_mask = torch.full((words,), -1, dtype=torch.int64, device=dev)
+                st = sv.solve_device(d_s.data_ptr(), d_e.data_ptr(), s.size, 50_000, 40,
+                                     d_mask.data_ptr(), stream=stream.cuda_stream)
+            got = d_mask.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want)
+            assert st.n_kept == int(np.unpackbits(got.view(np.uint8)).sum())
+            # find_pairs on the device mask, in place
+            sv.complete_pairs_device(d_mask.data_ptr(), s.size, stream=stream.cuda_stream)
+            assert np.array_equal(d_mask.cpu().numpy().view(np.uint64), oracle.find_pairs(want, s.size))
+
+
+def test_error_paths_leave_context_usable(pkg, solver):
+    z = np.zeros(4, np.uint32)
+    with pytest.raises(pkg.QmcpError) as ei:  # offsets do not end at n_reads
+        solver.solve(z, z, np.array([10, 10], np.uint32), 1, contig_read_offsets=np.array([0, 2, 3], np.uint64))
+    assert ei.value.code == -1
+    with pytest.raises(pkg.QmcpError) as ei:  # mixed spans beyond the LDS ring of the event sweep
+        solver.solve([0, 5], [20000, 6], 30000, 1)
+    assert ei.value.code == -3
+    assert solver.solve([0, 5], [9, 6], 10, 1).size == 1
