@@ -64,22 +64,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
     v += QMCP_DPP(0u, v, 0x143, 0xC);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan_min(uint32_t v) {
-    v = min(v, QMCP_DPP(kInf, v, 0x111, 0xF));
-    v = min(v, QMCP_DPP(kInf, v, 0x112, 0xF));
-    v = min(v, QMCP_DPP(kInf, v, 0x114, 0xF));
-    v = min(v, QMCP_DPP(kInf, v, 0x118, 0xF));
-    v = min(v, QMCP_DPP(kInf, v, 0x142, 0xA));
-    v = min(v, QMCP_DPP(kInf, v, 0x143, 0xC));
-    return v;
-}
-// value of lane-1 (lane 0 gets `id`)
-__device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v, uint32_t id) {
-    uint32_t r = (uint32_t)__shfl_up((int)v, 1, kWave);
-    return (threadIdx.x & 63) == 0 ? id : r;
-}
-__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return min(a + b, kInf); }
-
 // ------------------------------------------------------------------ prepare
 // One pass over the reads: validate (start <= end < contig length), reduce min/max span,
 // write the global start position of every read (the bucketing key of the uniform path) and
@@ -1429,6 +1413,9 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
             d_prev = d_last; d_cur = d_last;
         }
         for (uint32_t t = 0; t < n_left + 2; ++t) {
+#ifdef QMCP_MW_STAMP
+            const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#endif
             if (role == 0) {
                 if (t < n_left) {
                     const uint32_t g = g0 + t;
@@ -1557,7 +1544,18 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                     }
                 }
             }
+#ifdef QMCP_MW_STAMP
+            // diagnostic build only: cycles each role spends working vs waiting at the barrier
+            const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
+            const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && iter_stats) {
+                atomicAdd(&iter_stats[4 + 2 * role], (uint32_t)((stamp1 - stamp0) >> 4));
+                atomicAdd(&iter_stats[5 + 2 * role], (uint32_t)((stamp2 - stamp1) >> 4));
+            }
+#else
+            __syncthreads();
+#endif
             if (t >= 2 && s_flag[0] != 0) { failed = g0 + t - 2; break; }
         }
         if (failed == 0xFFFFFFFFu) { g0 = n_groups; break; }
