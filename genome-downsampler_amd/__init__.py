@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "qmcp_hip_destroy", "qmcp_hip_solve_host", "qmcp_hip_solve_device", "qmcp_hip_coverage_host",
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
-    "qmcp_hip_kernel_times",
+    "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host",
 )
 
 QMCP_OK = 0
@@ -79,6 +79,9 @@ _hip.qmcp_hip_complete_pairs_host.argtypes = [C.c_void_p, _u64p, C.c_uint64]
 _hip.qmcp_hip_amplicon_filter_host.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, _u32p, C.c_uint64,
                                                _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                _u64p]
+_hip.qmcp_hip_filter_solve_host.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, _u32p, C.c_uint64, _u32p,
+                                            _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_int, _u64p, _u64p, C.POINTER(Stats)]
 _hip.qmcp_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
 _hip.qmcp_hip_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 if _host is not None:
@@ -241,6 +244,28 @@ class Solver:
     def complete_pairs_device(self, d_mask, n_reads, stream=0):
         _check(_hip.qmcp_hip_complete_pairs_device(self._ctx, C.c_void_p(d_mask), int(n_reads),
                                                    C.c_void_p(stream)))
+
+    def filter_solve(self, starts, ends, ref_genome_length, max_coverage, amp_starts=None,
+                     amp_ends=None, seq_lengths=None, qualities=None, min_length=0, min_mapq=0,
+                     complete_pairs=False):
+        """FILTER -> compaction -> solve -> (find_pairs) in one device-resident call; returns
+        (keep mask over the ORIGINAL read indices, number of pairs the pre-pass dropped)"""
+        starts, ends = _u32(starts), _u32(ends)
+        n = starts.size
+        a0 = _u32(amp_starts) if amp_starts is not None else None
+        a1 = _u32(amp_ends) if amp_ends is not None else None
+        sl = _u32(seq_lengths) if seq_lengths is not None else None
+        q = _u32(qualities) if qualities is not None else None
+        mask = np.zeros(max(mask_words(n), 1), dtype=np.uint64)
+        dropped = C.c_uint64(0)
+        st = Stats()
+        _check(_hip.qmcp_hip_filter_solve_host(self._ctx, _p32(starts), _p32(ends), _p32(sl), _p32(q), n,
+                                               _p32(a0), _p32(a1), 0 if a0 is None else a0.size,
+                                               int(min_length), int(min_mapq), int(ref_genome_length),
+                                               int(max_coverage), int(bool(complete_pairs)),
+                                               _p64(mask), C.byref(dropped), C.byref(st)))
+        self.last_stats = st
+        return mask[:mask_words(n)], int(dropped.value)
 
     def amplicon_filter(self, starts, ends, amp_starts, amp_ends, seq_lengths=None, qualities=None,
                         min_length=0, min_mapq=0):

@@ -61,6 +61,7 @@ struct qmcp_hip_ctx {
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
+    DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
     DevBuf lookback;   // chained radix: (tile, digit) status granules, zeroed when (re)allocated
     DevBuf radixctl;   // [4][256] digit counts, [4][256] digit bases, 4 tickets, timeout flag
     uint32_t radix_epoch = 0;      // unique per chained pass for the life of the context
@@ -698,7 +699,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -881,6 +882,104 @@ int qmcp_hip_amplicon_filter_host(qmcp_hip_ctx* c, const uint32_t* starts, const
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pair_keep_out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
+}
+
+int qmcp_hip_filter_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
+                               const uint32_t* seq_lengths, const uint32_t* qualities,
+                               uint64_t n_reads, const uint32_t* amp_starts,
+                               const uint32_t* amp_ends, uint32_t n_amplicons, uint32_t min_length,
+                               uint32_t min_mapq, uint32_t ref_genome_length, uint32_t max_coverage,
+                               int complete_pairs, uint64_t* keep_mask_out,
+                               uint64_t* pairs_filtered_out, qmcp_hip_stats* stats) {
+    TRY(use_device(c));
+    if (n_reads & 1ull) return fail(QMCP_EINVAL, "n_reads must be even (reads come in mate pairs)");
+    if (n_reads > (1ull << 30)) return fail(QMCP_ERANGE, "n_reads exceeds 2^30 per call");
+    const size_t words = (size_t)((n_reads + 63) / 64);
+    if (n_reads && (!starts || !ends || !keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    if (n_amplicons && (!amp_starts || !amp_ends)) return fail(QMCP_EINVAL, "null amplicon table");
+    if (pairs_filtered_out) *pairs_filtered_out = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n_reads == 0) return QMCP_OK;
+    const uint64_t n_pairs = n_reads / 2;
+    const size_t pwords = (size_t)((n_pairs + 63) / 64);
+    const size_t nb = (size_t)n_reads * 4;
+    hipStream_t st = c->stream;
+    TRY(ensure(c, c->in_starts, nb));
+    TRY(ensure(c, c->in_ends, nb));
+    TRY(ensure(c, c->f_starts, nb));
+    TRY(ensure(c, c->f_ends, nb));
+    TRY(ensure(c, c->f_map, (size_t)n_pairs * 4 + 16));
+    TRY(ensure(c, c->f_words, (pwords + 2) * 4));
+    TRY(ensure(c, c->f_mask, pwords * 8 + 16));
+    TRY(ensure(c, c->mask, words * 8));
+    TRY(ensure(c, c->cov, words * 8 + 16));  // compact-index keep mask
+    TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries((uint32_t)pwords + 1) + 1) * 4 + 16));
+    HIP_TRY(hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, st));
+    const uint32_t* d_len = nullptr;
+    const uint32_t* d_q = nullptr;
+    if (seq_lengths) {
+        TRY(ensure(c, c->in_aux0, nb));
+        HIP_TRY(hipMemcpyAsync(c->in_aux0.p, seq_lengths, nb, hipMemcpyHostToDevice, st));
+        d_len = (const uint32_t*)c->in_aux0.p;
+    }
+    if (qualities) {
+        TRY(ensure(c, c->in_aux1, nb));
+        HIP_TRY(hipMemcpyAsync(c->in_aux1.p, qualities, nb, hipMemcpyHostToDevice, st));
+        d_q = (const uint32_t*)c->in_aux1.p;
+    }
+    // 1. FILTER predicate per pair.  Without amplicons (AmpliconBehaviour::IGNORE) one interval
+    //    covering every coordinate stands in for the amplicon set.
+    TRY(ensure(c, c->amp, (size_t)2 * ((size_t)n_amplicons + 2) * 4));
+    uint32_t* d_as = (uint32_t*)c->amp.p;
+    uint32_t* d_ae = d_as + n_amplicons + 2;
+    uint32_t n_amp_eff = n_amplicons;
+    if (n_amplicons) {
+        HIP_TRY(hipMemcpyAsync(d_as, amp_starts, (size_t)n_amplicons * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_ae, amp_ends, (size_t)n_amplicons * 4, hipMemcpyHostToDevice, st));
+    } else {
+        const uint32_t everything[2] = {0u, 0xFFFFFFFFu};
+        HIP_TRY(hipMemcpyAsync(d_as, &everything[0], 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_ae, &everything[1], 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // `everything` lives on this stack frame
+        n_amp_eff = 1;
+    }
+    qmcp::launch_amplicon_filter(st, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p,
+                                 d_len, d_q, n_pairs, d_as, d_ae, n_amp_eff, min_length, min_mapq,
+                                 (uint64_t*)c->f_mask.p);
+    // 2. compaction: per-word popcounts -> exclusive scan -> scatter of surviving pairs
+    qmcp::launch_word_popcounts(st, (const uint64_t*)c->f_mask.p, (uint32_t)pwords, (uint32_t*)c->f_words.p);
+    qmcp::launch_exclusive_scan(st, (const uint32_t*)c->f_words.p, (uint32_t)pwords, (uint32_t*)c->f_words.p,
+                                (uint32_t*)c->spine.p, true);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_surv_pairs = 0;
+    HIP_TRY(hipMemcpyAsync(&n_surv_pairs, (uint32_t*)c->f_words.p + pwords, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (pairs_filtered_out) *pairs_filtered_out = n_pairs - n_surv_pairs;
+    qmcp::launch_compact_pairs(st, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p,
+                               (const uint64_t*)c->f_mask.p, (const uint32_t*)c->f_words.p, n_pairs,
+                               (uint32_t*)c->f_starts.p, (uint32_t*)c->f_ends.p, (uint32_t*)c->f_map.p);
+    HIP_TRY(hipGetLastError());
+    // 3. solve the survivors (device-resident), 4. complete mates, 5. back to original indices
+    const uint64_t n_c = 2ull * n_surv_pairs;
+    const uint64_t offs[2] = {0, n_c};
+    uint64_t* d_mask_c = (uint64_t*)c->cov.p;
+    TRY(solve_on_device(c, (const uint32_t*)c->f_starts.p, (const uint32_t*)c->f_ends.p, offs,
+                        &ref_genome_length, 1, n_c, max_coverage, d_mask_c, stats));
+    const uint32_t words_c = (uint32_t)((n_c + 63) / 64);
+    if (complete_pairs && words_c) {
+        qmcp::launch_complete_pairs(st, d_mask_c, words_c, n_c);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemsetAsync(c->mask.p, 0, words * 8, st));
+    if (n_c) {
+        qmcp::launch_expand_mask(st, d_mask_c, (const uint32_t*)c->f_map.p, (uint32_t)n_c,
+                                 (uint64_t*)c->mask.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(keep_mask_out, c->mask.p, words * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return QMCP_OK;
 }
 

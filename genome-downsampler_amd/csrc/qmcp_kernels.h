@@ -62,6 +62,12 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
                      uint32_t* cov);
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads);
+void launch_word_popcounts(hipStream_t st, const uint64_t* words, uint32_t n_words, uint32_t* counts);
+void launch_compact_pairs(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
+                          const uint64_t* pair_keep, const uint32_t* word_base, uint64_t n_pairs,
+                          uint32_t* starts_c, uint32_t* ends_c, uint32_t* orig_pair);
+void launch_expand_mask(hipStream_t st, const uint64_t* mask_c, const uint32_t* orig_pair,
+                        uint32_t n_reads_c, uint64_t* mask);
 void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
                             const uint32_t* seq_lengths, const uint32_t* qualities,
                             uint64_t n_pairs, const uint32_t* amp_starts, const uint32_t* amp_ends,

@@ -1968,6 +1968,55 @@ __global__ __launch_bounds__(256) void k_amplicon_filter(const uint32_t* __restr
     }
 }
 
+// ------------------------------------------------------------------ filter -> solve pipeline glue
+// Stream compaction of the pairs that survive the FILTER (pairs stay adjacent: survivor q'
+// becomes reads 2q', 2q'+1) and the map back to original read indices -- the device-resident
+// equivalent of what BamApi does while ingesting (bam_api.cpp:434-461: only accepted pairs are
+// appended) and of the id bookkeeping around the solver in App::execute (src/app.cpp:134-142).
+__global__ __launch_bounds__(256) void k_word_popcounts(const uint64_t* __restrict__ words,
+                                                        uint32_t n_words,
+                                                        uint32_t* __restrict__ counts) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride)
+        counts[w] = __popcll(words[w]);
+}
+
+__global__ __launch_bounds__(256) void k_compact_pairs(const uint32_t* __restrict__ starts,
+                                                       const uint32_t* __restrict__ ends,
+                                                       const uint64_t* __restrict__ pair_keep,
+                                                       const uint32_t* __restrict__ word_base,
+                                                       uint64_t n_pairs,
+                                                       uint32_t* __restrict__ starts_c,
+                                                       uint32_t* __restrict__ ends_c,
+                                                       uint32_t* __restrict__ orig_pair) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pairs; q += stride) {
+        const uint64_t word = pair_keep[q >> 6];
+        const uint32_t bit = (uint32_t)(q & 63);
+        if ((word >> bit) & 1ull) {
+            const uint32_t dst = word_base[q >> 6] + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+            starts_c[2 * dst] = starts[2 * q];
+            starts_c[2 * dst + 1] = starts[2 * q + 1];
+            ends_c[2 * dst] = ends[2 * q];
+            ends_c[2 * dst + 1] = ends[2 * q + 1];
+            orig_pair[dst] = (uint32_t)q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_expand_mask(const uint64_t* __restrict__ mask_c,
+                                                     const uint32_t* __restrict__ orig_pair,
+                                                     uint32_t n_reads_c,
+                                                     uint32_t* __restrict__ mask32) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads_c; i += stride) {
+        if ((mask_c[i >> 6] >> (i & 63)) & 1ull) {
+            const uint32_t orig = 2u * orig_pair[i >> 1] + (i & 1u);
+            atomicOr(&mask32[orig >> 5], 1u << (orig & 31));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host-side launchers
 static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 * 8) {
     uint64_t g = (n + block - 1) / block;
@@ -2253,6 +2302,22 @@ void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads) {
     hipLaunchKernelGGL(k_complete_pairs, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask,
                        n_words, n_reads);
+}
+
+void launch_word_popcounts(hipStream_t st, const uint64_t* words, uint32_t n_words, uint32_t* counts) {
+    hipLaunchKernelGGL(k_word_popcounts, dim3(grid_for(n_words, 256)), dim3(256), 0, st, words, n_words,
+                       counts);
+}
+void launch_compact_pairs(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
+                          const uint64_t* pair_keep, const uint32_t* word_base, uint64_t n_pairs,
+                          uint32_t* starts_c, uint32_t* ends_c, uint32_t* orig_pair) {
+    hipLaunchKernelGGL(k_compact_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, st, starts, ends,
+                       pair_keep, word_base, n_pairs, starts_c, ends_c, orig_pair);
+}
+void launch_expand_mask(hipStream_t st, const uint64_t* mask_c, const uint32_t* orig_pair,
+                        uint32_t n_reads_c, uint64_t* mask) {
+    hipLaunchKernelGGL(k_expand_mask, dim3(grid_for(n_reads_c, 256)), dim3(256), 0, st, mask_c,
+                       orig_pair, n_reads_c, (uint32_t*)mask);
 }
 
 void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32_t* ends,

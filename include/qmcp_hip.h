@@ -165,6 +165,25 @@ int qmcp_hip_amplicon_filter_host(qmcp_hip_ctx* ctx,
                                   uint32_t n_amplicons, uint32_t min_length, uint32_t min_mapq,
                                   uint64_t* pair_keep_out);
 
+/* The device-resident part of App::execute around the solver (src/app.cpp:113-142) for one
+ * contig, in one call: FILTER pre-pass as in qmcp_hip_amplicon_filter_host (n_amplicons == 0
+ * skips the amplicon predicate, i.e. AmpliconBehaviour::IGNORE; seq_lengths / qualities may be
+ * NULL), compaction of the surviving pairs on the device (what BamApi does while ingesting:
+ * only accepted pairs are appended, bam_api.cpp:434-461), the solve on the survivors, optional
+ * mate completion (BamApi::find_pairs, src/app.cpp:141), and the result expressed over the
+ * ORIGINAL read indices.  keep_mask_out: ceil(n_reads/64) words.  pairs_filtered_out (may be
+ * NULL) receives the number of pairs the pre-pass dropped (BamApi::get_filtered_out_reads
+ * counts their reads).  n_reads must be even (whole pairs). */
+int qmcp_hip_filter_solve_host(qmcp_hip_ctx* ctx,
+                               const uint32_t* starts, const uint32_t* ends,
+                               const uint32_t* seq_lengths, const uint32_t* qualities,
+                               uint64_t n_reads,
+                               const uint32_t* amp_starts, const uint32_t* amp_ends,
+                               uint32_t n_amplicons, uint32_t min_length, uint32_t min_mapq,
+                               uint32_t ref_genome_length, uint32_t max_coverage, int complete_pairs,
+                               uint64_t* keep_mask_out, uint64_t* pairs_filtered_out,
+                               qmcp_hip_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

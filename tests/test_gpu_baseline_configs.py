@@ -80,3 +80,50 @@ def test_cfg4_full_size_properties(pkg, oracle, solver):
     assert np.array_equal(want0, bits[:n_c])
     # minimum cardinality on deep uniform data: M reads per read length of genome, per contig
     assert n_kept == int(bits.sum()) and abs(n_kept - 8 * M * L / 150) < 8 * 2 * M
+
+
+def _oracle_filter_solve(oracle, pkg, s, e, L, M, a0, a1, lens, mapq, min_len, min_q, pairs):
+    n = s.size
+    if a0 is None:
+        keep_pairs = oracle.amplicon_filter(s, e, [0], [0xFFFFFFFF], seq_lengths=lens, qualities=mapq,
+                                            min_length=min_len, min_mapq=min_q)
+    else:
+        keep_pairs = oracle.amplicon_filter(s, e, a0, a1, seq_lengths=lens, qualities=mapq,
+                                            min_length=min_len, min_mapq=min_q)
+    kp = np.zeros(n // 2, bool)
+    kp[pkg.mask_to_indices(keep_pairs, n // 2).astype(np.int64)] = True
+    sel = np.repeat(kp, 2)
+    orig = np.flatnonzero(sel)
+    m = oracle.solve(s[sel], e[sel], L, M)
+    if pairs:
+        m = oracle.find_pairs(m, orig.size)
+    kept_c = pkg.mask_to_indices(m, orig.size).astype(np.int64)
+    return pkg.indices_to_mask(orig[kept_c], n), int((~kp).sum())
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_filter_solve_pipeline_matches_composed_oracle(pkg, oracle, solver, pairs):
+    """App::execute around the solver, device-resident: FILTER -> compaction -> solve -> find_pairs,
+    result over the ORIGINAL read indices (src/app.cpp:113-142)"""
+    s, e, a0, a1, straddle = workloads.amplicon_reads(400_000, seed=21)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(60, 151, size=s.size).astype(np.uint32)
+    mapq = rng.integers(0, 61, size=s.size).astype(np.uint32)
+    got, dropped = solver.filter_solve(s, e, 29_903, 200, amp_starts=a0, amp_ends=a1, seq_lengths=lens,
+                                       qualities=mapq, min_length=90, min_mapq=30, complete_pairs=pairs)
+    want, want_dropped = _oracle_filter_solve(oracle, pkg, s, e, 29_903, 200, a0, a1, lens, mapq, 90, 30, pairs)
+    assert dropped == want_dropped and dropped > int(straddle.sum())
+    assert np.array_equal(got, want)
+    # no amplicons given: AmpliconBehaviour::IGNORE, only the length / MAPQ filters act
+    got, dropped = solver.filter_solve(s, e, 29_903, 50, seq_lengths=lens, qualities=mapq, min_length=90,
+                                       min_mapq=30, complete_pairs=pairs)
+    want, want_dropped = _oracle_filter_solve(oracle, pkg, s, e, 29_903, 50, None, None, lens, mapq, 90, 30, pairs)
+    assert dropped == want_dropped and np.array_equal(got, want)
+    # nothing filtered at all == the plain solve
+    got, dropped = solver.filter_solve(s, e, 29_903, 50, complete_pairs=False)
+    assert dropped == 0 and np.array_equal(got, solver.solve(s, e, 29_903, 50))
+    # everything filtered
+    got, dropped = solver.filter_solve(s, e, 29_903, 50, seq_lengths=lens, min_length=1000)
+    assert dropped == s.size // 2 and not got.any()
+    with pytest.raises(pkg.QmcpError):
+        solver.filter_solve(s[:-1], e[:-1], 29_903, 50)
