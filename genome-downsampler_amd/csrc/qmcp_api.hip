@@ -64,6 +64,7 @@ struct qmcp_hip_ctx {
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
     DevBuf lookback;   // chained radix: (tile, digit) status granules, zeroed when (re)allocated
     DevBuf radixctl;   // [4][256] digit counts, [4][256] digit bases, 4 tickets, timeout flag
+    DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     uint32_t radix_epoch = 0;      // unique per chained pass for the life of the context
     bool chained_radix_ok = true;  // cleared for good if a look-back ever times out
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
@@ -201,7 +202,8 @@ int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
 // want_counts -- the solve derives its bucket offsets from the sorted keys instead.
 int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                 const Problem& pr, const uint64_t* d_keep_mask, bool want_keys, bool want_counts,
-                bool want_part_hist, uint32_t* d_global_digit_hist, uint32_t host_stats[3]) {
+                bool want_part_hist, uint32_t part_shift, uint32_t* d_global_digit_hist,
+                uint32_t host_stats[3]) {
     const uint32_t n = (uint32_t)pr.n;
     TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     if (want_counts) TRY(ensure(c, c->cstart, ((size_t)pr.ltot + 1) * sizeof(uint32_t)));
@@ -216,8 +218,8 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
                              (const uint64_t*)c->poff.p, pr.n_contigs, d_keep_mask,
                              want_keys ? (uint32_t*)c->vals[1].p : nullptr,
                              want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p,
-                             want_part_hist ? (uint32_t*)c->hist2.p : nullptr,
-                             want_part_hist ? (uint32_t*)c->hist.p : nullptr, d_global_digit_hist);
+                             part_shift, want_part_hist ? (uint32_t*)c->hist2.p : nullptr, nullptr,
+                             d_global_digit_hist);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -239,6 +241,11 @@ int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
     HIP_TRY(hipGetLastError());
     return QMCP_OK;
 }
+
+// the ranked path is taken when no position range holds more than 1/kRankBalance of the reads:
+// a range's ranking is one wave's serial walk (~0.65 ns per read) against ~0.03 ns per read for
+// the radix sort it replaces
+constexpr uint64_t kRankBalance = 24;
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
@@ -284,15 +291,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->scalars, 64));
+        TRY(ensure(c, c->ranges, 260 * sizeof(uint32_t)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     }
     HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
     TRY(upload_tables(c, roff, pr));
 
     uint32_t hs[3];
-    // the counting partition's per-tile histogram is produced by the same pass when the
-    // two-stream path can be taken (uniformity is only known afterwards; the table is cheap)
-    const bool may_overlap = n >= (1u << 22) && qmcp::early_counts_supported(ltot);
     // Chained radix passes (one kernel per digit, decoupled look-back) are an opt-in experiment:
     // on cfg4 they measured 1.02 ms per pass against 1.13 ms for histogram + scan + scatter, and
     // the whole-call digit histograms they need cost k_prepare 0.2 ms -- no net gain until the
@@ -311,7 +316,11 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         d_ctl = (uint32_t*)c->radixctl.p;
         HIP_TRY(hipMemsetAsync(d_ctl, 0, (2 * 4 * 256 + 16) * sizeof(uint32_t), c->stream));
     }
-    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_overlap, d_ctl, hs));
+    // the range partition's per-tile histogram is produced by the same pass when the range-ranked
+    // path can be taken (uniformity is only known afterwards; the table is cheap)
+    const uint32_t range_shift = qmcp::range_shift_for(ltot);
+    const bool may_rank = n >= (1u << 22) && qmcp::range_path_supported(ltot) && !try_chained;
+    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_rank, range_shift, d_ctl, hs));
     HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
@@ -351,65 +360,86 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
 
-    // Uniform span: the sweep needs only reads-per-position counts, not the sorted order, so
-    // counts are produced early (key partition + LDS histograms) and the sweep runs on a second
-    // stream beside the radix passes.  Worth it only for problems large enough to fill the chip.
-    const bool overlap = uniform && may_overlap;
+    // Uniform span, large call: neither the sweep nor the keep mask needs a full sort.  One stable
+    // partition of {start, index} records by position range, per-range LDS counts, the sweep, and
+    // a per-range ordered ranking against S(p) -- see "range-ranked uniform path" in the kernels.
+    // The heaviest range's load is read back on the second stream while the partition runs; if
+    // one range holds too much (its ranking is one wave's serial walk), the keep mask comes from
+    // the radix sort instead (the counts and the sweep done here stay valid).
+    bool sweep_done = false, ranked = false;
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
-    if (overlap) {
-        // Counts first, alone on the main stream: k_lds_count needs a whole CU's LDS per
-        // workgroup and crawls when it has to wait for radix workgroups to drain (0.9 ms beside
-        // them, 0.2 ms alone).  Then fork: scan + sweep on the high-priority stream, the radix
-        // passes on the main stream.
+    if (uniform && may_rank) {
         hipStream_t s1 = c->stream;
+        uint32_t* d_range_start = (uint32_t*)c->ranges.p;
+        uint32_t* d_max_load = d_range_start + 257;
         {
             KernelSpan sp(c, "scan_radix_hist(3 kernels)");
             qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
         {
-            KernelSpan sp(c, "k_count_partition");
-            qmcp::launch_count_partition_scatter(s1, d_key32, n, (const uint32_t*)c->hist2.p,
-                                                 (uint32_t*)c->vals[0].p);
+            KernelSpan sp(c, "k_range_table");
+            qmcp::launch_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
         }
-        {
-            KernelSpan sp(c, "k_lds_count");
-            qmcp::launch_lds_count(s1, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->hist2.p, n,
-                                   ltot, (uint32_t*)c->cstart.p);
-        }
-        HIP_TRY(hipGetLastError());
-        hipStream_t s2 = c->stream2;
         HIP_TRY(hipEventRecord(c->ev_fork, s1));
-        HIP_TRY(hipStreamWaitEvent(s2, c->ev_fork, 0));
         {
-            KernelSpan sp(c, "scan_positions(3 kernels)", s2);
-            qmcp::launch_exclusive_scan(s2, (const uint32_t*)c->cstart.p, ltot, (uint32_t*)c->boff.p,
+            KernelSpan sp(c, "k_radix_scatter_rec");
+            qmcp::launch_radix_scatter_rec(s1, true, d_key32, nullptr, n, range_shift,
+                                           (const uint32_t*)c->hist2.p, c->keys[0].p);
+        }
+        {
+            KernelSpan sp(c, "k_range_count");
+            qmcp::launch_range_count(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+                                     (uint32_t*)c->cstart.p);
+        }
+        {
+            KernelSpan sp(c, "scan_positions(3 kernels)");
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->cstart.p, ltot, (uint32_t*)c->boff.p,
                                         (uint32_t*)c->spine2.p, true);
         }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
         {
             // three waves per contig where the span allows it, else the single-wave kernel
             KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
-                                                                       : "k_sweep_uniform", s2);
-            if (!qmcp::launch_sweep_uniform_mw(s2, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
+                                                                       : "k_sweep_uniform");
+            if (!qmcp::launch_sweep_uniform_mw(s1, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
                                                n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p,
                                                d_iters) &&
-                !qmcp::launch_sweep_uniform(s2, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
+                !qmcp::launch_sweep_uniform(s1, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
                                             n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p, d_iters))
                 return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_join, s2));
+        HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
+        sweep_done = true;
+        // heaviest range, fetched beside the work queued above
+        uint32_t max_load = 0;
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(hipMemcpyAsync(&max_load, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
+        HIP_TRY(hipStreamSynchronize(c->stream2));
+        ranked = (uint64_t)max_load * kRankBalance <= (uint64_t)n;
+        if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
+        if (ranked) {
+            KernelSpan sp(c, "k_rank_mark");
+            qmcp::launch_rank_mark(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+                                   (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p,
+                                   (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p);
+            HIP_TRY(hipGetLastError());
+        }
     }
 
     // radix bucketing: stable LSD, 8-bit digits
     const uint32_t key_bits = pos_bits + span_bits;
     const uint32_t passes = (key_bits + 7) / 8;
-    local.sort_passes = passes;
+    local.sort_passes = ranked ? 1u : passes;  // ranked path: one range partition, no sort
     const uint32_t n_tiles = qmcp::sort_tiles(n);
     int kin = 0, vin = 0;  // buffers holding the sorted output at the end
     const bool chained = try_chained && uniform;
-    if (chained) {
+    if (ranked) {
+        // keep mask already written by k_rank_mark
+    } else if (chained) {
         // one kernel per digit: decoupled look-back over per-tile digit counts
         uint32_t* d_base = d_ctl + 4 * 256;
         uint32_t* d_ticket = d_ctl + 8 * 256;
@@ -436,8 +466,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         for (uint32_t p = 0; p < passes; ++p) {
             const bool first = p == 0;
             const int kout = first ? 0 : (kin ^ 1);
-            // (the first pass's histogram was produced by k_prepare on the two-stream path)
-            if (!(first && overlap)) {
+            {
                 KernelSpan sp(c, "k_radix_hist_rec");
                 qmcp::launch_radix_hist_rec(c->stream, first, d_key32, recs_in, n, 8 * p,
                                             (uint32_t*)c->hist.p);
@@ -483,7 +512,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         }
     }
     // bucket offsets straight from the sorted keys (no atomics)
-    if (!overlap) {
+    if (!sweep_done) {
     HIP_TRY(hipMemsetAsync(c->boff.p, 0xFF, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
     {
         KernelSpan sp(c, "k_bucket_heads");
@@ -496,11 +525,11 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[EV_SORT], c->stream));
+    if (!sweep_done) HIP_TRY(hipEventRecord(c->ev[EV_SORT], c->stream));
 
     // selection sweep
-    if (overlap) {
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // sweep ran on stream2
+    if (sweep_done) {
+        // done above, from the early counts
     } else if (uniform) {
         KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
                                                                    : "k_sweep_uniform");
@@ -544,10 +573,10 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], c->stream));
+    if (!sweep_done) HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], c->stream));
 
     // keep mask
-    {
+    if (!ranked) {
         KernelSpan sp(c, "k_mark");
         qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, ltot,
                           (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p, d_mask,
@@ -624,7 +653,7 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     TRY(upload_tables(c, roff, pr));
     uint32_t hs[3];
     TRY(run_prepare(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, pr, d_keep,
-                    true, true, false, nullptr, hs));
+                    true, true, false, 0, nullptr, hs));
     TRY(scan_counts(c, c->cstart, c->boff, ltot));
     TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
@@ -699,7 +728,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

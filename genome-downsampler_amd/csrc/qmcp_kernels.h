@@ -15,8 +15,9 @@ static constexpr uint32_t kMaxCachedSpan = 4032;    // LDS-cached mixed-span swe
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats, uint32_t* part_hist /* digit-major [256][tiles] or null */,
-                    uint32_t* digit0_hist /* same shape; written iff part_hist is */,
+                    uint32_t* stats, uint32_t part_shift,
+                    uint32_t* part_hist /* digit-major [256][tiles] of (gstart >> part_shift), or null */,
+                    uint32_t* digit0_hist /* same shape, low byte of gstart; needs part_hist; or null */,
                     uint32_t* global_digit_hist /* [4][256] whole-call digit counts of gstart, or null */);
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
@@ -80,12 +81,17 @@ void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, con
                            uint32_t n, uint32_t shift, const uint32_t* digit_base,
                            unsigned long long* status, uint32_t epoch, uint32_t* ticket,
                            uint32_t* timeout_flag, void* recs_out);
-// early counts (uniform path): reads per start position from a key partition + LDS histograms
-bool early_counts_supported(uint32_t ltot);
-void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
-                                    const uint32_t* offs, uint32_t* part_keys);
-void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,
-                      uint32_t ltot, uint32_t* cstart);
+// range-ranked uniform path: one stable partition of {start, index} records by position range,
+// then per-range LDS histograms (counts) and per-range ordered ranking against S(p) (keep mask)
+uint32_t range_shift_for(uint32_t ltot);
+bool range_path_supported(uint32_t ltot);
+void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
+                        uint32_t* range_start, uint32_t* max_load);
+void launch_range_count(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                        uint32_t ltot, uint32_t* cstart);
+void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                      uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                      unsigned long long* mask, unsigned long long* kept_total);
 
 }  // namespace qmcp
 #endif

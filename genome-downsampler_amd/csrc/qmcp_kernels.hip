@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     __syncthreads();
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
-    // Work is laid out in the radix tiles (4096 reads) so that two per-tile histograms fall out
-    // of the same pass: the counting partition's (digit = global start >> part_shift) and the
-    // first radix pass's (digit = low byte of the global start, the uniform path's key).
+    // Work is laid out in the radix tiles (4096 reads) so that per-tile histograms fall out of
+    // the same pass: the range partition's (digit = global start >> part_shift) and, optionally,
+    // the first LSD radix pass's (digit = low byte of the global start).
     const uint32_t t0 = blockIdx.x * tiles_per_block;
     for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
         const uint32_t tile = t0 + g;
@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             if (gstart_out) gstart_out[i] = gs;
             if (part_hist) {
                 atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
-                atomicAdd(&s_h0[gs & 255u], 1u);
+                if (digit0_hist) atomicAdd(&s_h0[gs & 255u], 1u);
             }
             if (global_digit_hist) {
                 // digit 0 is taken from s_h0 below when it exists; otherwise count it here too
-                if (!part_hist) atomicAdd(&s_gh[0][gs & 255u], 1u);
+                if (!(part_hist && digit0_hist)) atomicAdd(&s_gh[0][gs & 255u], 1u);
                 atomicAdd(&s_gh[1][(gs >> 8) & 255u], 1u);
                 atomicAdd(&s_gh[2][(gs >> 16) & 255u], 1u);
                 atomicAdd(&s_gh[3][(gs >> 24) & 255u], 1u);
@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
         if (part_hist) {
             __syncthreads();
             part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
-            digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
-            if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
+            if (digit0_hist) {
+                digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
+                if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
+            }
             __syncthreads();
         }
     }
@@ -529,83 +531,174 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
     }
 }
 
-// ------------------------------------------------------------------ early counts
-// Reads-per-start-position without global atomics and without waiting for the full sort:
-// keys partitioned by (pos >> kCountShift) arrive grouped by a 32 Ki-position range, one
-// workgroup per range histograms it in LDS (128 KiB of counters) and stores the counts
-// coalesced.  Lets the selection sweep (which needs counts only) run beside the radix passes.
-static constexpr uint32_t kCountShift = 15;
-static constexpr uint32_t kCountRange = 1u << kCountShift;
+// ------------------------------------------------------------------ range-ranked uniform path
+// Uniform-span selection needs two things per start position p: the number of reads starting
+// there (for the sweep) and, afterwards, the S(p) lowest read indices of the bucket.  Neither
+// needs a full sort.  ONE stable partition of {global start, read index} records by position
+// range (digit = gstart >> shift, <= 256 ranges of <= 32 Ki positions, the first pass of the
+// record radix with a different shift) groups the reads of a range together IN INDEX ORDER;
+// per range an LDS array then gives
+//   k_range_count : reads per position (LDS histogram, coalesced store), and
+//   k_rank_mark   : the kept reads, by walking the range's records in order against a
+//                   per-position quota that starts at S(p).
+// 8 + 8 B/read for the partition instead of three radix passes (3 x 24 B/read) plus k_mark.
+static constexpr uint32_t kMaxRangeShift = 15;  // 32 Ki positions x 4 B = 128 KiB of LDS
 
-// Counting partition: order inside a partition is irrelevant (the keys are only counted), so
-// ranks come from LDS returning atomics instead of the stable ballot matching.  The tile is
-// staged through LDS and leaves as one contiguous run per partition.
-__global__ __launch_bounds__(kSortThreads) void k_count_partition(
-    const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_tiles,
-    uint32_t tiles_per_block, const uint32_t* __restrict__ offs, uint32_t* __restrict__ part_keys) {
-    __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_off[256];
-    __shared__ uint32_t s_gbase[256];
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_key[kSortTile];
-    const uint32_t t0 = blockIdx.x * tiles_per_block;
-    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
-        const uint32_t tile = t0 + g;
-        s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t tile_base = tile * kSortTile;
-        const uint32_t tile_count = min((uint32_t)kSortTile, n - tile_base);
-        uint32_t key[kSortItems], rank[kSortItems];
-#pragma unroll
-        for (int k = 0; k < kSortItems; ++k) {
-            const uint32_t j = k * kSortThreads + threadIdx.x;
-            key[k] = j < tile_count ? keys[tile_base + j] : 0u;
-            rank[k] = j < tile_count ? atomicAdd(&s_cnt[(key[k] >> shift) & 255u], 1u) : 0u;
-        }
-        __syncthreads();
-        {
-            const uint32_t d = threadIdx.x;
-            uint32_t tot;
-            const uint32_t off = block_excl_scan_256(s_cnt[d], s_wave, tot);
-            s_off[d] = off;
-            s_gbase[d] = offs[d * n_tiles + tile] - off;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kSortItems; ++k) {
-            const uint32_t j = k * kSortThreads + threadIdx.x;
-            if (j < tile_count) s_key[s_off[(key[k] >> shift) & 255u] + rank[k]] = key[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kSortItems; ++k) {
-            const uint32_t j = k * kSortThreads + threadIdx.x;
-            if (j < tile_count) {
-                const uint32_t kk = s_key[j];
-                part_keys[s_gbase[(kk >> shift) & 255u] + j] = kk;
-            }
-        }
-        __syncthreads();
-    }
+// starts of the ranges in partitioned order (257 entries) and the heaviest range's load
+__global__ __launch_bounds__(256) void k_range_table(const uint32_t* __restrict__ scanned_hist,
+                                                     uint32_t n_tiles, uint32_t n,
+                                                     uint32_t* __restrict__ range_start,
+                                                     uint32_t* __restrict__ max_load) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t d = threadIdx.x;
+    const uint32_t lo = scanned_hist[d * n_tiles];
+    const uint32_t hi = d + 1 < 256 ? scanned_hist[(d + 1) * n_tiles] : n;
+    range_start[d] = lo;
+    if (d == 255) range_start[256] = n;
+    const uint32_t m = wave_max_u32(hi - lo);
+    if ((d & 63) == 0) s_red[d >> 6] = m;
+    __syncthreads();
+    if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-__global__ __launch_bounds__(1024) void k_lds_count(const uint32_t* __restrict__ part_keys,
-                                                    const uint32_t* __restrict__ part_offs,
-                                                    uint32_t n_tiles, uint32_t n, uint32_t n_parts,
-                                                    uint32_t ltot, uint32_t* __restrict__ cstart) {
-    extern __shared__ uint32_t s_cnt32[];  // [kCountRange]
-    const uint32_t part = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < kCountRange; i += blockDim.x) s_cnt32[i] = 0;
+__global__ __launch_bounds__(1024) void k_range_count(const Rec* __restrict__ recs,
+                                                      const uint32_t* __restrict__ range_start,
+                                                      uint32_t shift, uint32_t ltot,
+                                                      uint32_t* __restrict__ cstart) {
+    extern __shared__ uint32_t s_cnt32[];  // [1 << shift]
+    const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
+    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[i] = 0;
     __syncthreads();
-    const uint32_t lo = part_offs[part * n_tiles];
-    const uint32_t hi = part + 1 < 256 ? part_offs[(part + 1) * n_tiles] : n;
-    const uint32_t pos0 = part << kCountShift;
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x)
-        atomicAdd(&s_cnt32[part_keys[j] - pos0], 1u);
+    const uint32_t lo = range_start[range], hi = range_start[range + 1];
+    // eight loads in flight per thread: the range's records stream in at L2 speed instead of one
+    // round trip per iteration
+    constexpr int U = 8;
+    uint32_t j = lo + threadIdx.x;
+    for (; j + (U - 1) * 1024u < hi; j += U * 1024u) {
+        uint32_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) k[u] = recs[j + u * 1024u].key;
+#pragma unroll
+        for (int u = 0; u < U; ++u) atomicAdd(&s_cnt32[k[u] - pos0], 1u);
+    }
+    for (; j < hi; j += 1024u) atomicAdd(&s_cnt32[recs[j].key - pos0], 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kCountRange; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x)
         if (pos0 + i <= ltot) cstart[pos0 + i] = s_cnt32[i];
-    (void)n_parts;
+}
+
+// One workgroup (16 waves) per range.  The quota array starts at q[p] = S(p) = selend - boff.
+// The range's records are walked in order (they are in read-index order), one chunk of
+// blockDim.x records at a time: every thread draws old = q[p]-- for its record, a barrier, then
+// reads q_after = q[p].  Chunks are ordered by the barrier, so a read is kept iff old > 0 --
+// except that threads of ONE chunk that hit the same position draw their `old` values in an
+// unspecified order, which matters only where the quota runs out inside the chunk
+// (0 < quota < colliders).  Exactly one thread of such a group draws old == 1 while seeing
+// q_after < 0; it lists the position, and the listed positions are resolved by index order:
+// per-wave ballots + a 16-entry count exchange give every member its rank inside the group, and
+// the lowest `quota` ranks keep.  If a chunk lists more positions than is worth resolving one by
+// one (tiny ranges with deep pile-ups), the chunk's decrements are undone and redone wave by
+// wave in order, each wave resolving its own collisions with ballots.  Either way the kept set
+// is exactly the S(p) lowest indices of every bucket, independent of LDS arbitration order.
+static constexpr uint32_t kAmbCap = 12;
+
+__global__ __launch_bounds__(1024) void k_rank_mark(const Rec* __restrict__ recs,
+                                                    const uint32_t* __restrict__ range_start,
+                                                    uint32_t shift, uint32_t ltot,
+                                                    const uint32_t* __restrict__ boff,
+                                                    const uint32_t* __restrict__ selend,
+                                                    unsigned long long* __restrict__ mask,
+                                                    unsigned long long* __restrict__ kept_total) {
+    extern __shared__ int32_t s_q[];  // [(1 << shift) + 1]; the last entry absorbs idle threads
+    __shared__ uint32_t s_amb[kAmbCap];
+    __shared__ uint32_t s_namb[3];
+    __shared__ uint32_t s_wcnt[16];
+    const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
+    const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nw = nthreads >> 6;
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t i = tid; i < live; i += nthreads)
+        s_q[i] = (int32_t)(selend[pos0 + i] - boff[pos0 + i]);
+    if (tid < 3) s_namb[tid] = 0;
+    const uint32_t lo = range_start[range], hi = range_start[range + 1];
+    if (lo >= hi) return;  // uniform
+    __syncthreads();
+    const uint32_t n_chunks = (hi - lo + nthreads - 1) / nthreads;
+    uint32_t kept = 0;
+
+    auto fetch = [&](Rec& dst, uint32_t c) { dst = recs[min(lo + c * nthreads + tid, hi - 1)]; };
+    auto chunk = [&](const Rec& r, uint32_t c, uint32_t slot /* c % 3 */) {
+        const bool valid = lo + c * nthreads + tid < hi;
+        const uint32_t li = valid ? r.key - pos0 : width;
+        const int32_t old = atomicSub(&s_q[li], 1);
+        if (tid == 0) s_namb[slot == 2 ? 0 : slot + 1] = 0;  // counter of the NEXT chunk (last read two chunks ago)
+        __syncthreads();
+        const int32_t aft = s_q[li];
+        bool keep = valid && old > 0;
+        if (keep && old == 1 && aft < 0) {
+            const uint32_t k = atomicAdd(&s_namb[slot], 1u);
+            if (k < kAmbCap) s_amb[k] = li;
+        }
+        __syncthreads();
+        const uint32_t namb = s_namb[slot];
+        if (namb != 0 && namb <= kAmbCap) {
+            for (uint32_t k = 0; k < namb; ++k) {
+                const bool member = valid && li == s_amb[k];
+                const uint64_t m = __ballot(member);
+                if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(m);
+                __syncthreads();
+                if (member) {
+                    uint32_t before = 0, total = 0;
+                    for (uint32_t x = 0; x < nw; ++x) {
+                        const uint32_t cx = s_wcnt[x];
+                        total += cx;
+                        before += x < w ? cx : 0u;
+                    }
+                    keep = (int32_t)(before + (uint32_t)__popcll(m & lt_mask)) < aft + (int32_t)total;
+                }
+                __syncthreads();
+            }
+        } else if (namb != 0) {
+            atomicAdd(&s_q[li], 1);  // undo the chunk
+            __syncthreads();
+            for (uint32_t x = 0; x < nw; ++x) {
+                if (w == x) {
+                    const int32_t o2 = atomicSub(&s_q[li], 1);
+                    const int32_t a2 = s_q[li];
+                    keep = valid && o2 > 0;
+                    uint64_t trig = __ballot(keep && a2 < 0);  // quota ran out inside this wave's step
+                    while (trig) {
+                        const int leader = __ffsll((long long)trig) - 1;
+                        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)li, leader);
+                        const uint64_t same = __ballot(valid && li == p0);
+                        const int32_t quota = __builtin_amdgcn_readlane(a2, leader) + (int32_t)__popcll(same);
+                        if (valid && li == p0) keep = (int32_t)__popcll(same & lt_mask) < quota;
+                        trig &= ~same;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (keep) atomicOr(&mask[r.val >> 6], 1ull << (r.val & 63u));
+        kept += (uint32_t)__popcll(__ballot(keep));
+    };
+    // Records are prefetched two chunks ahead into three registers that rotate by NAME (the loop
+    // is unrolled three times): no register copies, so the wait for a chunk's records is a counted
+    // s_waitcnt that covers only the fire-and-forget mask atomics of two chunks ago.  Chunks past
+    // the end run with every thread idle (dummy quota slot).
+    Rec A, B, C;
+    fetch(A, 0);
+    fetch(B, 1);
+    for (uint32_t c = 0; c < n_chunks; c += 3) {
+        fetch(C, c + 2);
+        chunk(A, c, 0);
+        fetch(A, c + 3);
+        chunk(B, c + 1, 1);
+        fetch(B, c + 4);
+        chunk(C, c + 2, 2);
+    }
+    if (lane == 0 && kept) atomicAdd(kept_total, (unsigned long long)kept);
 }
 
 // ------------------------------------------------------------------ chained radix pass
@@ -1324,6 +1417,60 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
 // before storing), and the chain wave is at most one group ahead of it, so no speculative value
 // ever reaches memory.
 // LDS: three group slots x four blocks x (6E + 2) words x 64 lanes, word-major (conflict-free).
+// A "row" is one block's bucket offsets in slot layout: X[r] = cb[min(a + lane*E + r, L)].
+// Each lane's E slots are adjacent in memory, so a row is ONE vector load per lane (dwordx2/x3/
+// x4) instead of E scalar ones; rows that poke past the end of the table fall back to clamped
+// scalar loads.  The three views a block needs are then built in registers:
+//   x0 = X(b),  x1 = X(b) shifted by one slot,  x2 = X(b+1) shifted by one slot,
+// where "shifted" takes slot r+1 of the same lane, the next lane's slot 0 (DPP wave_shl:1) for
+// the lane's last slot, and the following row's very first entry for the block's last slot.
+template <int E> struct RowVec;
+template <> struct RowVec<1> { typedef uint32_t type; };
+template <> struct RowVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct RowVec<3> { typedef uint32_t type __attribute__((ext_vector_type(3), aligned(4))); };
+template <> struct RowVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
+
+template <int E>
+__device__ __forceinline__ void row_load(const uint32_t* __restrict__ cb, uint32_t a, uint32_t L,
+                                         uint32_t lane, uint32_t (&X)[E]) {
+    // branch-free (a load inside a divergent branch makes the compiler drain vmcnt at the join):
+    // the vector is read at a base clamped so that it ends at cb[L] at the latest, and lanes
+    // whose base moved pick their entries with selects: X[r] = v[min(sh + r, E-1)]
+    const uint32_t p = a + lane * E;
+    const uint32_t pe = min(p, L + 1 - E);  // L >= ell > E always
+    const uint32_t sh = p - pe;
+    if constexpr (E == 1) {
+        X[0] = cb[pe];
+    } else {
+        typedef typename RowVec<E>::type V;
+        const V v = *reinterpret_cast<const V*>(cb + pe);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            uint32_t x = v[E - 1];
+#pragma unroll
+            for (int q = E - 2; q >= r; --q) x = (sh + r <= (uint32_t)q) ? v[q] : x;
+            X[r] = x;
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void rows_to_loads(const uint32_t (&Xa)[E], const uint32_t (&Xb)[E],
+                                              const uint32_t (&Xc)[E], uint32_t lane,
+                                              uint32_t last_lane, uint32_t last_r, SweepLoads<E>& o) {
+    const uint32_t nb0 = QMCP_DPP(0u, Xa[0], 0x130, 0xF);  // next lane's first slot (wave_shl:1)
+    const uint32_t nb1 = QMCP_DPP(0u, Xb[0], 0x130, 0xF);
+    const uint32_t tail1 = __builtin_amdgcn_readlane(Xb[0], 0);  // cb[a + ell]
+    const uint32_t tail2 = __builtin_amdgcn_readlane(Xc[0], 0);  // cb[a + 2 ell]
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const bool is_last = lane == last_lane && (uint32_t)r == last_r;
+        o.x0[r] = Xa[r];
+        o.x1[r] = is_last ? tail1 : (r + 1 < E ? Xa[r + 1 < E ? r + 1 : r] : nb0);
+        o.x2[r] = is_last ? tail2 : (r + 1 < E ? Xb[r + 1 < E ? r + 1 : r] : nb1);
+    }
+}
+
 template <int E>
 struct MwLayout {
     static constexpr int kC = 0;            // [E]  inclusive count prefix       PREP -> CHAIN
@@ -1402,10 +1549,12 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
         // pipeline over groups g0, g0+1, ...: stage t has PREP on g0+t, CHAIN on g0+t-1, CHECK on g0+t-2
         const uint32_t n_left = n_groups - g0;
         uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
-        SweepLoads<E> ld[4];
+        // PREP keeps a window of six rows (blocks 4g .. 4g+5); the four new rows of the next
+        // stage are loaded at the start of each stage and have a whole stage to land
+        uint32_t W[6][E], Nw[4][E];
         if (role == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sweep_load<E>(cb, (g0 * 4 + k) * ell, ell, L, lane, ld[k]);
+            for (int k = 0; k < 6; ++k) row_load<E>(cb, (g0 * 4 + k) * ell, L, lane, W[k]);
         }
         if (role == 1) {
 #pragma unroll
@@ -1421,11 +1570,13 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                     const uint32_t g = g0 + t;
                     const uint32_t slot = g % Ly::kSlots;
 #pragma unroll
+                    for (int k = 0; k < 4; ++k) row_load<E>(cb, (g * 4 + 6 + k) * ell, L, lane, Nw[k]);
+#pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        SweepLoads<E> ldk;
+                        rows_to_loads<E>(W[k], W[k + 1], W[k + 2], lane, last_lane, last_r, ldk);
                         BlockPrep<E> pr;
-                        prep_block<E>(ld[k], (g * 4 + k) * ell, ell, L, M, lane, pr);
-                        // loads of the same block of the NEXT group: a whole stage to land
-                        sweep_load<E>(cb, ((g + 1) * 4 + k) * ell, ell, L, lane, ld[k]);
+                        prep_block<E>(ldk, (g * 4 + k) * ell, ell, L, M, lane, pr);
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
                             MW_AT(slot, k, Ly::kC + r) = pr.C[r];
@@ -1435,6 +1586,12 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                         }
                         MW_AT(slot, k, Ly::kBefore) = pr.before;
                     }
+                    // slide the window by four rows
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        W[0][r] = W[4][r]; W[1][r] = W[5][r];
+                        W[2][r] = Nw[0][r]; W[3][r] = Nw[1][r]; W[4][r] = Nw[2][r]; W[5][r] = Nw[3][r];
+                    }
                 }
             } else if (role == 1) {
                 if (t >= 1 && t <= n_left) {
@@ -1443,15 +1600,30 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
 #pragma unroll
                     for (int r = 0; r < E; ++r) { h_prev[r] = h_cur[r]; h_cur[r] = h[r]; }
                     d_prev = d_cur; d_cur = d_last;
+                    // terms of block k+1 are read from LDS before block k's scans start, so their
+                    // latency hides under the scans (the compiler will not hoist LDS reads above the
+                    // previous block's LDS writes by itself)
+                    uint32_t Cn[E], exn[E], bn;
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        Cn[r] = MW_AT(slot, 0, Ly::kC + r);
+                        exn[r] = MW_AT(slot, 0, Ly::kEx + r);
+                    }
+                    bn = MW_AT(slot, 0, Ly::kBefore);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         uint32_t C[E], exj[E];
 #pragma unroll
-                        for (int r = 0; r < E; ++r) {
-                            C[r] = MW_AT(slot, k, Ly::kC + r);
-                            exj[r] = MW_AT(slot, k, Ly::kEx + r);
+                        for (int r = 0; r < E; ++r) { C[r] = Cn[r]; exj[r] = exn[r]; }
+                        const uint32_t before = bn;
+                        if (k < 3) {
+#pragma unroll
+                            for (int r = 0; r < E; ++r) {
+                                Cn[r] = MW_AT(slot, k + 1, Ly::kC + r);
+                                exn[r] = MW_AT(slot, k + 1, Ly::kEx + r);
+                            }
+                            bn = MW_AT(slot, k + 1, Ly::kBefore);
                         }
-                        const uint32_t before = MW_AT(slot, k, Ly::kBefore);
                         // the two chain scans, interleaved (see sweep_block_fast)
                         int32_t lp[E];
                         int32_t pm = 0x7FFFFFFF;
@@ -2030,14 +2202,14 @@ static inline uint32_t tiles_per_block_for(uint32_t n_tiles);
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
-                    uint32_t* stats, uint32_t* part_hist, uint32_t* digit0_hist,
-                    uint32_t* global_digit_hist) {
+                    uint32_t* stats, uint32_t part_shift, uint32_t* part_hist,
+                    uint32_t* digit0_hist, uint32_t* global_digit_hist) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const uint32_t g = tiles_per_block_for(n_tiles);
     hipLaunchKernelGGL(k_prepare, dim3((n_tiles + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       kCountShift, part_hist, digit0_hist, global_digit_hist);
+                       part_shift, part_hist, digit0_hist, global_digit_hist);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
@@ -2273,25 +2445,38 @@ void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, con
                            timeout_flag, (Rec*)recs_out);
 }
 
-// early counts: partition bare keys by (pos >> 15), then one LDS histogram per 32 Ki range
-bool early_counts_supported(uint32_t ltot) { return ((ltot + kCountRange) >> kCountShift) <= 256; }
-
-void launch_count_partition_scatter(hipStream_t st, const uint32_t* keys, uint32_t n,
-                                    const uint32_t* offs, uint32_t* part_keys) {
-    const uint32_t n_tiles = sort_tiles(n);
-    const uint32_t g = tiles_per_block_for(n_tiles);
-    hipLaunchKernelGGL(k_count_partition, dim3((n_tiles + g - 1) / g), dim3(kSortThreads), 0, st,
-                       keys, n, kCountShift, n_tiles, g, offs, part_keys);
+// range-ranked uniform path: geometry, partition table, counts, rank + mark
+uint32_t range_shift_for(uint32_t ltot) {
+    // smallest shift whose ranges (positions 0..ltot inclusive) fit the 256 digits of one pass
+    uint32_t shift = 0;
+    while (shift <= kMaxRangeShift && (ltot >> shift) >= 256u) ++shift;
+    return shift;  // > kMaxRangeShift: not supported
 }
-void launch_lds_count(hipStream_t st, const uint32_t* part_keys, const uint32_t* part_offs, uint32_t n,
-                      uint32_t ltot, uint32_t* cstart) {
-    const uint32_t n_tiles = sort_tiles(n);
-    const uint32_t n_parts = (ltot + kCountRange) >> kCountShift;  // covers positions 0..ltot
-    const size_t lds = (size_t)kCountRange * sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void*)k_lds_count, hipFuncAttributeMaxDynamicSharedMemorySize,
+bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxRangeShift; }
+
+void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
+                        uint32_t* range_start, uint32_t* max_load) {
+    hipLaunchKernelGGL(k_range_table, dim3(1), dim3(256), 0, st, scanned_hist, sort_tiles(n), n,
+                       range_start, max_load);
+}
+void launch_range_count(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                        uint32_t ltot, uint32_t* cstart) {
+    const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
+    const size_t lds = ((size_t)1 << shift) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void*)k_range_count, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_lds_count, dim3(n_parts), dim3(1024), lds, st, part_keys, part_offs, n_tiles,
-                       n, n_parts, ltot, cstart);
+    hipLaunchKernelGGL(k_range_count, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs,
+                       range_start, shift, ltot, cstart);
+}
+void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                      uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                      unsigned long long* mask, unsigned long long* kept_total) {
+    const uint32_t n_ranges = (ltot >> shift) + 1;
+    const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void*)k_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs, range_start,
+                       shift, ltot, boff, selend, mask, kept_total);
 }
 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,

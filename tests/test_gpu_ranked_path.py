@@ -1,0 +1,99 @@
+"""The range-ranked uniform path (calls of >= 4 Mi reads): one stable partition by position range,
+per-range LDS counts, sweep, per-range ordered ranking against S(p).  The kept set must be the
+S(p) lowest read indices of every start bucket -- bit-identical to the oracle -- whatever order the
+LDS arbitrates colliding lanes in, and identical to what the radix-sort route produces."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_BIG = (1 << 22) + 12_345  # just above the threshold of the ranked path, not a tile multiple
+
+
+def _uniform_reads(rng, n, L, span):
+    s = rng.integers(0, L - span + 1, size=n, dtype=np.uint32)
+    return s, (s + np.uint32(span - 1)).astype(np.uint32)
+
+
+def _solve_both_routes(solver, s, e, lengths, M, offs=None):
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    passes = solver.last_stats.sort_passes
+    os.environ["QMCP_HIP_NO_RANK"] = "1"
+    try:
+        sorted_route = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        sorted_passes = solver.last_stats.sort_passes
+    finally:
+        del os.environ["QMCP_HIP_NO_RANK"]
+    return got, passes, sorted_route, sorted_passes
+
+
+@pytest.mark.parametrize("M", [1, 3, 40])
+def test_small_genome_pileups_collide_inside_a_step(pkg, oracle, solver, M):
+    """4.2 M reads on 20 k positions: ~210 reads per start, 128-position ranges, so most lanes of a
+    64-record step share positions and quotas run out in the middle of a step (slow path)"""
+    rng = np.random.default_rng(100 + M)
+    L, span = 20_000, 100
+    s, e = _uniform_reads(rng, N_BIG, L, span)
+    got, passes, sorted_route, sorted_passes = _solve_both_routes(solver, s, e, L, M)
+    assert solver.last_stats.path == pkg.PATH_UNIFORM
+    assert passes == 1 and sorted_passes == 2
+    assert np.array_equal(got, sorted_route)
+    assert np.array_equal(got, oracle.solve(s, e, L, M))
+
+
+def test_last_range_partial_and_reads_at_the_last_position(pkg, oracle, solver):
+    rng = np.random.default_rng(7)
+    L, span = 3 * 32768 + 77, 150   # shift 9: 193 ranges, the last one 77 positions wide
+    s, e = _uniform_reads(rng, N_BIG, L, span)
+    s[:5000] = L - span              # pile on the very last start position
+    e[:5000] = L - 1
+    s[5000:9000] = 0
+    e[5000:9000] = span - 1
+    got, passes, sorted_route, _ = _solve_both_routes(solver, s, e, L, 25)
+    assert passes == 1
+    assert np.array_equal(got, sorted_route)
+    assert np.array_equal(got, oracle.solve(s, e, L, 25))
+
+
+def test_multi_contig_ranges_straddle_contig_borders(pkg, oracle, solver):
+    rng = np.random.default_rng(11)
+    lengths = np.array([70_001, 33_333, 250_000, 1_000], np.uint32)
+    counts = np.array([1_500_000, 700_000, 1_994_304 + 12_345, 40_000])
+    span = 120
+    ss, ee = zip(*[_uniform_reads(rng, int(c), int(L), span) for c, L in zip(counts, lengths)])
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    got, passes, sorted_route, _ = _solve_both_routes(solver, s, e, lengths, 60, offs)
+    assert passes == 1 and solver.last_stats.n_contigs == 4
+    assert np.array_equal(got, sorted_route)
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 60, contig_read_offsets=offs))
+
+
+def test_one_heavy_range_falls_back_to_the_sort(pkg, oracle, solver):
+    """a third of the reads start inside one 8 Ki-position range: its ranking would be one wave's
+    walk over 1.4 M records, so the keep mask comes from the radix sort (3 passes), same answer"""
+    rng = np.random.default_rng(13)
+    L, span = 2_000_000, 150
+    s, e = _uniform_reads(rng, N_BIG, L, span)
+    hot = rng.integers(1_000_000, 1_004_000, size=N_BIG // 3, dtype=np.uint32)
+    s[: hot.size] = hot
+    e[: hot.size] = hot + np.uint32(span - 1)
+    got = solver.solve(s, e, L, 30)
+    assert solver.last_stats.sort_passes == 3
+    assert np.array_equal(got, oracle.solve(s, e, L, 30))
+
+
+def test_kept_count_and_validity_match(pkg, oracle, solver):
+    rng = np.random.default_rng(17)
+    L, span, M = 500_000, 151, 100
+    s, e = _uniform_reads(rng, N_BIG, L, span)
+    got = solver.solve(s, e, L, M)
+    assert solver.last_stats.sort_passes == 1
+    bits = np.unpackbits(got.view(np.uint8), bitorder="little")[: s.size]
+    assert int(bits.sum()) == solver.last_stats.n_kept
+    in_cov = solver.coverage(s, e, L)
+    out_cov = solver.coverage(s, e, L, keep_mask=got)
+    assert oracle.is_out_cover_valid(in_cov, out_cov, M)
+    assert np.array_equal(got, oracle.solve(s, e, L, M))
