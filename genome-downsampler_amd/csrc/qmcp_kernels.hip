@@ -1430,28 +1430,42 @@ template <> struct RowVec<2> { typedef uint32_t type __attribute__((ext_vector_t
 template <> struct RowVec<3> { typedef uint32_t type __attribute__((ext_vector_type(3), aligned(4))); };
 template <> struct RowVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
 
+// Split in two so that the select fix-up (which needs the data) can sit a whole stage after the
+// load was issued: row_issue starts the load, row_finish turns it into slot values.
 template <int E>
-__device__ __forceinline__ void row_load(const uint32_t* __restrict__ cb, uint32_t a, uint32_t L,
-                                         uint32_t lane, uint32_t (&X)[E]) {
+struct RowRaw { typename RowVec<E>::type v; uint32_t sh; };
+
+template <int E>
+__device__ __forceinline__ void row_issue(const uint32_t* __restrict__ cb, uint32_t a, uint32_t L,
+                                          uint32_t lane, RowRaw<E>& raw) {
     // branch-free (a load inside a divergent branch makes the compiler drain vmcnt at the join):
-    // the vector is read at a base clamped so that it ends at cb[L] at the latest, and lanes
-    // whose base moved pick their entries with selects: X[r] = v[min(sh + r, E-1)]
+    // the vector is read at a base clamped so that it ends at cb[L] at the latest
     const uint32_t p = a + lane * E;
     const uint32_t pe = min(p, L + 1 - E);  // L >= ell > E always
-    const uint32_t sh = p - pe;
+    raw.sh = p - pe;
+    raw.v = *reinterpret_cast<const typename RowVec<E>::type*>(cb + pe);
+}
+template <int E>
+__device__ __forceinline__ void row_finish(const RowRaw<E>& raw, uint32_t (&X)[E]) {
+    // lanes whose base moved pick their entries with selects: X[r] = v[min(sh + r, E-1)]
     if constexpr (E == 1) {
-        X[0] = cb[pe];
+        X[0] = raw.v;
     } else {
-        typedef typename RowVec<E>::type V;
-        const V v = *reinterpret_cast<const V*>(cb + pe);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            uint32_t x = v[E - 1];
+            uint32_t x = raw.v[E - 1];
 #pragma unroll
-            for (int q = E - 2; q >= r; --q) x = (sh + r <= (uint32_t)q) ? v[q] : x;
+            for (int q = E - 2; q >= r; --q) x = (raw.sh + r <= (uint32_t)q) ? raw.v[q] : x;
             X[r] = x;
         }
     }
+}
+template <int E>
+__device__ __forceinline__ void row_load(const uint32_t* __restrict__ cb, uint32_t a, uint32_t L,
+                                         uint32_t lane, uint32_t (&X)[E]) {
+    RowRaw<E> raw;
+    row_issue<E>(cb, a, L, lane, raw);
+    row_finish<E>(raw, X);
 }
 
 template <int E>
@@ -1475,19 +1489,19 @@ template <int E>
 struct MwLayout {
     static constexpr int kC = 0;            // [E]  inclusive count prefix       PREP -> CHAIN
     static constexpr int kEx = E;           // [E]  ex at the jump landing       PREP -> CHAIN
-    static constexpr int kBefore = 2 * E;   // [1]  counts of lower lanes        PREP -> CHAIN
+    // (word 2E is unused)
     static constexpr int kX0 = 2 * E + 1;   // [E]  bucket offsets               PREP -> CHECK
     static constexpr int kCnt = 3 * E + 1;  // [E]  counts                       PREP -> CHECK
     static constexpr int kDn = 4 * E + 1;   // [E]  distances                    CHAIN -> CHECK
     static constexpr int kHn = 5 * E + 1;   // [E]  h'                           CHAIN -> CHECK
-    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the lane          CHAIN -> CHECK
+    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the block         CHAIN -> CHECK
     static constexpr int kWords = 6 * E + 2;
     static constexpr int kSlots = 3;
     static constexpr size_t kBytes = (size_t)kSlots * 4 * kWords * 64 * sizeof(uint32_t) + 64;
 };
 
 template <int E>
-__global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
+__global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
                                                           const uint64_t* __restrict__ contig_pos_off,
                                                           uint32_t ell, uint32_t M, uint32_t ltot,
                                                           uint32_t* __restrict__ selend,
@@ -1496,7 +1510,12 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
     extern __shared__ uint32_t s_mw[];
     uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * 4 * Ly::kWords * 64;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t role = threadIdx.x >> 6;  // 0 PREP, 1 CHAIN, 2 CHECK
+    // five waves: 0,1 PREP (blocks 0-1 / 2-3 of a group), 2 CHAIN, 3,4 CHECK (blocks 0-1 / 2-3).
+    // Only the chain is serial; the prepare and check work of a group is independent per block, so
+    // it is split over two waves each and the stage time is the chain wave's.
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t role = wv < 2 ? 0u : (wv == 2 ? 1u : 2u);  // 0 PREP, 1 CHAIN, 2 CHECK
+    const uint32_t half = wv < 2 ? wv : wv - 3;               // which pair of blocks (PREP / CHECK)
     const uint32_t c_id = blockIdx.x;
     const uint32_t base = (uint32_t)contig_pos_off[c_id];
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
@@ -1507,7 +1526,7 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
     uint32_t* __restrict__ csel = selend + base;
     const uint32_t trash = ltot - base;
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
-    // all three waves form one serial pipeline: each must win issue arbitration against the
+    // the waves form one serial pipeline: each must win issue arbitration against the
     // streaming kernels that share their SIMDs
     __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) s_flag[0] = 0;
@@ -1533,7 +1552,10 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
     uint32_t g0 = 0;
     __syncthreads();
 
-#define MW_AT(slot, k, w) s_mw[(((slot) * 4 + (k)) * Ly::kWords + (w)) * 64 + lane]
+    // MW_AT: word w of block k of a slot; `slot` is a per-stage base pointer, so k and w fold into
+    // the instruction's immediate offset
+#define MW_SLOT(idx) (s_mw + (size_t)(idx) * 4 * Ly::kWords * 64 + lane)
+#define MW_AT(slot, k, w) (slot)[((k) * Ly::kWords + (w)) * 64]
 
     while (g0 < n_groups) {
         if (penalty > 0) {
@@ -1549,13 +1571,15 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
         // pipeline over groups g0, g0+1, ...: stage t has PREP on g0+t, CHAIN on g0+t-1, CHECK on g0+t-2
         const uint32_t n_left = n_groups - g0;
         uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
-        // PREP keeps a window of six rows (blocks 4g .. 4g+5); the four new rows of the next
-        // stage are loaded at the start of each stage and have a whole stage to land
-        uint32_t W[6][E], Nw[4][E];
+        // a PREP wave keeps the four rows its two blocks need (blocks 4g+2*half .. +3); the rows of
+        // the next stage are loaded at the start of each stage and have a whole stage to land
+        uint32_t W[4][E];
+        RowRaw<E> Nw[4];
         if (role == 0) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) row_load<E>(cb, (g0 * 4 + k) * ell, L, lane, W[k]);
+            for (int k = 0; k < 4; ++k) row_load<E>(cb, (g0 * 4 + 2 * half + k) * ell, L, lane, W[k]);
         }
+        uint32_t sel[2][E];  // CHECK: results of the group checked in this stage, stored after the verdict
         if (role == 1) {
 #pragma unroll
             for (int r = 0; r < E; ++r) { h_prev[r] = h[r]; h_cur[r] = h[r]; }
@@ -1568,13 +1592,15 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
             if (role == 0) {
                 if (t < n_left) {
                     const uint32_t g = g0 + t;
-                    const uint32_t slot = g % Ly::kSlots;
+                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) row_load<E>(cb, (g * 4 + 6 + k) * ell, L, lane, Nw[k]);
+                    for (int k = 0; k < 4; ++k)
+                        row_issue<E>(cb, ((g + 1) * 4 + 2 * half + k) * ell, L, lane, Nw[k]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const uint32_t k = 2 * half + kk;
                         SweepLoads<E> ldk;
-                        rows_to_loads<E>(W[k], W[k + 1], W[k + 2], lane, last_lane, last_r, ldk);
+                        rows_to_loads<E>(W[kk], W[kk + 1], W[kk + 2], lane, last_lane, last_r, ldk);
                         BlockPrep<E> pr;
                         prep_block<E>(ldk, (g * 4 + k) * ell, ell, L, M, lane, pr);
 #pragma unroll
@@ -1584,46 +1610,41 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                             MW_AT(slot, k, Ly::kX0 + r) = pr.x0[r];
                             MW_AT(slot, k, Ly::kCnt + r) = pr.cnt[r];
                         }
-                        MW_AT(slot, k, Ly::kBefore) = pr.before;
                     }
-                    // slide the window by four rows
 #pragma unroll
-                    for (int r = 0; r < E; ++r) {
-                        W[0][r] = W[4][r]; W[1][r] = W[5][r];
-                        W[2][r] = Nw[0][r]; W[3][r] = Nw[1][r]; W[4][r] = Nw[2][r]; W[5][r] = Nw[3][r];
-                    }
+                    for (int k = 0; k < 4; ++k) row_finish<E>(Nw[k], W[k]);
                 }
             } else if (role == 1) {
                 if (t >= 1 && t <= n_left) {
                     const uint32_t g = g0 + t - 1;
-                    const uint32_t slot = g % Ly::kSlots;
+                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
 #pragma unroll
                     for (int r = 0; r < E; ++r) { h_prev[r] = h_cur[r]; h_cur[r] = h[r]; }
                     d_prev = d_cur; d_cur = d_last;
                     // terms of block k+1 are read from LDS before block k's scans start, so their
                     // latency hides under the scans (the compiler will not hoist LDS reads above the
                     // previous block's LDS writes by itself)
-                    uint32_t Cn[E], exn[E], bn;
+                    uint32_t Cn[E], exn[E];
 #pragma unroll
                     for (int r = 0; r < E; ++r) {
                         Cn[r] = MW_AT(slot, 0, Ly::kC + r);
                         exn[r] = MW_AT(slot, 0, Ly::kEx + r);
                     }
-                    bn = MW_AT(slot, 0, Ly::kBefore);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         uint32_t C[E], exj[E];
 #pragma unroll
                         for (int r = 0; r < E; ++r) { C[r] = Cn[r]; exj[r] = exn[r]; }
-                        const uint32_t before = bn;
                         if (k < 3) {
 #pragma unroll
                             for (int r = 0; r < E; ++r) {
                                 Cn[r] = MW_AT(slot, k + 1, Ly::kC + r);
                                 exn[r] = MW_AT(slot, k + 1, Ly::kEx + r);
                             }
-                            bn = MW_AT(slot, k + 1, Ly::kBefore);
                         }
+                        // d entering the block, for the CHECK wave (it derives every lane's entering d
+                        // from the distances itself)
+                        MW_AT(slot, k, Ly::kDin) = d_last;
                         // the two chain scans, interleaved (see sweep_block_fast)
                         int32_t lp[E];
                         int32_t pm = 0x7FFFFFFF;
@@ -1633,7 +1654,6 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                         for (int r = 0; r < E; ++r) { pm = min(pm, (int32_t)h[r] - (int32_t)C[r]); lp[r] = pm; }
 #pragma unroll
                         for (int r = E - 1; r >= 0; --r) { sx[r] = sm; sm = min(sm, h[r]); }
-                        const uint32_t srun = sm;
                         pm = min(pm, QMCP_DPP_IMIN(pm, 0x111, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x101, 0xF));
                         pm = min(pm, QMCP_DPP_IMIN(pm, 0x112, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x102, 0xF));
                         pm = min(pm, QMCP_DPP_IMIN(pm, 0x114, 0xF));  sm = min(sm, QMCP_DPP_UMIN(sm, 0x104, 0xF));
@@ -1650,33 +1670,32 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                             const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
                             sm = min(min(sm, r1 | off1), min(r2 | off2, r3 | off3));
                         }
-                        const int32_t pp = __builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false);
+                        // min(d_last + C, C + min(pp, lp)) = C + min(d_last, pp, lp): d_last joins the prefix
+                        const int32_t pp = min(__builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false),
+                                               (int32_t)d_last);
                         const uint32_t after = QMCP_DPP(0xFFFFFFFFu, sm, 0x130, 0xF);
-                        uint32_t d_in = min(min(d_last + before, (uint32_t)(pp + (int32_t)before)), min(srun, after));
-                        d_in = lane == 0 ? d_last : d_in;
                         uint32_t pick = 0;
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
                             const uint32_t viaP = (uint32_t)((int32_t)C[r] + min(pp, lp[r]));
-                            const uint32_t dnr = min(min(d_last + C[r], viaP), min(sx[r], after));
+                            const uint32_t dnr = min(viaP, min(sx[r], after));
                             const uint32_t hnr = dnr + exj[r];
                             MW_AT(slot, k, Ly::kDn + r) = dnr;
                             MW_AT(slot, k, Ly::kHn + r) = hnr;
                             if ((uint32_t)r == last_r) pick = dnr;
                             h[r] = hnr;
                         }
-                        MW_AT(slot, k, Ly::kDin) = d_in;
                         d_last = __builtin_amdgcn_readlane(pick, last_lane);
                     }
                 }
             } else {
                 if (t >= 2) {
                     const uint32_t g = g0 + t - 2;
-                    const uint32_t slot = g % Ly::kSlots;
-                    uint32_t sel[4][E];
+                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
                     bool undercut = false;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const uint32_t k = 2 * half + kk;
                         uint32_t dn[E], hn[E];
                         uint32_t vm = 0xFFFFFFFFu;
 #pragma unroll
@@ -1692,28 +1711,19 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
                         vm = min(vm, QMCP_DPP_UMIN(vm, 0x142, 0xA));
                         vm = min(vm, QMCP_DPP_UMIN(vm, 0x143, 0xC));
                         uint32_t run = QMCP_DPP(0xFFFFFFFFu, vm, 0x138, 0xF);
-                        uint32_t prev = MW_AT(slot, k, Ly::kDin);
+                        // d entering the lane: the lane below's last distance; lane 0: d entering the block
+                        const uint32_t d_blk = MW_AT(slot, k, Ly::kDin);
+                        uint32_t prev = QMCP_DPP(0u, dn[E - 1], 0x138, 0xF);
+                        prev = lane == 0 ? d_blk : prev;
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
                             undercut |= run < dn[r];
                             run = min(run, hn[r]);
-                            sel[k][r] = MW_AT(slot, k, Ly::kX0 + r) + (MW_AT(slot, k, Ly::kCnt + r) - (dn[r] - prev));
+                            sel[kk][r] = MW_AT(slot, k, Ly::kX0 + r) + (MW_AT(slot, k, Ly::kCnt + r) - (dn[r] - prev));
                             prev = dn[r];
                         }
                     }
-                    if (__any(undercut)) {
-                        if (lane == 0) s_flag[0] = 1;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                            for (int r = 0; r < E; ++r) {
-                                const uint32_t i = lane * E + r;
-                                const uint32_t p = (g * 4 + k) * ell + i;
-                                csel[(i < ell && p < L) ? p : trash] = sel[k][r];
-                            }
-                        }
-                    }
+                    if (__any(undercut) && lane == 0) s_flag[0] = 1;
                 }
             }
 #ifdef QMCP_MW_STAMP
@@ -1722,13 +1732,26 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
             __syncthreads();
             const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
             if (lane == 0 && iter_stats) {
-                atomicAdd(&iter_stats[4 + 2 * role], (uint32_t)((stamp1 - stamp0) >> 4));
-                atomicAdd(&iter_stats[5 + 2 * role], (uint32_t)((stamp2 - stamp1) >> 4));
+                atomicAdd(&iter_stats[4 + 2 * wv], (uint32_t)((stamp1 - stamp0) >> 4));
+                atomicAdd(&iter_stats[5 + 2 * wv], (uint32_t)((stamp2 - stamp1) >> 4));
             }
 #else
             __syncthreads();
 #endif
             if (t >= 2 && s_flag[0] != 0) { failed = g0 + t - 2; break; }
+            // the whole group passed (both CHECK waves): only now do its results reach memory
+            if (role == 2 && t >= 2) {
+                const uint32_t g = g0 + t - 2;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        const uint32_t i = lane * E + r;
+                        const uint32_t p = (g * 4 + 2 * half + kk) * ell + i;
+                        csel[(i < ell && p < L) ? p : trash] = sel[kk][r];
+                    }
+                }
+            }
         }
         if (failed == 0xFFFFFFFFu) { g0 = n_groups; break; }
         // group `failed` needs the general form.  CHAIN was working on failed+1 (or had finished):
@@ -1757,6 +1780,7 @@ __global__ __launch_bounds__(192) void k_sweep_uniform_mw(const uint32_t* __rest
         __syncthreads();
     }
 #undef MW_AT
+#undef MW_SLOT
     if (role == 1) {
         if (n_groups * 4 < n_blocks)
             sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
@@ -2275,7 +2299,7 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
         const size_t lds = MwLayout<EE>::kBytes;                                                        \
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_mw<EE>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(192), lds, st, boff, d_poff,   \
+        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(320), lds, st, boff, d_poff,   \
                            ell, M, ltot, selend, iter_stats);                                           \
     }
     switch (e) {

@@ -48,11 +48,12 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         hipError_t e = hipDeviceSynchronize();
         hipMemcpy(got.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
         hipMemcpy(it2, d_it, 8, hipMemcpyDeviceToHost);
-        uint32_t st[12]; hipMemcpy(st, d_it, 48, hipMemcpyDeviceToHost);
         const double stages = (double)(nb / 4) * reps * contigs;
-        printf("   per stage (x16 cycles -> cycles): prep work %.0f wait %.0f | chain work %.0f wait %.0f | check work %.0f wait %.0f\n",
+        uint32_t st[16]; hipMemcpy(st, d_it, 64, hipMemcpyDeviceToHost);
+        printf("   per stage, cycles (work/wait): prepA %.0f/%.0f prepB %.0f/%.0f | chain %.0f/%.0f | checkA %.0f/%.0f checkB %.0f/%.0f\n",
                16.0 * st[4] / stages, 16.0 * st[5] / stages, 16.0 * st[6] / stages, 16.0 * st[7] / stages,
-               16.0 * st[8] / stages, 16.0 * st[9] / stages);
+               16.0 * st[8] / stages, 16.0 * st[9] / stages, 16.0 * st[10] / stages, 16.0 * st[11] / stages,
+               16.0 * st[12] / stages, 16.0 * st[13] / stages);
         size_t diff = 0, first = 0;
         for (uint64_t i = 0; i < Lt; ++i) if (ref[i] != got[i]) { if (!diff) first = i; ++diff; }
         printf("   three-wave: %s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form %u) mismatches %zu (first at %zu) %s\n",
