@@ -1493,15 +1493,15 @@ struct MwLayout {
     static constexpr int kX0 = 2 * E + 1;   // [E]  bucket offsets               PREP -> CHECK
     static constexpr int kCnt = 3 * E + 1;  // [E]  counts                       PREP -> CHECK
     static constexpr int kDn = 4 * E + 1;   // [E]  distances                    CHAIN -> CHECK
-    static constexpr int kHn = 5 * E + 1;   // [E]  h'                           CHAIN -> CHECK
-    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the block         CHAIN -> CHECK
+    // (words 5E+1 .. 6E are unused: CHECK rebuilds h' = d + ex)
+    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the group (block 0) CHAIN -> CHECK
     static constexpr int kWords = 6 * E + 2;
     static constexpr int kSlots = 3;
     static constexpr size_t kBytes = (size_t)kSlots * 4 * kWords * 64 * sizeof(uint32_t) + 64;
 };
 
 template <int E>
-__global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
+__global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
                                                           const uint64_t* __restrict__ contig_pos_off,
                                                           uint32_t ell, uint32_t M, uint32_t ltot,
                                                           uint32_t* __restrict__ selend,
@@ -1510,12 +1510,15 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
     extern __shared__ uint32_t s_mw[];
     uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * 4 * Ly::kWords * 64;
     const uint32_t lane = threadIdx.x & 63;
-    // five waves: 0,1 PREP (blocks 0-1 / 2-3 of a group), 2 CHAIN, 3,4 CHECK (blocks 0-1 / 2-3).
-    // Only the chain is serial; the prepare and check work of a group is independent per block, so
-    // it is split over two waves each and the stage time is the chain wave's.
+    // Seven waves: 0,1,2,4 PREP (one block of the group each), 3 CHAIN, 5,6 CHECK (blocks 0-1 / 2-3).
+    // Only the chain is serial; the prepare and check work of a group is independent per block.  A
+    // lone wave issues an instruction every 5-8 cycles (lab/issue_lab.hip), so that work is spread
+    // until the stage time is the chain wave's; with waves placed round-robin on the four SIMDs the
+    // chain wave (3) has a SIMD to itself.
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t role = wv < 2 ? 0u : (wv == 2 ? 1u : 2u);  // 0 PREP, 1 CHAIN, 2 CHECK
-    const uint32_t half = wv < 2 ? wv : wv - 3;               // which pair of blocks (PREP / CHECK)
+    const uint32_t role = wv == 3 ? 1u : (wv >= 5 ? 2u : 0u);  // 0 PREP, 1 CHAIN, 2 CHECK
+    const uint32_t pblk = wv == 4 ? 3u : wv;                  // PREP: which block of the group
+    const uint32_t half = wv - 5;                             // CHECK: which pair of blocks
     const uint32_t c_id = blockIdx.x;
     const uint32_t base = (uint32_t)contig_pos_off[c_id];
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
@@ -1550,11 +1553,15 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
     uint32_t n_full = 0;
     uint32_t penalty = 0;
     uint32_t g0 = 0;
+#ifdef QMCP_MW_STAMP
+    unsigned long long stamp_work = 0, stamp_wait = 0;
+#endif
     __syncthreads();
 
     // MW_AT: word w of block k of a slot; `slot` is a per-stage base pointer, so k and w fold into
     // the instruction's immediate offset
-#define MW_SLOT(idx) (s_mw + (size_t)(idx) * 4 * Ly::kWords * 64 + lane)
+#define MW_SLOT0(idx) (s_mw + (size_t)(idx) * 4 * Ly::kWords * 64)
+#define MW_SLOT(idx) (MW_SLOT0(idx) + lane)
 #define MW_AT(slot, k, w) (slot)[((k) * Ly::kWords + (w)) * 64]
 
     while (g0 < n_groups) {
@@ -1571,14 +1578,36 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
         // pipeline over groups g0, g0+1, ...: stage t has PREP on g0+t, CHAIN on g0+t-1, CHECK on g0+t-2
         const uint32_t n_left = n_groups - g0;
         uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
-        // a PREP wave keeps the four rows its two blocks need (blocks 4g+2*half .. +3); the rows of
-        // the next stage are loaded at the start of each stage and have a whole stage to land
-        uint32_t W[4][E];
-        RowRaw<E> Nw[4];
+        // A PREP wave needs three rows for its block (blocks 4g+pblk .. +2).  The rows of stage t+1
+        // are loaded during stage t: issued at its start, turned into slot values at its end.  (Keeping
+        // the raw loads in registers across the loop's back edge makes the allocator copy them,
+        // and a copy waits for the load.)
+        uint32_t W[3][E];
+        RowRaw<E> Nw[3];
         if (role == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) row_load<E>(cb, (g0 * 4 + 2 * half + k) * ell, L, lane, W[k]);
+            for (int k = 0; k < 3; ++k) row_load<E>(cb, (g0 * 4 + pblk + k) * ell, L, lane, W[k]);
         }
+        auto prep_stage = [&](uint32_t g) {
+            uint32_t* const slot = MW_SLOT(g % Ly::kSlots) + pblk * Ly::kWords * 64;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                row_issue<E>(cb, ((g + 1) * 4 + pblk + k) * ell, L, lane, Nw[k]);
+            SweepLoads<E> ldk;
+            rows_to_loads<E>(W[0], W[1], W[2], lane, last_lane, last_r, ldk);
+            BlockPrep<E> pr;
+            prep_block<E>(ldk, (g * 4 + pblk) * ell, ell, L, M, lane, pr);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                MW_AT(slot, 0, Ly::kC + r) = pr.C[r];
+                MW_AT(slot, 0, Ly::kEx + r) = pr.exj[r];
+                MW_AT(slot, 0, Ly::kX0 + r) = pr.x0[r];
+                MW_AT(slot, 0, Ly::kCnt + r) = pr.cnt[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the fix-up (and its wait) at the end of the stage
+#pragma unroll
+            for (int k = 0; k < 3; ++k) row_finish<E>(Nw[k], W[k]);
+        };
         uint32_t sel[2][E];  // CHECK: results of the group checked in this stage, stored after the verdict
         if (role == 1) {
 #pragma unroll
@@ -1590,30 +1619,7 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
             const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
 #endif
             if (role == 0) {
-                if (t < n_left) {
-                    const uint32_t g = g0 + t;
-                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        row_issue<E>(cb, ((g + 1) * 4 + 2 * half + k) * ell, L, lane, Nw[k]);
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const uint32_t k = 2 * half + kk;
-                        SweepLoads<E> ldk;
-                        rows_to_loads<E>(W[kk], W[kk + 1], W[kk + 2], lane, last_lane, last_r, ldk);
-                        BlockPrep<E> pr;
-                        prep_block<E>(ldk, (g * 4 + k) * ell, ell, L, M, lane, pr);
-#pragma unroll
-                        for (int r = 0; r < E; ++r) {
-                            MW_AT(slot, k, Ly::kC + r) = pr.C[r];
-                            MW_AT(slot, k, Ly::kEx + r) = pr.exj[r];
-                            MW_AT(slot, k, Ly::kX0 + r) = pr.x0[r];
-                            MW_AT(slot, k, Ly::kCnt + r) = pr.cnt[r];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) row_finish<E>(Nw[k], W[k]);
-                }
+                if (t < n_left) prep_stage(g0 + t);
             } else if (role == 1) {
                 if (t >= 1 && t <= n_left) {
                     const uint32_t g = g0 + t - 1;
@@ -1624,6 +1630,10 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
                     // terms of block k+1 are read from LDS before block k's scans start, so their
                     // latency hides under the scans (the compiler will not hoist LDS reads above the
                     // previous block's LDS writes by itself)
+                    const uint32_t* const slot0 = MW_SLOT0(g % Ly::kSlots);
+                    // d entering the group, for the CHECK waves (inside a group they read the previous
+                    // block's last distance themselves)
+                    MW_AT(slot, 0, Ly::kDin) = d_last;
                     uint32_t Cn[E], exn[E];
 #pragma unroll
                     for (int r = 0; r < E; ++r) {
@@ -1642,9 +1652,6 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
                                 exn[r] = MW_AT(slot, k + 1, Ly::kEx + r);
                             }
                         }
-                        // d entering the block, for the CHECK wave (it derives every lane's entering d
-                        // from the distances itself)
-                        MW_AT(slot, k, Ly::kDin) = d_last;
                         // the two chain scans, interleaved (see sweep_block_fast)
                         int32_t lp[E];
                         int32_t pm = 0x7FFFFFFF;
@@ -1670,28 +1677,30 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
                             const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
                             sm = min(min(sm, r1 | off1), min(r2 | off2, r3 | off3));
                         }
-                        // min(d_last + C, C + min(pp, lp)) = C + min(d_last, pp, lp): d_last joins the prefix
-                        const int32_t pp = min(__builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false),
-                                               (int32_t)d_last);
+                        // min(d_last + C, C + min(pp, lp)) = C + min(d_last, pp, lp): d_last joins the prefix.
+                        // For the lane's last slot min(pp, lp) is the inclusive scan value itself.
+                        const int32_t dl = (int32_t)d_last;
+                        const int32_t pp = min(__builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)pm, 0x138, 0xF, 0xF, false), dl);
+                        const int32_t pin = min(pm, dl);
                         const uint32_t after = QMCP_DPP(0xFFFFFFFFu, sm, 0x130, 0xF);
-                        uint32_t pick = 0;
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
-                            const uint32_t viaP = (uint32_t)((int32_t)C[r] + min(pp, lp[r]));
-                            const uint32_t dnr = min(viaP, min(sx[r], after));
-                            const uint32_t hnr = dnr + exj[r];
+                            const int32_t pre = r == E - 1 ? pin : min(pp, lp[r]);
+                            const uint32_t viaP = (uint32_t)((int32_t)C[r] + pre);
+                            const uint32_t dnr = r == E - 1 ? min(viaP, after) : min(viaP, min(sx[r], after));
                             MW_AT(slot, k, Ly::kDn + r) = dnr;
-                            MW_AT(slot, k, Ly::kHn + r) = hnr;
-                            if ((uint32_t)r == last_r) pick = dnr;
-                            h[r] = hnr;
+                            h[r] = dnr + exj[r];
                         }
-                        d_last = __builtin_amdgcn_readlane(pick, last_lane);
+                        // the block's last distance, read back as a broadcast: cheaper for a lone wave than
+                        // selecting the slot and v_readlane, and its latency hides under the next scans
+                        d_last = slot0[((k * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
                     }
                 }
             } else {
                 if (t >= 2) {
                     const uint32_t g = g0 + t - 2;
                     uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
+                    const uint32_t* const slot0 = MW_SLOT0(g % Ly::kSlots);
                     bool undercut = false;
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
@@ -1701,7 +1710,7 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
                             dn[r] = MW_AT(slot, k, Ly::kDn + r);
-                            hn[r] = MW_AT(slot, k, Ly::kHn + r);
+                            hn[r] = dn[r] + MW_AT(slot, k, Ly::kEx + r);
                             vm = min(vm, hn[r]);
                         }
                         vm = min(vm, QMCP_DPP_UMIN(vm, 0x111, 0xF));
@@ -1712,7 +1721,8 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
                         vm = min(vm, QMCP_DPP_UMIN(vm, 0x143, 0xC));
                         uint32_t run = QMCP_DPP(0xFFFFFFFFu, vm, 0x138, 0xF);
                         // d entering the lane: the lane below's last distance; lane 0: d entering the block
-                        const uint32_t d_blk = MW_AT(slot, k, Ly::kDin);
+                        const uint32_t d_blk = k == 0 ? MW_AT(slot, 0, Ly::kDin)
+                                                      : slot0[(((k - 1) * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
                         uint32_t prev = QMCP_DPP(0u, dn[E - 1], 0x138, 0xF);
                         prev = lane == 0 ? d_blk : prev;
 #pragma unroll
@@ -1731,10 +1741,8 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
             const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
             const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && iter_stats) {
-                atomicAdd(&iter_stats[4 + 2 * wv], (uint32_t)((stamp1 - stamp0) >> 4));
-                atomicAdd(&iter_stats[5 + 2 * wv], (uint32_t)((stamp2 - stamp1) >> 4));
-            }
+            stamp_work += stamp1 - stamp0;  // summed in registers: per-stage atomics would perturb the run
+            stamp_wait += stamp2 - stamp1;
 #else
             __syncthreads();
 #endif
@@ -1781,6 +1789,13 @@ __global__ __launch_bounds__(320) void k_sweep_uniform_mw(const uint32_t* __rest
     }
 #undef MW_AT
 #undef MW_SLOT
+#undef MW_SLOT0
+#ifdef QMCP_MW_STAMP
+    if (lane == 0 && iter_stats) {
+        atomicAdd(&iter_stats[4 + 2 * wv], (uint32_t)(stamp_work >> 4));
+        atomicAdd(&iter_stats[5 + 2 * wv], (uint32_t)(stamp_wait >> 4));
+    }
+#endif
     if (role == 1) {
         if (n_groups * 4 < n_blocks)
             sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
@@ -2299,7 +2314,7 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
         const size_t lds = MwLayout<EE>::kBytes;                                                        \
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_mw<EE>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(320), lds, st, boff, d_poff,   \
+        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(448), lds, st, boff, d_poff,   \
                            ell, M, ltot, selend, iter_stats);                                           \
     }
     switch (e) {

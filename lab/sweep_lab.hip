@@ -16,11 +16,11 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
     std::vector<uint64_t> poff(contigs + 1);
     for (int c = 0; c <= contigs; ++c) poff[c] = (uint64_t)c * L;
     uint32_t *d_boff, *d_sel, *d_it; uint64_t* d_poff;
-    hipMalloc(&d_boff, (Lt + 1) * 4); hipMalloc(&d_sel, (Lt + 2) * 4); hipMalloc(&d_it, 64);
+    hipMalloc(&d_boff, (Lt + 1) * 4); hipMalloc(&d_sel, (Lt + 2) * 4); hipMalloc(&d_it, 128);
     hipMalloc(&d_poff, (contigs + 1) * 8);
     hipMemcpy(d_boff, boff.data(), (Lt + 1) * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_poff, poff.data(), (contigs + 1) * 8, hipMemcpyHostToDevice);
-    hipMemset(d_it, 0, 64);
+    hipMemset(d_it, 0, 128);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); float best = 1e9;
     const int reps = 5;
     for (int it = 0; it < reps; ++it) {
@@ -37,7 +37,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         std::vector<uint32_t> ref(Lt + 1), got(Lt + 1);
         hipMemcpy(ref.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
         hipMemset(d_sel, 0xEE, (Lt + 1) * 4);
-        hipMemset(d_it, 0, 64);
+        hipMemset(d_it, 0, 128);
         float best2 = 1e9;
         bool ok = true;
         for (int it = 0; it < reps; ++it) {
@@ -49,11 +49,12 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         hipMemcpy(got.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
         hipMemcpy(it2, d_it, 8, hipMemcpyDeviceToHost);
         const double stages = (double)(nb / 4) * reps * contigs;
-        uint32_t st[16]; hipMemcpy(st, d_it, 64, hipMemcpyDeviceToHost);
-        printf("   per stage, cycles (work/wait): prepA %.0f/%.0f prepB %.0f/%.0f | chain %.0f/%.0f | checkA %.0f/%.0f checkB %.0f/%.0f\n",
-               16.0 * st[4] / stages, 16.0 * st[5] / stages, 16.0 * st[6] / stages, 16.0 * st[7] / stages,
-               16.0 * st[8] / stages, 16.0 * st[9] / stages, 16.0 * st[10] / stages, 16.0 * st[11] / stages,
-               16.0 * st[12] / stages, 16.0 * st[13] / stages);
+        uint32_t st[32]; hipMemcpy(st, d_it, 128, hipMemcpyDeviceToHost);
+        printf("   per stage, cycles (work/wait):");
+        const char* names[7] = {"prep0", "prep1", "prep2", "chain", "prep3", "checkA", "checkB"};
+        for (int wv = 0; wv < 7; ++wv)
+            printf(" %s %.0f/%.0f", names[wv], 16.0 * st[4 + 2 * wv] / stages, 16.0 * st[5 + 2 * wv] / stages);
+        printf("\n");
         size_t diff = 0, first = 0;
         for (uint64_t i = 0; i < Lt; ++i) if (ref[i] != got[i]) { if (!diff) first = i; ++diff; }
         printf("   three-wave: %s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form %u) mismatches %zu (first at %zu) %s\n",
