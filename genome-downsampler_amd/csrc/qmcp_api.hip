@@ -289,7 +289,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->hist2, (size_t)256 * tiles * sizeof(uint32_t)));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
-        TRY(ensure(c, c->selend, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
         TRY(ensure(c, c->ranges, 260 * sizeof(uint32_t)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));

@@ -1487,19 +1487,36 @@ __device__ __forceinline__ void rows_to_loads(const uint32_t (&Xa)[E], const uin
 
 template <int E>
 struct MwLayout {
+    static constexpr int kG = 8;            // blocks per group (one pipeline stage)
     static constexpr int kC = 0;            // [E]  inclusive count prefix       PREP -> CHAIN
-    static constexpr int kEx = E;           // [E]  ex at the jump landing       PREP -> CHAIN
-    // (word 2E is unused)
-    static constexpr int kX0 = 2 * E + 1;   // [E]  bucket offsets               PREP -> CHECK
-    static constexpr int kCnt = 3 * E + 1;  // [E]  counts                       PREP -> CHECK
-    static constexpr int kDn = 4 * E + 1;   // [E]  distances                    CHAIN -> CHECK
-    // (words 5E+1 .. 6E are unused: CHECK rebuilds h' = d + ex)
-    static constexpr int kDin = 6 * E + 1;  // [1]  d entering the group (block 0) CHAIN -> CHECK
-    static constexpr int kWords = 6 * E + 2;
+    static constexpr int kEx = E;           // [E]  ex at the jump landing       PREP -> CHAIN, CHECK
+    static constexpr int kX0 = 2 * E;       // [E]  bucket offsets               PREP -> CHECK
+    static constexpr int kCnt = 3 * E;      // [E]  counts                       PREP -> CHECK
+    static constexpr int kDn = 4 * E;       // [E]  distances                    CHAIN -> CHECK
+    static constexpr int kH0 = 5 * E;       // [E]  block 0 only: h entering the group (rollback state)
+    static constexpr int kDin = 6 * E;      // [1]  block 0 only: d entering the group   CHAIN -> CHECK
+    static constexpr int kWords = 6 * E + 1;
     static constexpr int kSlots = 3;
-    static constexpr size_t kBytes = (size_t)kSlots * 4 * kWords * 64 * sizeof(uint32_t) + 64;
+    static constexpr size_t kBytes = (size_t)kSlots * kG * kWords * 64 * sizeof(uint32_t) + 64;
 };
 
+// Pipelined form of the sweep: one workgroup of seven waves per contig.
+//   waves 0,1,2,4  PREP   two blocks of the group each: bucket-offset rows -> counts, prefix, ex
+//   wave  3        CHAIN  the serial part: two min-scans + combine per block (alone on its SIMD:
+//                         waves are placed round-robin on the four SIMDs)
+//   waves 5,6      CHECK  four blocks of the group each: undercut check, selected counts, stores
+// A lone wave issues an instruction every 5-8 cycles (lab/issue_lab.hip), so everything that does
+// not depend on the chain is kept off the chain wave.  Blocks go in groups of kG; stage t has PREP
+// on group g0+t, CHAIN on g0+t-1, CHECK on g0+t-2, one barrier per stage, all hand-offs through
+// three LDS slots.  Results reach memory only after the verdict: every block before the first
+// failed one of a group is exact and is stored.  On a failed check every wave but CHAIN leaves the
+// pipeline right after the barrier; CHAIN, which reads the flag without waiting for it, notices
+// at the end of the stage it has already started, rebuilds the state entering the failed block
+// from LDS (it publishes h and d at every group entry; inside a group the state is the previous
+// block's distances + ex), redoes the rest of that group in the general form, and the pipeline
+// restarts behind it -- warm: what PREP made for the next two groups is still in LDS.  Only when
+// the first group of a run fails again does CHAIN back off to runs of 1, 3, 7 ... 63 groups in the
+// general form (sparse data, where the fast form rarely holds).
 template <int E>
 __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __restrict__ boff,
                                                           const uint64_t* __restrict__ contig_pos_off,
@@ -1507,32 +1524,30 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                                                           uint32_t* __restrict__ selend,
                                                           uint32_t* __restrict__ iter_stats) {
     using Ly = MwLayout<E>;
+    constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
-    uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * 4 * Ly::kWords * 64;
+    uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * kG * Ly::kWords * 64;
     const uint32_t lane = threadIdx.x & 63;
-    // Seven waves: 0,1,2,4 PREP (one block of the group each), 3 CHAIN, 5,6 CHECK (blocks 0-1 / 2-3).
-    // Only the chain is serial; the prepare and check work of a group is independent per block.  A
-    // lone wave issues an instruction every 5-8 cycles (lab/issue_lab.hip), so that work is spread
-    // until the stage time is the chain wave's; with waves placed round-robin on the four SIMDs the
-    // chain wave (3) has a SIMD to itself.
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t role = wv == 3 ? 1u : (wv >= 5 ? 2u : 0u);  // 0 PREP, 1 CHAIN, 2 CHECK
-    const uint32_t pblk = wv == 4 ? 3u : wv;                  // PREP: which block of the group
-    const uint32_t half = wv - 5;                             // CHECK: which pair of blocks
+    const uint32_t pblk = 2 * (wv == 4 ? 3u : wv);            // PREP: first of its two blocks
+    const uint32_t cblk = 4 * (wv - 5);                       // CHECK: first of its four blocks
     const uint32_t c_id = blockIdx.x;
     const uint32_t base = (uint32_t)contig_pos_off[c_id];
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
     if (L == 0) return;
     const uint32_t n_blocks = (L + ell - 1) / ell;
-    const uint32_t n_groups = n_blocks / 4;
+    const uint32_t n_groups = n_blocks / kG;
     const uint32_t* __restrict__ cb = boff + base;
     uint32_t* __restrict__ csel = selend + base;
-    const uint32_t trash = ltot - base;
+    const uint32_t trash = ltot - base;  // E spare words behind the table absorb idle lanes' stores
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
     // the waves form one serial pipeline: each must win issue arbitration against the
-    // streaming kernels that share their SIMDs
+    // streaming kernels that may share their SIMDs
     __builtin_amdgcn_s_setprio(3);
-    if (threadIdx.x == 0) s_flag[0] = 0;
+    // s_flag[0]: first block of the checked group whose check failed (kNoFail: none)
+    constexpr uint32_t kNoFail = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_flag[0] = kNoFail;
 
     // chain state (meaningful in the CHAIN wave only)
     uint32_t h[E];
@@ -1546,94 +1561,96 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
         }
     }
     uint32_t d_last = 0;
-    uint32_t h_prev[E], h_cur[E];  // state at the start of the previous / current chain group
-    uint32_t d_prev = 0, d_cur = 0;
-#pragma unroll
-    for (int r = 0; r < E; ++r) { h_prev[r] = h[r]; h_cur[r] = h[r]; }
     uint32_t n_full = 0;
     uint32_t penalty = 0;
     uint32_t g0 = 0;
+    bool warm = false;  // the PREP data of groups g0 and g0+1 (and the rows of g0+2) survive from the failed run
+    uint32_t W[4][E];   // PREP: rows of the next group it will prepare
 #ifdef QMCP_MW_STAMP
-    unsigned long long stamp_work = 0, stamp_wait = 0;
+    unsigned long long stamp_work = 0, stamp_wait = 0, stamp_fail = 0, stamp_fails = 0, stamp_post = 0, stamp_iters = 0;
+    unsigned long long stamp_prev = 0;
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
 
     // MW_AT: word w of block k of a slot; `slot` is a per-stage base pointer, so k and w fold into
     // the instruction's immediate offset
-#define MW_SLOT0(idx) (s_mw + (size_t)(idx) * 4 * Ly::kWords * 64)
+#define MW_SLOT0(idx) (s_mw + (size_t)(idx) * kG * Ly::kWords * 64)
 #define MW_SLOT(idx) (MW_SLOT0(idx) + lane)
 #define MW_AT(slot, k, w) (slot)[((k) * Ly::kWords + (w)) * 64]
 
     while (g0 < n_groups) {
         if (penalty > 0) {
+            warm = false;
             const uint32_t run = min(penalty, n_groups - g0);
             if (role == 1) {
-                sweep_full_run<E>(cb, g0 * 4, (g0 + run) * 4, trash, ell, L, M, lane, last_lane, last_r,
+                sweep_full_run<E>(cb, g0 * kG, (g0 + run) * kG, trash, ell, L, M, lane, last_lane, last_r,
                                   h, d_last, csel);
-                n_full += run * 4;
+                n_full += run * kG;
             }
             g0 += run;
             if (g0 >= n_groups) break;
         }
-        // pipeline over groups g0, g0+1, ...: stage t has PREP on g0+t, CHAIN on g0+t-1, CHECK on g0+t-2
         const uint32_t n_left = n_groups - g0;
         uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
-        // A PREP wave needs three rows for its block (blocks 4g+pblk .. +2).  The rows of stage t+1
-        // are loaded during stage t: issued at its start, turned into slot values at its end.  (Keeping
-        // the raw loads in registers across the loop's back edge makes the allocator copy them,
+        // A PREP wave needs four rows for its two blocks (blocks kG*g+pblk .. +3).  The rows of stage
+        // t+1 are loaded during stage t: issued at its start, turned into slot values at its end.
+        // (Keeping raw loads in registers across the loop's back edge makes the allocator copy them,
         // and a copy waits for the load.)
-        uint32_t W[3][E];
-        RowRaw<E> Nw[3];
-        if (role == 0) {
+        RowRaw<E> Nw[4];
+        if (role == 0 && !warm) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) row_load<E>(cb, (g0 * 4 + pblk + k) * ell, L, lane, W[k]);
+            for (int k = 0; k < 4; ++k) row_load<E>(cb, (g0 * kG + pblk + k) * ell, L, lane, W[k]);
         }
-        auto prep_stage = [&](uint32_t g) {
-            uint32_t* const slot = MW_SLOT(g % Ly::kSlots) + pblk * Ly::kWords * 64;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                row_issue<E>(cb, ((g + 1) * 4 + pblk + k) * ell, L, lane, Nw[k]);
-            SweepLoads<E> ldk;
-            rows_to_loads<E>(W[0], W[1], W[2], lane, last_lane, last_r, ldk);
-            BlockPrep<E> pr;
-            prep_block<E>(ldk, (g * 4 + pblk) * ell, ell, L, M, lane, pr);
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                MW_AT(slot, 0, Ly::kC + r) = pr.C[r];
-                MW_AT(slot, 0, Ly::kEx + r) = pr.exj[r];
-                MW_AT(slot, 0, Ly::kX0 + r) = pr.x0[r];
-                MW_AT(slot, 0, Ly::kCnt + r) = pr.cnt[r];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the fix-up (and its wait) at the end of the stage
-#pragma unroll
-            for (int k = 0; k < 3; ++k) row_finish<E>(Nw[k], W[k]);
-        };
-        uint32_t sel[2][E];  // CHECK: results of the group checked in this stage, stored after the verdict
-        if (role == 1) {
-#pragma unroll
-            for (int r = 0; r < E; ++r) { h_prev[r] = h[r]; h_cur[r] = h[r]; }
-            d_prev = d_last; d_cur = d_last;
-        }
-        for (uint32_t t = 0; t < n_left + 2; ++t) {
+        uint32_t sel[4][E];   // CHECK: results of the group checked in this stage, stored after the verdict
+        uint32_t flag_seen = kNoFail;  // CHAIN: the flag as read after the previous stage's barrier
+        // A warm run starts one stage in: the chain can take group g0 at once, and PREP resumes
+        // with group g0+2, whose rows it still holds.
+        const uint32_t prep_from = warm ? 2u : 0u;
+        for (uint32_t t = warm ? 1u : 0u; t < n_left + 2; ++t) {
 #ifdef QMCP_MW_STAMP
             const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+            if (stamp_prev != 0) stamp_post += stamp0 - stamp_prev;
+            stamp_iters += 1;
 #endif
             if (role == 0) {
-                if (t < n_left) prep_stage(g0 + t);
+                if (t >= prep_from && t < n_left) {
+                    const uint32_t g = g0 + t;
+                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots) + pblk * Ly::kWords * 64;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        row_issue<E>(cb, ((g + 1) * kG + pblk + k) * ell, L, lane, Nw[k]);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        SweepLoads<E> ldk;
+                        rows_to_loads<E>(W[kk], W[kk + 1], W[kk + 2], lane, last_lane, last_r, ldk);
+                        BlockPrep<E> pr;
+                        prep_block<E>(ldk, (g * kG + pblk + kk) * ell, ell, L, M, lane, pr);
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            MW_AT(slot, kk, Ly::kC + r) = pr.C[r];
+                            MW_AT(slot, kk, Ly::kEx + r) = pr.exj[r];
+                            MW_AT(slot, kk, Ly::kX0 + r) = pr.x0[r];
+                            MW_AT(slot, kk, Ly::kCnt + r) = pr.cnt[r];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the fix-up (and its wait) at the end of the stage
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) row_finish<E>(Nw[k], W[k]);
+                }
             } else if (role == 1) {
                 if (t >= 1 && t <= n_left) {
                     const uint32_t g = g0 + t - 1;
                     uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
+                    const uint32_t* const slot0 = MW_SLOT0(g % Ly::kSlots);
+                    // state entering the group: d for the CHECK waves (inside a group they read the
+                    // previous block's last distance themselves), h and d for a rollback
+                    MW_AT(slot, 0, Ly::kDin) = d_last;
 #pragma unroll
-                    for (int r = 0; r < E; ++r) { h_prev[r] = h_cur[r]; h_cur[r] = h[r]; }
-                    d_prev = d_cur; d_cur = d_last;
+                    for (int r = 0; r < E; ++r) MW_AT(slot, 0, Ly::kH0 + r) = h[r];
                     // terms of block k+1 are read from LDS before block k's scans start, so their
                     // latency hides under the scans (the compiler will not hoist LDS reads above the
                     // previous block's LDS writes by itself)
-                    const uint32_t* const slot0 = MW_SLOT0(g % Ly::kSlots);
-                    // d entering the group, for the CHECK waves (inside a group they read the previous
-                    // block's last distance themselves)
-                    MW_AT(slot, 0, Ly::kDin) = d_last;
                     uint32_t Cn[E], exn[E];
 #pragma unroll
                     for (int r = 0; r < E; ++r) {
@@ -1641,11 +1658,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                         exn[r] = MW_AT(slot, 0, Ly::kEx + r);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < kG; ++k) {
                         uint32_t C[E], exj[E];
 #pragma unroll
                         for (int r = 0; r < E; ++r) { C[r] = Cn[r]; exj[r] = exn[r]; }
-                        if (k < 3) {
+                        if (k + 1 < kG) {
 #pragma unroll
                             for (int r = 0; r < E; ++r) {
                                 Cn[r] = MW_AT(slot, k + 1, Ly::kC + r);
@@ -1696,15 +1713,19 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                         d_last = slot0[((k * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
                     }
                 }
+                // the flag raised for group g0+t-3 (read after the previous barrier) is looked at only
+                // now, so the chain never waits for it
+                if (flag_seen != kNoFail) { failed = g0 + t - 3; break; }
             } else {
                 if (t >= 2) {
                     const uint32_t g = g0 + t - 2;
                     uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
                     const uint32_t* const slot0 = MW_SLOT0(g % Ly::kSlots);
-                    bool undercut = false;
+                    uint32_t first_bad = kNoFail;
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const uint32_t k = 2 * half + kk;
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const uint32_t k = cblk + kk;
+                        bool undercut = false;
                         uint32_t dn[E], hn[E];
                         uint32_t vm = 0xFFFFFFFFu;
 #pragma unroll
@@ -1732,60 +1753,104 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                             sel[kk][r] = MW_AT(slot, k, Ly::kX0 + r) + (MW_AT(slot, k, Ly::kCnt + r) - (dn[r] - prev));
                             prev = dn[r];
                         }
+                        if (__any(undercut)) first_bad = min(first_bad, k);
                     }
-                    if (__any(undercut) && lane == 0) s_flag[0] = 1;
+                    if (first_bad != kNoFail && lane == 0) atomicMin(&s_flag[0], first_bad);
                 }
             }
 #ifdef QMCP_MW_STAMP
-            // diagnostic build only: cycles each role spends working vs waiting at the barrier
+            // diagnostic build only: cycles each wave spends working vs waiting at the barrier
             const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
             const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
             stamp_work += stamp1 - stamp0;  // summed in registers: per-stage atomics would perturb the run
             stamp_wait += stamp2 - stamp1;
+            stamp_prev = stamp2;
 #else
             __syncthreads();
 #endif
-            if (t >= 2 && s_flag[0] != 0) { failed = g0 + t - 2; break; }
-            // the whole group passed (both CHECK waves): only now do its results reach memory
-            if (role == 2 && t >= 2) {
-                const uint32_t g = g0 + t - 2;
+            if (role == 1) {
+                flag_seen = t >= 2 ? s_flag[0] : kNoFail;  // not waited for here
+            } else {
+                const uint32_t bad = t >= 2 ? s_flag[0] : kNoFail;
+                // only now do results reach memory: every block before the first failed one is exact
+                // (its check passed and so did those of all blocks before it)
+                if (role == 2 && t >= 2) {
+                    const uint32_t g = g0 + t - 2;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (cblk + kk < bad) {
+                            // one contiguous vector store per lane (its E slots are adjacent positions);
+                            // lanes without E valid slots write the spare words behind the table
+                            const uint32_t blk_first = (g * kG + cblk + kk) * ell;
+                            const uint32_t p0 = blk_first + lane * E;
+                            const bool full = lane * E + E <= ell && p0 + E <= L;
+                            if constexpr (E == 1) {
+                                csel[full ? p0 : trash] = sel[kk][0];
+                            } else {
+                                typedef typename RowVec<E>::type V;
+                                V v;
 #pragma unroll
-                    for (int r = 0; r < E; ++r) {
-                        const uint32_t i = lane * E + r;
-                        const uint32_t p = (g * 4 + 2 * half + kk) * ell + i;
-                        csel[(i < ell && p < L) ? p : trash] = sel[kk][r];
+                                for (int r = 0; r < E; ++r) v[r] = sel[kk][r];
+                                *reinterpret_cast<V*>(csel + (full ? p0 : trash)) = v;
+                                // a lane with only some valid slots exists only if E does not divide the
+                                // span or the block is cut by the contig's end (uniform test)
+                                if (ell % E != 0 || blk_first + ell > L) {
+#pragma unroll
+                                    for (int r = 0; r < E; ++r) {
+                                        const uint32_t i = lane * E + r;
+                                        if (!full && i < ell && blk_first + i < L) csel[blk_first + i] = sel[kk][r];
+                                    }
+                                }
+                            }
+                        }
                     }
                 }
+                if (bad != kNoFail) { failed = g0 + t - 2; break; }
             }
         }
-        if (failed == 0xFFFFFFFFu) { g0 = n_groups; break; }
-        // group `failed` needs the general form.  CHAIN was working on failed+1 (or had finished):
-        // its state at the start of `failed` is h_prev when it had moved on to failed+1, else h_cur
+#ifdef QMCP_MW_STAMP
+        const unsigned long long stamp_f0 = __builtin_amdgcn_s_memtime();
+        stamp_prev = 0;
+#endif
+        // CHAIN leaves the loop one stage late (or at its end): the last flag it read is still unseen
+        if (role == 1 && failed == 0xFFFFFFFFu && flag_seen != kNoFail) failed = g0 + n_left - 1;
+        // every wave must agree on whether the pipeline failed: the flag itself says so
+        __syncthreads();
+        const uint32_t bad_blk = s_flag[0];
+        if (bad_blk == kNoFail) { g0 = n_groups; break; }
         __syncthreads();  // everyone has read the flag
-        if (threadIdx.x == 0) s_flag[0] = 0;
+        if (threadIdx.x == 0) s_flag[0] = kNoFail;
         if (role == 1) {
-            const bool moved_on = (failed + 1 < n_groups) && (failed + 1 - g0 + 1 <= n_left);
-            // CHAIN solved group (g0 + t - 1) at the failing stage t = failed - g0 + 2, i.e. failed + 1,
-            // provided that group exists in this pipeline
-            if (moved_on) {
+            // state on entering the failed block: published at the group's entry, or rebuilt from the
+            // (exact) distances of the block before it
+            uint32_t* const slot = MW_SLOT(failed % Ly::kSlots);
+            if (bad_blk == 0) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) h[r] = h_prev[r];
-                d_last = d_prev;
+                for (int r = 0; r < E; ++r) h[r] = MW_AT(slot, 0, Ly::kH0 + r);
+                d_last = MW_AT(slot, 0, Ly::kDin);
             } else {
+                uint32_t* const blk = slot + (bad_blk - 1) * Ly::kWords * 64;
 #pragma unroll
-                for (int r = 0; r < E; ++r) h[r] = h_cur[r];
-                d_last = d_cur;
+                for (int r = 0; r < E; ++r) h[r] = MW_AT(blk, 0, Ly::kDn + r) + MW_AT(blk, 0, Ly::kEx + r);
+                d_last = MW_SLOT0(failed % Ly::kSlots)[(((bad_blk - 1) * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
             }
-            sweep_full_run<E>(cb, failed * 4, failed * 4 + 4, trash, ell, L, M, lane, last_lane, last_r, h,
-                              d_last, csel);
-            n_full += 4;
+            sweep_full_run<E>(cb, failed * kG + bad_blk, failed * kG + kG, trash, ell, L, M, lane, last_lane,
+                              last_r, h, d_last, csel);
+            n_full += kG - bad_blk;
         }
-        penalty = failed > g0 ? 1u : min(2 * penalty + 1, 63u);
+        // `failed` is known to every wave: CHAIN derived the same group one stage later.
+        // An isolated failure (the usual case on deep data) costs only the rest of the failed group:
+        // what PREP made for the two groups after it is still in LDS, so the next run starts warm.
+        // A failure of the very first group of a run means the fast form keeps failing here: back off.
+        penalty = failed > g0 ? 0u : min(2 * penalty + 1, 63u);
+        warm = penalty == 0;
         g0 = failed + 1;
         __syncthreads();
+#ifdef QMCP_MW_STAMP
+        stamp_fail += __builtin_amdgcn_s_memtime() - stamp_f0;
+        stamp_fails += 1;
+#endif
     }
 #undef MW_AT
 #undef MW_SLOT
@@ -1794,11 +1859,18 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
     if (lane == 0 && iter_stats) {
         atomicAdd(&iter_stats[4 + 2 * wv], (uint32_t)(stamp_work >> 4));
         atomicAdd(&iter_stats[5 + 2 * wv], (uint32_t)(stamp_wait >> 4));
+        if (wv == 3) {
+            atomicAdd(&iter_stats[20], (uint32_t)(stamp_fail >> 4));
+            atomicAdd(&iter_stats[21], (uint32_t)stamp_fails);
+            atomicAdd(&iter_stats[22], (uint32_t)((__builtin_amdgcn_s_memtime() - stamp_begin) >> 4));
+            atomicAdd(&iter_stats[23], (uint32_t)(stamp_post >> 4));
+            atomicAdd(&iter_stats[24], (uint32_t)stamp_iters);
+        }
     }
 #endif
     if (role == 1) {
-        if (n_groups * 4 < n_blocks)
-            sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
+        if (n_groups * kG < n_blocks)
+            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
                               csel);
         if (iter_stats && lane == 0) {
             atomicAdd(&iter_stats[0], n_full);
