@@ -1528,7 +1528,9 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
     extern __shared__ uint32_t s_mw[];
     uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * kG * Ly::kWords * 64;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wv = threadIdx.x >> 6;
+    // wave-uniform in the compiler's eyes too: role branches are scalar branches, so the PREP
+    // waves can run their own copy of the stage loop
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t role = wv == 3 ? 1u : (wv >= 5 ? 2u : 0u);  // 0 PREP, 1 CHAIN, 2 CHECK
     const uint32_t pblk = 2 * (wv == 4 ? 3u : wv);            // PREP: first of its two blocks
     const uint32_t cblk = 4 * (wv - 5);                       // CHECK: first of its four blocks
@@ -1564,8 +1566,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
     uint32_t n_full = 0;
     uint32_t penalty = 0;
     uint32_t g0 = 0;
-    bool warm = false;  // the PREP data of groups g0 and g0+1 (and the rows of g0+2) survive from the failed run
-    uint32_t W[4][E];   // PREP: rows of the next group it will prepare
+    bool warm = false;  // the PREP data of groups g0 and g0+1 survive from the failed run
 #ifdef QMCP_MW_STAMP
     unsigned long long stamp_work = 0, stamp_wait = 0, stamp_fail = 0, stamp_fails = 0, stamp_post = 0, stamp_iters = 0;
     unsigned long long stamp_prev = 0;
@@ -1593,37 +1594,60 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
         }
         const uint32_t n_left = n_groups - g0;
         uint32_t failed = 0xFFFFFFFFu;  // group whose check failed
-        // A PREP wave needs four rows for its two blocks (blocks kG*g+pblk .. +3).  The rows of stage
-        // t+1 are loaded during stage t: issued at its start, turned into slot values at its end.
-        // (Keeping raw loads in registers across the loop's back edge makes the allocator copy them,
-        // and a copy waits for the load.)
-        RowRaw<E> Nw[4];
-        if (role == 0 && !warm) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) row_load<E>(cb, (g0 * kG + pblk + k) * ell, L, lane, W[k]);
-        }
         uint32_t sel[4][E];   // CHECK: results of the group checked in this stage, stored after the verdict
         uint32_t flag_seen = kNoFail;  // CHAIN: the flag as read after the previous stage's barrier
         // A warm run starts one stage in: the chain can take group g0 at once, and PREP resumes
-        // with group g0+2, whose rows it still holds.
+        // with group g0+2.
         const uint32_t prep_from = warm ? 2u : 0u;
-        for (uint32_t t = warm ? 1u : 0u; t < n_left + 2; ++t) {
+        const uint32_t t_begin = warm ? 1u : 0u;
 #ifdef QMCP_MW_STAMP
-            const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
-            if (stamp_prev != 0) stamp_post += stamp0 - stamp_prev;
-            stamp_iters += 1;
+#define MW_STAGE_BEGIN()                                                  \
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();       \
+    if (stamp_prev != 0) stamp_post += stamp0 - stamp_prev;               \
+    stamp_iters += 1;
+#define MW_STAGE_BARRIER()                                                \
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();       \
+    __syncthreads();                                                      \
+    const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();       \
+    stamp_work += stamp1 - stamp0;                                        \
+    stamp_wait += stamp2 - stamp1;                                        \
+    stamp_prev = stamp2;
+#else
+#define MW_STAGE_BEGIN()
+#define MW_STAGE_BARRIER() __syncthreads();
 #endif
-            if (role == 0) {
-                if (t >= prep_from && t < n_left) {
-                    const uint32_t g = g0 + t;
-                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots) + pblk * Ly::kWords * 64;
+        if (role == 0) {
+            // PREP waves run their own copy of the stage loop (same barriers, same exits), unrolled
+            // kD times: a wave needs four rows for its two blocks (blocks kG*g+pblk .. +3), and loads
+            // them kD stages ahead into kD register sets that take turns in a FIXED order in the
+            // instruction stream -- so the compiler waits for exactly the oldest set (a counted
+            // s_waitcnt) and a row has kD whole stages to land.  Memory latency beside a
+            // bandwidth-bound kernel is several microseconds; one stage is about one.
+            constexpr uint32_t kD = 3;
+            RowRaw<E> R0[4], R1[4], R2[4];
+            auto issue_rows = [&](RowRaw<E> (&buf)[4], uint32_t g) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        row_issue<E>(cb, ((g + 1) * kG + pblk + k) * ell, L, lane, Nw[k]);
+                for (int k = 0; k < 4; ++k) row_issue<E>(cb, (g * kG + pblk + k) * ell, L, lane, buf[k]);
+            };
+            issue_rows(R0, g0 + t_begin);
+            issue_rows(R1, g0 + t_begin + 1);
+            issue_rows(R2, g0 + t_begin + 2);
+            // one stage with register set `buf` (which holds the rows of group g0+t); false: run over
+            auto pstage = [&](RowRaw<E> (&buf)[4], uint32_t t) -> bool {
+                MW_STAGE_BEGIN()
+                const uint32_t g = g0 + t;
+                if (t >= prep_from && t < n_left) {
+                    uint32_t* const slot = MW_SLOT(g % Ly::kSlots) + pblk * Ly::kWords * 64;
+                    uint32_t Wr[4][E];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) row_finish<E>(buf[k], Wr[k]);
+                    __builtin_amdgcn_sched_barrier(0);  // rows consumed before the set is reloaded
+                    issue_rows(buf, g + kD);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
                         SweepLoads<E> ldk;
-                        rows_to_loads<E>(W[kk], W[kk + 1], W[kk + 2], lane, last_lane, last_r, ldk);
+                        rows_to_loads<E>(Wr[kk], Wr[kk + 1], Wr[kk + 2], lane, last_lane, last_r, ldk);
                         BlockPrep<E> pr;
                         prep_block<E>(ldk, (g * kG + pblk + kk) * ell, ell, L, M, lane, pr);
 #pragma unroll
@@ -1634,11 +1658,23 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                             MW_AT(slot, kk, Ly::kCnt + r) = pr.cnt[r];
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the fix-up (and its wait) at the end of the stage
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) row_finish<E>(Nw[k], W[k]);
+                } else if (t < n_left) {
+                    issue_rows(buf, g + kD);  // a warm run's first stage: the group exists already, the set moves on
                 }
-            } else if (role == 1) {
+                MW_STAGE_BARRIER()
+                const uint32_t bad = t >= 2 ? s_flag[0] : kNoFail;
+                if (bad != kNoFail) { failed = g0 + t - 2; return false; }
+                return true;
+            };
+            for (uint32_t t = t_begin;; t += kD) {
+                if (t >= n_left + 2 || !pstage(R0, t)) break;
+                if (t + 1 >= n_left + 2 || !pstage(R1, t + 1)) break;
+                if (t + 2 >= n_left + 2 || !pstage(R2, t + 2)) break;
+            }
+        } else
+        for (uint32_t t = t_begin; t < n_left + 2; ++t) {
+            MW_STAGE_BEGIN()
+            if (role == 1) {
                 if (t >= 1 && t <= n_left) {
                     const uint32_t g = g0 + t - 1;
                     uint32_t* const slot = MW_SLOT(g % Ly::kSlots);
@@ -1758,17 +1794,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                     if (first_bad != kNoFail && lane == 0) atomicMin(&s_flag[0], first_bad);
                 }
             }
-#ifdef QMCP_MW_STAMP
-            // diagnostic build only: cycles each wave spends working vs waiting at the barrier
-            const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
-            const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
-            stamp_work += stamp1 - stamp0;  // summed in registers: per-stage atomics would perturb the run
-            stamp_wait += stamp2 - stamp1;
-            stamp_prev = stamp2;
-#else
-            __syncthreads();
-#endif
+            MW_STAGE_BARRIER()  // (diagnostic builds: stamps around it, summed in registers)
             if (role == 1) {
                 flag_seen = t >= 2 ? s_flag[0] : kNoFail;  // not waited for here
             } else {
@@ -1855,6 +1881,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
 #undef MW_AT
 #undef MW_SLOT
 #undef MW_SLOT0
+#undef MW_STAGE_BEGIN
+#undef MW_STAGE_BARRIER
 #ifdef QMCP_MW_STAMP
     if (lane == 0 && iter_stats) {
         atomicAdd(&iter_stats[4 + 2 * wv], (uint32_t)(stamp_work >> 4));
