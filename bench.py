@@ -176,7 +176,7 @@ def main():
         dom_name, (dom_launches, dom_ms) = max(ktimes.items(), key=lambda kv: kv[1][1])
         dom_avg_ms = dom_ms / dom_launches
         achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9
-        dev_ms = float(st.ms_total)  # HIP events around the whole solve (kernels overlap on two streams)
+        dev_ms = float(st.ms_total)  # HIP events around the whole solve
         traffic = None
         try:
             pmc = json.load(open(PMC_TRAFFIC_FILE.format(workload=args.workload)))

@@ -55,7 +55,7 @@ struct qmcp_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t ev_in = nullptr;
-    hipStream_t stream2 = nullptr;  // counting + sweep run here, beside the radix passes
+    hipStream_t stream2 = nullptr;  // side stream: small read-backs beside the work queued on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // arena (grow-only, reused across solves like a reference solver instance's members)
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;

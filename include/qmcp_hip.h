@@ -76,7 +76,8 @@ typedef struct qmcp_hip_stats {
     uint32_t path;            /* QMCP_PATH_*                                                      */
     uint32_t min_span;        /* min / max of (end - start + 1) over the call                     */
     uint32_t max_span;
-    uint32_t sort_passes;     /* radix passes used by the bucketing stage                         */
+    uint32_t sort_passes;     /* radix passes of the bucketing stage (1 = one range partition,    */
+                              /* the large uniform-span route; >= 2 = LSD radix sort)             */
     uint32_t reserved0;
     float ms_total;           /* device time of the whole solve (HIP events on the solver stream) */
     float ms_prepare;         /* validate + span reduction + per-position start/end counts        */
