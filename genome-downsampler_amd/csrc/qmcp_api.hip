@@ -384,9 +384,9 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         }
         HIP_TRY(hipEventRecord(c->ev_fork, s1));
         {
-            KernelSpan sp(c, "k_radix_scatter_rec");
-            qmcp::launch_radix_scatter_rec(s1, true, d_key32, nullptr, n, range_shift,
-                                           (const uint32_t*)c->hist2.p, c->keys[0].p);
+            KernelSpan sp(c, "k_range_partition");
+            qmcp::launch_range_partition(s1, d_key32, n, range_shift, (const uint32_t*)c->hist2.p,
+                                         c->keys[0].p);
         }
         {
             KernelSpan sp(c, "k_range_count");

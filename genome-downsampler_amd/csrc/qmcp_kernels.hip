@@ -544,6 +544,110 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
 // 8 + 8 B/read for the partition instead of three radix passes (3 x 24 B/read) plus k_mark.
 static constexpr uint32_t kMaxRangeShift = 15;  // 32 Ki positions x 4 B = 128 KiB of LDS
 
+// The range partition itself: the stable scatter of k_radix_scatter_rec<true, false>, but a
+// workgroup of 16 waves stages FOUR consecutive 4096-read tiles (16 Ki records, 128 KiB of LDS)
+// before writing: a range then leaves as one run of ~64 records (512 B) instead of four runs of
+// ~16 (128 B, unaligned), which cuts the partial-line writes that made the scatter move 1.7 x its
+// bytes.  The per-4096-tile histogram of k_prepare and its scan are used as they are: for a fixed
+// range the four tiles' runs are adjacent, so the big tile starts at its first tile's offset.
+static constexpr int kPartTiles = 4;                          // 4096-read tiles per workgroup pass
+static constexpr int kPartRecs = kPartTiles * kSortTile;      // 16384
+static constexpr int kPartThreads = 1024;
+static constexpr size_t kPartLds = (size_t)kPartRecs * sizeof(Rec) + 16 * 256 * sizeof(uint32_t) +
+                                   256 * sizeof(uint32_t) + 64;
+
+__global__ __launch_bounds__(kPartThreads) void k_range_partition(
+    const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_tiles,
+    const uint32_t* __restrict__ offs, Rec* __restrict__ out) {
+    extern __shared__ uint32_t s_part[];
+    Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
+    uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [16][256]
+    uint32_t* s_gbase = s_cnt + 16 * 256;                              // [256]
+    uint32_t* s_wave = s_gbase + 256;                                  // [4]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t tile0 = blockIdx.x * kPartTiles;                    // first 4096-tile of this pass
+    const uint32_t base = tile0 * kSortTile;
+    const uint32_t count = min((uint32_t)kPartRecs, n - base);
+    for (int i = threadIdx.x; i < 16 * 256; i += kPartThreads) s_cnt[i] = 0;
+    __syncthreads();
+    // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
+    // range = (wave, round, lane) = read-index order
+    const uint32_t wbase = base + w * (kSortItems * 64);
+    Rec rec[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        rec[k].key = i < n ? keys[i] : 0u;
+        rec[k].val = i;
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = (rec[k].key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t in_group = __popcll(peers & lt_mask);
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = s_cnt[w * 256 + d];
+            s_cnt[w * 256 + d] = old + __popcll(peers);
+        }
+        old = (uint32_t)__shfl((int)old, leader, kWave);
+        rank[k] = old + in_group;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        // range d = threadIdx.x: where each wave's records of the range go inside the pass, and the
+        // global base of the range's run
+        const uint32_t d = threadIdx.x;
+        uint32_t c[16], tot = 0;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { c[x] = s_cnt[x * 256 + d]; tot += c[x]; }
+        // exclusive scan of the 256 range totals over four waves
+        const uint32_t inc = wave_incl_scan_add(tot);
+        if (lane == 63) s_wave[w] = inc;
+        s_gbase[d] = inc - tot;  // exclusive inside the wave; completed after the barrier
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const uint32_t d = threadIdx.x;
+        uint32_t wave_base = 0;
+        for (int x = 0; x < w; ++x) wave_base += s_wave[x];
+        const uint32_t tile_off = s_gbase[d] + wave_base;
+        uint32_t run = tile_off;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
+        s_gbase[d] = offs[d * n_tiles + tile0] - tile_off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (rec[k].key >> shift) & 255u;
+            s_rec[s_cnt[w * 256 + d] + rank[k]] = rec[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t j = k * kPartThreads + threadIdx.x;
+        if (j < count) {
+            const Rec r = s_rec[j];
+            out[s_gbase[(r.key >> shift) & 255u] + j] = r;
+        }
+    }
+}
+
 // starts of the ranges in partitioned order (257 entries) and the heaviest range's load
 __global__ __launch_bounds__(256) void k_range_table(const uint32_t* __restrict__ scanned_hist,
                                                      uint32_t n_tiles, uint32_t n,
@@ -2593,6 +2697,15 @@ uint32_t range_shift_for(uint32_t ltot) {
 }
 bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxRangeShift; }
 
+void launch_range_partition(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t shift,
+                            const uint32_t* offs, void* recs_out) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    (void)hipFuncSetAttribute((const void*)k_range_partition, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kPartLds);
+    hipLaunchKernelGGL(k_range_partition, dim3((n_tiles + kPartTiles - 1) / kPartTiles), dim3(kPartThreads),
+                       kPartLds, st, keys, n, shift, n_tiles, offs, (Rec*)recs_out);
+}
 void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
                         uint32_t* range_start, uint32_t* max_load) {
     hipLaunchKernelGGL(k_range_table, dim3(1), dim3(256), 0, st, scanned_hist, sort_tiles(n), n,
