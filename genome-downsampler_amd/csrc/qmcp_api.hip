@@ -389,14 +389,10 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                                          c->keys[0].p);
         }
         {
-            KernelSpan sp(c, "k_range_count");
-            qmcp::launch_range_count(s1, c->keys[0].p, d_range_start, range_shift, ltot,
-                                     (uint32_t*)c->cstart.p);
-        }
-        {
-            KernelSpan sp(c, "scan_positions(3 kernels)");
-            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->cstart.p, ltot, (uint32_t*)c->boff.p,
-                                        (uint32_t*)c->spine2.p, true);
+            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
+            KernelSpan sp(c, "k_range_offsets");
+            qmcp::launch_range_offsets(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+                                       (uint32_t*)c->boff.p);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));

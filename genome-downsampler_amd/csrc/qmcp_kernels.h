@@ -89,8 +89,8 @@ void launch_range_partition(hipStream_t st, const uint32_t* keys, uint32_t n, ui
                             const uint32_t* offs, void* recs_out);
 void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
                         uint32_t* range_start, uint32_t* max_load);
-void launch_range_count(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                        uint32_t ltot, uint32_t* cstart);
+void launch_range_offsets(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                          uint32_t ltot, uint32_t* boff);
 void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
                       uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
                       unsigned long long* mask, unsigned long long* kept_total);

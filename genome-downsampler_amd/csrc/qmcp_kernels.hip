@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
 // range (digit = gstart >> shift, <= 256 ranges of <= 32 Ki positions, the first pass of the
 // record radix with a different shift) groups the reads of a range together IN INDEX ORDER;
 // per range an LDS array then gives
-//   k_range_count : reads per position (LDS histogram, coalesced store), and
+//   k_range_offsets: reads per position (LDS histogram) scanned into bucket offsets, and
 //   k_rank_mark   : the kept reads, by walking the range's records in order against a
 //                   per-position quota that starts at S(p).
 // 8 + 8 B/read for the partition instead of three radix passes (3 x 24 B/read) plus k_mark.
@@ -665,13 +665,17 @@ __global__ __launch_bounds__(256) void k_range_table(const uint32_t* __restrict_
     if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-__global__ __launch_bounds__(1024) void k_range_count(const Rec* __restrict__ recs,
-                                                      const uint32_t* __restrict__ range_start,
-                                                      uint32_t shift, uint32_t ltot,
-                                                      uint32_t* __restrict__ cstart) {
-    extern __shared__ uint32_t s_cnt32[];  // [1 << shift]
+__global__ __launch_bounds__(1024) void k_range_offsets(const Rec* __restrict__ recs,
+                                                        const uint32_t* __restrict__ range_start,
+                                                        uint32_t shift, uint32_t ltot,
+                                                        uint32_t* __restrict__ boff) {
+    // [1 << shift] counters, one pad word after every 32: a thread's 32 consecutive positions then
+    // sit in 32 different banks during the scan
+    extern __shared__ uint32_t s_cnt32[];
+#define PADDED(i) ((i) + ((i) >> 5))
+    __shared__ uint32_t s_wsum[16];
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
-    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[i] = 0;
+    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[PADDED(i)] = 0;
     __syncthreads();
     const uint32_t lo = range_start[range], hi = range_start[range + 1];
     // eight loads in flight per thread: the range's records stream in at L2 speed instead of one
@@ -683,12 +687,34 @@ __global__ __launch_bounds__(1024) void k_range_count(const Rec* __restrict__ re
 #pragma unroll
         for (int u = 0; u < U; ++u) k[u] = recs[j + u * 1024u].key;
 #pragma unroll
-        for (int u = 0; u < U; ++u) atomicAdd(&s_cnt32[k[u] - pos0], 1u);
+        for (int u = 0; u < U; ++u) atomicAdd(&s_cnt32[PADDED(k[u] - pos0)], 1u);
     }
-    for (; j < hi; j += 1024u) atomicAdd(&s_cnt32[recs[j].key - pos0], 1u);
+    for (; j < hi; j += 1024u) atomicAdd(&s_cnt32[PADDED(recs[j].key - pos0)], 1u);
+    __syncthreads();
+    // counts -> bucket offsets, in place: exclusive scan over the range's positions, started at
+    // the number of records in all lower ranges (= the offset of the range's first position), so
+    // the array needs no separate scan pass over the whole genome
+    const uint32_t per = width >= 1024u ? width >> 10 : 1u;  // positions per thread
+    const uint32_t first = threadIdx.x * per;
+    uint32_t sum = 0;
+    if (first < width)
+        for (uint32_t q = 0; q < per; ++q) sum += s_cnt32[PADDED(first + q)];
+    const uint32_t inc = wave_incl_scan_add(sum);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = lo + inc - sum;
+    for (uint32_t x = 0; x < w; ++x) run += s_wsum[x];
+    if (first < width)
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t cq = s_cnt32[PADDED(first + q)];
+            s_cnt32[PADDED(first + q)] = run;
+            run += cq;
+        }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < width; i += blockDim.x)
-        if (pos0 + i <= ltot) cstart[pos0 + i] = s_cnt32[i];
+        if (pos0 + i <= ltot) boff[pos0 + i] = s_cnt32[PADDED(i)];
+#undef PADDED
 }
 
 // One workgroup (16 waves) per range.  The quota array starts at q[p] = S(p) = selend - boff.
@@ -2711,14 +2737,14 @@ void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n
     hipLaunchKernelGGL(k_range_table, dim3(1), dim3(256), 0, st, scanned_hist, sort_tiles(n), n,
                        range_start, max_load);
 }
-void launch_range_count(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                        uint32_t ltot, uint32_t* cstart) {
+void launch_range_offsets(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
+                          uint32_t ltot, uint32_t* boff) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
-    const size_t lds = ((size_t)1 << shift) * sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void*)k_range_count, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t lds = (((size_t)1 << shift) + ((size_t)1 << shift) / 32 + 1) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void*)k_range_offsets, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_range_count, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs,
-                       range_start, shift, ltot, cstart);
+    hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs,
+                       range_start, shift, ltot, boff);
 }
 void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
                       uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
