@@ -320,8 +320,64 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // path can be taken (uniformity is only known afterwards; the table is cheap)
     const uint32_t range_shift = qmcp::range_shift_for(ltot);
     const bool may_rank = n >= (1u << 22) && qmcp::range_path_supported(ltot) && !try_chained;
-    TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, may_rank, range_shift, d_ctl, hs));
-    HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
+    uint32_t* d_range_start = (uint32_t*)c->ranges.p;
+    uint32_t* d_max_load = d_range_start + 257;
+    uint32_t max_load = 0;
+    bool have_gstart = true;
+    if (!may_rank) {
+        TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, false, range_shift, d_ctl, hs));
+        HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
+    } else {
+        // Large call that can take the range-ranked route if its spans turn out uniform.  The host
+        // needs the span statistics before it can pick the sweep, but the device need not idle for
+        // that round trip: the partition and the bucket offsets depend only on the start positions,
+        // so they are queued behind k_prepare at once and the statistics (and the heaviest range's
+        // load) are fetched on the side stream meanwhile.  k_prepare does not write the global
+        // start positions on this route -- the partition rebuilds them from the starts.
+        have_gstart = false;
+        hipStream_t s1 = c->stream;
+        const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+        HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
+        {
+            KernelSpan sp(c, "k_prepare");
+            qmcp::launch_prepare(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
+                                 (const uint64_t*)c->poff.p, n_contigs, nullptr, nullptr, nullptr,
+                                 (uint32_t*)c->stats.p, range_shift, (uint32_t*)c->hist2.p, nullptr, nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
+        {
+            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
+                                        (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
+        }
+        {
+            KernelSpan sp(c, "k_range_table");
+            qmcp::launch_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
+        }
+        HIP_TRY(hipEventRecord(c->ev_fork, s1));
+        {
+            KernelSpan sp(c, "k_range_partition");
+            qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
+                                         (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
+                                         (const uint32_t*)c->hist2.p, c->keys[0].p);
+        }
+        {
+            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
+            KernelSpan sp(c, "k_range_offsets");
+            qmcp::launch_range_offsets(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+                                       (uint32_t*)c->boff.p);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(hipMemcpyAsync(hs, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
+        HIP_TRY(hipMemcpyAsync(&max_load, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
+        HIP_TRY(hipStreamSynchronize(c->stream2));
+        if (hs[2] != 0) {
+            (void)hipStreamSynchronize(s1);  // what was queued stays in bounds; let it drain
+            return fail(QMCP_EREAD, "a read has start > end or end >= its contig length");
+        }
+    }
     const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
     local.max_span = max_span;
@@ -342,7 +398,15 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     bool wide = false;
     const uint32_t* d_gstart = (const uint32_t*)c->vals[1].p;
     const uint32_t* d_key32 = d_gstart;  // uniform span: the key is the start position itself
+    auto need_gstart = [&]() {
+        if (have_gstart) return;
+        KernelSpan sp(c, "k_gstart");
+        qmcp::launch_gstart(c->stream, d_starts, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
+                            n_contigs, (uint32_t*)c->vals[1].p);
+        have_gstart = true;
+    };
     if (!uniform) {
+        need_gstart();
         span_bits = bit_width(max_span - min_span);
         wide = pos_bits + span_bits > 32;
         TRY(ensure(c, c->ecnt, ((size_t)ltot + 1) * sizeof(uint32_t)));
@@ -370,30 +434,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     if (uniform && may_rank) {
-        hipStream_t s1 = c->stream;
-        uint32_t* d_range_start = (uint32_t*)c->ranges.p;
-        uint32_t* d_max_load = d_range_start + 257;
-        {
-            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
-            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
-                                        (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
-        }
-        {
-            KernelSpan sp(c, "k_range_table");
-            qmcp::launch_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
-        }
-        HIP_TRY(hipEventRecord(c->ev_fork, s1));
-        {
-            KernelSpan sp(c, "k_range_partition");
-            qmcp::launch_range_partition(s1, d_key32, n, range_shift, (const uint32_t*)c->hist2.p,
-                                         c->keys[0].p);
-        }
-        {
-            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
-            KernelSpan sp(c, "k_range_offsets");
-            qmcp::launch_range_offsets(s1, c->keys[0].p, d_range_start, range_shift, ltot,
-                                       (uint32_t*)c->boff.p);
-        }
+        hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
         {
@@ -410,11 +451,6 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
         sweep_done = true;
-        // heaviest range, fetched beside the work queued above
-        uint32_t max_load = 0;
-        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        HIP_TRY(hipMemcpyAsync(&max_load, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
-        HIP_TRY(hipStreamSynchronize(c->stream2));
         ranked = (uint64_t)max_load * kRankBalance <= (uint64_t)n;
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
         if (ranked) {
@@ -433,6 +469,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     const uint32_t n_tiles = qmcp::sort_tiles(n);
     int kin = 0, vin = 0;  // buffers holding the sorted output at the end
     const bool chained = try_chained && uniform;
+    if (!ranked && uniform) need_gstart();  // the sort-based routes bucket the bare keys
     if (ranked) {
         // keep mask already written by k_rank_mark
     } else if (chained) {

@@ -85,8 +85,11 @@ void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, con
 // then per-range LDS histograms (counts) and per-range ordered ranking against S(p) (keep mask)
 uint32_t range_shift_for(uint32_t ltot);
 bool range_path_supported(uint32_t ltot);
-void launch_range_partition(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t shift,
-                            const uint32_t* offs, void* recs_out);
+void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
+                            const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
+                            uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out);
+void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
+                   const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
 void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
                         uint32_t* range_start, uint32_t* max_load);
 void launch_range_offsets(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,

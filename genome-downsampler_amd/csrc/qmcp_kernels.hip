@@ -136,11 +136,18 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
             else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
             const uint32_t len_c = (uint32_t)(p1 - p0);
-            if (s > e || e >= len_c) { bad = 1; if (gstart_out) gstart_out[i] = 0; continue; }
+            const uint32_t gs = (uint32_t)p0 + s;
+            if (s > e || e >= len_c) {
+                // the call will fail, but kernels queued behind this one before the host knows must
+                // stay in bounds: the read is counted under the digit the partition will compute
+                bad = 1;
+                if (gstart_out) gstart_out[i] = gs;
+                if (part_hist) atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+                continue;
+            }
             const uint32_t span = e - s + 1;
             mn = min(mn, span);
             mx = max(mx, span);
-            const uint32_t gs = (uint32_t)p0 + s;
             if (gstart_out) gstart_out[i] = gs;
             if (part_hist) {
                 atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
@@ -556,14 +563,18 @@ static constexpr int kPartThreads = 1024;
 static constexpr size_t kPartLds = (size_t)kPartRecs * sizeof(Rec) + 16 * 256 * sizeof(uint32_t) +
                                    256 * sizeof(uint32_t) + 64;
 
+// FROM_STARTS: the key (global start position) is built here from the read's start and its
+// contig's offset, so k_prepare need not write it (4 B/read less traffic); otherwise read from `keys`.
+template <bool FROM_STARTS>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
-    const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_tiles,
-    const uint32_t* __restrict__ offs, Rec* __restrict__ out) {
+    const uint32_t* __restrict__ keys, const uint64_t* __restrict__ contig_read_off,
+    const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs, uint32_t n, uint32_t shift,
+    uint32_t n_tiles, const uint32_t* __restrict__ offs, Rec* __restrict__ out) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
     uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [16][256]
     uint32_t* s_gbase = s_cnt + 16 * 256;                              // [256]
-    uint32_t* s_wave = s_gbase + 256;                                  // [4]
+    uint32_t* s_wave = s_gbase + 256;                                  // [4] (+ pad to 16)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t tile0 = blockIdx.x * kPartTiles;                    // first 4096-tile of this pass
@@ -581,6 +592,30 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         const uint32_t i = wbase + k * 64 + lane;
         rec[k].key = i < n ? keys[i] : 0u;
         rec[k].val = i;
+    }
+    if (FROM_STARTS) {
+        // `keys` holds contig-relative starts: add the contig's position offset.  Almost every pass
+        // lies inside one contig (reads are grouped by contig); otherwise search per read.
+        auto contig_of = [&](uint32_t i) {
+            uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
+        const uint32_t c_first = contig_of(base), c_last = contig_of(base + count - 1);
+        if (c_first == c_last) {
+            const uint32_t p0 = (uint32_t)contig_pos_off[c_first];
+#pragma unroll
+            for (int k = 0; k < kSortItems; ++k) rec[k].key += p0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kSortItems; ++k) {
+                const uint32_t i = wbase + k * 64 + lane;
+                if (i < n) rec[k].key += (uint32_t)contig_pos_off[contig_of(i)];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
@@ -687,9 +722,13 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const Rec* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) k[u] = recs[j + u * 1024u].key;
 #pragma unroll
-        for (int u = 0; u < U; ++u) atomicAdd(&s_cnt32[PADDED(k[u] - pos0)], 1u);
+        for (int u = 0; u < U; ++u)
+            if (k[u] - pos0 < width) atomicAdd(&s_cnt32[PADDED(k[u] - pos0)], 1u);  // (garbage keys of an invalid call)
     }
-    for (; j < hi; j += 1024u) atomicAdd(&s_cnt32[PADDED(recs[j].key - pos0)], 1u);
+    for (; j < hi; j += 1024u) {
+        const uint32_t li = recs[j].key - pos0;
+        if (li < width) atomicAdd(&s_cnt32[PADDED(li)], 1u);
+    }
     __syncthreads();
     // counts -> bucket offsets, in place: exclusive scan over the range's positions, started at
     // the number of records in all lower ranges (= the offset of the range's first position), so
@@ -2723,14 +2762,46 @@ uint32_t range_shift_for(uint32_t ltot) {
 }
 bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxRangeShift; }
 
-void launch_range_partition(hipStream_t st, const uint32_t* keys, uint32_t n, uint32_t shift,
-                            const uint32_t* offs, void* recs_out) {
+void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
+                            const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
+                            uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
-    (void)hipFuncSetAttribute((const void*)k_range_partition, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kPartLds);
-    hipLaunchKernelGGL(k_range_partition, dim3((n_tiles + kPartTiles - 1) / kPartTiles), dim3(kPartThreads),
-                       kPartLds, st, keys, n, shift, n_tiles, offs, (Rec*)recs_out);
+    const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles), block(kPartThreads);
+    if (gstart_or_null) {
+        (void)hipFuncSetAttribute((const void*)k_range_partition<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
+        hipLaunchKernelGGL(k_range_partition<false>, grid, block, kPartLds, st, gstart_or_null, d_roff, d_poff,
+                           n_contigs, n, shift, n_tiles, offs, (Rec*)recs_out);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_range_partition<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
+        hipLaunchKernelGGL(k_range_partition<true>, grid, block, kPartLds, st, starts, d_roff, d_poff,
+                           n_contigs, n, shift, n_tiles, offs, (Rec*)recs_out);
+    }
+}
+
+// global start position per read (what k_prepare writes when asked to): for the routes that need
+// the bare keys after a call that did not ask for them
+__global__ __launch_bounds__(256) void k_gstart(const uint32_t* __restrict__ starts, uint32_t n,
+                                               const uint64_t* __restrict__ contig_read_off,
+                                               const uint64_t* __restrict__ contig_pos_off,
+                                               uint32_t n_contigs, uint32_t* __restrict__ gstart) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t lo = 0, hi = n_contigs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+        }
+        gstart[i] = (uint32_t)contig_pos_off[lo] + starts[i];
+    }
+}
+void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
+                   const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_gstart, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, n, d_roff, d_poff,
+                       n_contigs, gstart);
 }
 void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
                         uint32_t* range_start, uint32_t* max_load) {

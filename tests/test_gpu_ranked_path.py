@@ -97,3 +97,33 @@ def test_kept_count_and_validity_match(pkg, oracle, solver):
     out_cov = solver.coverage(s, e, L, keep_mask=got)
     assert oracle.is_out_cover_valid(in_cov, out_cov, M)
     assert np.array_equal(got, oracle.solve(s, e, L, M))
+
+
+def test_speculation_is_abandoned_cleanly(pkg, oracle, solver):
+    """The partition and bucket offsets of a large call are queued before the host has seen the span
+    statistics.  An invalid read must still give QMCP_EREAD (with everything queued staying in
+    bounds), mixed spans must still take the general route, and the context must stay usable."""
+    rng = np.random.default_rng(23)
+    L, span = 20_000, 100
+    s, e = _uniform_reads(rng, N_BIG, L, span)
+    bad_e = e.copy()
+    bad_e[123_457] = L + 5_000_000          # end beyond the contig
+    with pytest.raises(pkg.QmcpError) as err:
+        solver.solve(s, bad_e, L, 10)
+    assert err.value.code == -2  # QMCP_EREAD
+    bad_s = s.copy()
+    bad_s[N_BIG - 3] = 4_000_000_000        # start far beyond everything (garbage key in the partition)
+    with pytest.raises(pkg.QmcpError) as err:
+        solver.solve(bad_s, e, L, 10)
+    assert err.value.code == -2  # QMCP_EREAD
+    # mixed spans: a few reads one base longer
+    e2 = e.copy()
+    longer = rng.choice(N_BIG, size=1000, replace=False)
+    e2[longer] = np.minimum(e2[longer] + 1, L - 1)
+    got = solver.solve(s, e2, L, 7)
+    assert solver.last_stats.path == pkg.PATH_GENERAL
+    assert np.array_equal(got, oracle.solve(s, e2, L, 7))
+    # and the uniform call right after is served by the ranked route again
+    got = solver.solve(s, e, L, 7)
+    assert solver.last_stats.sort_passes == 1
+    assert np.array_equal(got, oracle.solve(s, e, L, 7))
