@@ -111,27 +111,42 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             s_h0[threadIdx.x] = 0;
             __syncthreads();
         }
-#pragma unroll 4
+        // all of the tile's loads first (32 in flight per thread), then the arithmetic
+        const uint32_t tbase = tile * 4096u;
+        const uint32_t tcount = min(4096u, n - tbase);
+        uint32_t sv[16], ev[16];
+#pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const uint32_t i = tile * 4096u + k * 256u + threadIdx.x;
-            if (i >= n) break;
-            const uint32_t s = starts[i], e = ends[i];
-            uint32_t c = 0;
-            if (n_contigs > 1) {
-                uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
-                if (n_contigs <= 64) {
-                    while (hi - lo > 1) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if (s_roff[mid] <= i) lo = mid; else hi = mid;
-                    }
-                } else {
-                    while (hi - lo > 1) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
-                    }
+            const uint32_t j = k * 256u + threadIdx.x;
+            const uint32_t i = tbase + min(j, tcount - 1);  // clamped: every lane loads
+            sv[k] = starts[i];
+            ev[k] = ends[i];
+        }
+        // reads are grouped by contig, so almost every tile lies inside one contig
+        auto contig_of = [&](uint32_t i) {
+            uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
+            if (n_contigs <= 64) {
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_roff[mid] <= i) lo = mid; else hi = mid;
                 }
-                c = lo;
+            } else {
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+                }
             }
+            return lo;
+        };
+        const uint32_t c_first = n_contigs > 1 ? contig_of(tbase) : 0u;
+        const uint32_t c_last = n_contigs > 1 ? contig_of(tbase + tcount - 1) : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t j = k * 256u + threadIdx.x;
+            if (j >= tcount) break;
+            const uint32_t i = tbase + j;
+            const uint32_t s = sv[k], e = ev[k];
+            const uint32_t c = c_first == c_last ? c_first : contig_of(i);
             uint64_t p0, p1;
             if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
             else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
