@@ -567,15 +567,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_rec(
 static constexpr uint32_t kMaxRangeShift = 15;  // 32 Ki positions x 4 B = 128 KiB of LDS
 
 // The range partition itself: the stable scatter of k_radix_scatter_rec<true, false>, but a
-// workgroup of 16 waves stages FOUR consecutive 4096-read tiles (16 Ki records, 128 KiB of LDS)
-// before writing: a range then leaves as one run of ~64 records (512 B) instead of four runs of
-// ~16 (128 B, unaligned), which cuts the partial-line writes that made the scatter move 1.7 x its
-// bytes.  The per-4096-tile histogram of k_prepare and its scan are used as they are: for a fixed
-// range the four tiles' runs are adjacent, so the big tile starts at its first tile's offset.
-static constexpr int kPartTiles = 4;                          // 4096-read tiles per workgroup pass
+// workgroup stages kPartTiles consecutive 4096-read tiles before writing, so a range leaves as
+// one run of kPartTiles x ~16 records instead of separate unaligned 128-byte runs (those made the
+// scatter move 1.7 x its bytes).  Two tiles (8 waves, 74 KiB of LDS) keep two workgroups on a CU,
+// whose phases overlap; four tiles make longer runs but leave the CU's memory pipes idle while
+// its single workgroup ranks.  The per-4096-tile histogram of k_prepare and its scan are used as
+// they are: for a fixed range the tiles' runs are adjacent, so a pass starts at its first tile's
+// offset.
+#ifndef QMCP_PART_TILES
+#define QMCP_PART_TILES 2  // measured on cfg4: 1 tile 0.64 ms, 2 tiles 0.34 ms, 4 tiles 0.46 ms
+#endif
+static constexpr int kPartTiles = QMCP_PART_TILES;             // 4096-read tiles per workgroup pass
 static constexpr int kPartRecs = kPartTiles * kSortTile;      // 16384
-static constexpr int kPartThreads = 1024;
-static constexpr size_t kPartLds = (size_t)kPartRecs * sizeof(Rec) + 16 * 256 * sizeof(uint32_t) +
+static constexpr int kPartThreads = 256 * kPartTiles;
+static constexpr int kPartWaves = kPartThreads / 64;
+static constexpr size_t kPartLds = (size_t)kPartRecs * sizeof(Rec) + kPartWaves * 256 * sizeof(uint32_t) +
                                    256 * sizeof(uint32_t) + 64;
 
 // FROM_STARTS: the key (global start position) is built here from the read's start and its
@@ -587,15 +593,15 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     uint32_t n_tiles, const uint32_t* __restrict__ offs, Rec* __restrict__ out) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
-    uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [16][256]
-    uint32_t* s_gbase = s_cnt + 16 * 256;                              // [256]
+    uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [kPartWaves][256]
+    uint32_t* s_gbase = s_cnt + kPartWaves * 256;                      // [256]
     uint32_t* s_wave = s_gbase + 256;                                  // [4] (+ pad to 16)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t tile0 = blockIdx.x * kPartTiles;                    // first 4096-tile of this pass
     const uint32_t base = tile0 * kSortTile;
     const uint32_t count = min((uint32_t)kPartRecs, n - base);
-    for (int i = threadIdx.x; i < 16 * 256; i += kPartThreads) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
     __syncthreads();
     // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
     // range = (wave, round, lane) = read-index order
@@ -659,9 +665,9 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         // range d = threadIdx.x: where each wave's records of the range go inside the pass, and the
         // global base of the range's run
         const uint32_t d = threadIdx.x;
-        uint32_t c[16], tot = 0;
+        uint32_t c[kPartWaves], tot = 0;
 #pragma unroll
-        for (int x = 0; x < 16; ++x) { c[x] = s_cnt[x * 256 + d]; tot += c[x]; }
+        for (int x = 0; x < kPartWaves; ++x) { c[x] = s_cnt[x * 256 + d]; tot += c[x]; }
         // exclusive scan of the 256 range totals over four waves
         const uint32_t inc = wave_incl_scan_add(tot);
         if (lane == 63) s_wave[w] = inc;
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         const uint32_t tile_off = s_gbase[d] + wave_base;
         uint32_t run = tile_off;
 #pragma unroll
-        for (int x = 0; x < 16; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
+        for (int x = 0; x < kPartWaves; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
         s_gbase[d] = offs[d * n_tiles + tile0] - tile_off;
     }
     __syncthreads();
