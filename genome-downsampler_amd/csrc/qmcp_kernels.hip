@@ -873,20 +873,27 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const Rec* __restrict__ recs
         if (keep) atomicOr(&mask[r.val >> 6], 1ull << (r.val & 63u));
         kept += (uint32_t)__popcll(__ballot(keep));
     };
-    // Records are prefetched two chunks ahead into three registers that rotate by NAME (the loop
-    // is unrolled three times): no register copies, so the wait for a chunk's records is a counted
-    // s_waitcnt that covers only the fire-and-forget mask atomics of two chunks ago.  Chunks past
-    // the end run with every thread idle (dummy quota slot).
-    Rec A, B, C;
+    // Records are prefetched four chunks ahead into five registers that rotate by NAME (the loop is
+    // unrolled five times): no register copies, so the wait for a chunk's records is a counted
+    // s_waitcnt that leaves the younger loads (and the fire-and-forget mask atomics) in flight.
+    // With one 8-byte record per thread per chunk, four chunks ahead is what keeps enough bytes in
+    // flight per CU.  Chunks past the end run with every thread idle (dummy quota slot).
+    Rec A, B, C, D, F;
     fetch(A, 0);
     fetch(B, 1);
-    for (uint32_t c = 0; c < n_chunks; c += 3) {
-        fetch(C, c + 2);
-        chunk(A, c, 0);
-        fetch(A, c + 3);
-        chunk(B, c + 1, 1);
-        fetch(B, c + 4);
-        chunk(C, c + 2, 2);
+    fetch(C, 2);
+    fetch(D, 3);
+    for (uint32_t c = 0; c < n_chunks; c += 5) {
+        fetch(F, c + 4);
+        chunk(A, c, c % 3);
+        fetch(A, c + 5);
+        chunk(B, c + 1, (c + 1) % 3);
+        fetch(B, c + 6);
+        chunk(C, c + 2, (c + 2) % 3);
+        fetch(C, c + 7);
+        chunk(D, c + 3, (c + 3) % 3);
+        fetch(D, c + 8);
+        chunk(F, c + 4, (c + 4) % 3);
     }
     if (lane == 0 && kept) atomicAdd(kept_total, (unsigned long long)kept);
 }
