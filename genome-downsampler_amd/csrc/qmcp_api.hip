@@ -360,12 +360,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             KernelSpan sp(c, "k_range_partition");
             qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
                                          (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
-                                         (const uint32_t*)c->hist2.p, c->keys[0].p);
+                                         (const uint32_t*)c->hist2.p, (uint16_t*)c->keys[0].p,
+                                         (uint32_t*)c->vals[0].p);
         }
         {
             // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
             KernelSpan sp(c, "k_range_offsets");
-            qmcp::launch_range_offsets(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+            qmcp::launch_range_offsets(s1, (const uint16_t*)c->keys[0].p, d_range_start, range_shift, ltot,
                                        (uint32_t*)c->boff.p);
         }
         HIP_TRY(hipGetLastError());
@@ -455,7 +456,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
         if (ranked) {
             KernelSpan sp(c, "k_rank_mark");
-            qmcp::launch_rank_mark(s1, c->keys[0].p, d_range_start, range_shift, ltot,
+            qmcp::launch_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p,
+                                   d_range_start, range_shift, ltot,
                                    (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p,
                                    (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p);
             HIP_TRY(hipGetLastError());

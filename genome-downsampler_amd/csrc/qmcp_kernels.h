@@ -87,15 +87,17 @@ uint32_t range_shift_for(uint32_t ltot);
 bool range_path_supported(uint32_t ltot);
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
-                            uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out);
+                            uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
+                            uint32_t* idx_out);
 void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
 void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
                         uint32_t* range_start, uint32_t* max_load);
-void launch_range_offsets(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                          uint32_t ltot, uint32_t* boff);
-void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                      uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
+                          uint32_t shift, uint32_t ltot, uint32_t* boff);
+void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
+                      const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
+                      const uint32_t* selend,
                       unsigned long long* mask, unsigned long long* kept_total);
 
 }  // namespace qmcp

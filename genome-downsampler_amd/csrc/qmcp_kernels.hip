@@ -590,7 +590,8 @@ template <bool FROM_STARTS>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t* __restrict__ keys, const uint64_t* __restrict__ contig_read_off,
     const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs, uint32_t n, uint32_t shift,
-    uint32_t n_tiles, const uint32_t* __restrict__ offs, Rec* __restrict__ out) {
+    uint32_t n_tiles, const uint32_t* __restrict__ offs, uint16_t* __restrict__ out_key,
+    uint32_t* __restrict__ out_idx) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
     uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [kPartWaves][256]
@@ -698,8 +699,12 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t j = k * kPartThreads + threadIdx.x;
         if (j < count) {
+            // two streams: the position inside the range (< 2^15: 16 bits) and the read index; the
+            // per-range kernels stream 2 + 0 and 2 + 4 bytes per read instead of 8 and 8
             const Rec r = s_rec[j];
-            out[s_gbase[(r.key >> shift) & 255u] + j] = r;
+            const uint32_t dst = s_gbase[(r.key >> shift) & 255u] + j;
+            out_key[dst] = (uint16_t)(r.key & ((1u << shift) - 1u));
+            out_idx[dst] = r.val;
         }
     }
 }
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(256) void k_range_table(const uint32_t* __restrict_
     if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-__global__ __launch_bounds__(1024) void k_range_offsets(const Rec* __restrict__ recs,
+__global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restrict__ keys16,
                                                         const uint32_t* __restrict__ range_start,
                                                         uint32_t shift, uint32_t ltot,
                                                         uint32_t* __restrict__ boff) {
@@ -741,13 +746,13 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const Rec* __restrict__ 
     for (; j + (U - 1) * 1024u < hi; j += U * 1024u) {
         uint32_t k[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) k[u] = recs[j + u * 1024u].key;
+        for (int u = 0; u < U; ++u) k[u] = keys16[j + u * 1024u];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (k[u] - pos0 < width) atomicAdd(&s_cnt32[PADDED(k[u] - pos0)], 1u);  // (garbage keys of an invalid call)
+            if (k[u] < width) atomicAdd(&s_cnt32[PADDED(k[u])], 1u);
     }
     for (; j < hi; j += 1024u) {
-        const uint32_t li = recs[j].key - pos0;
+        const uint32_t li = keys16[j];
         if (li < width) atomicAdd(&s_cnt32[PADDED(li)], 1u);
     }
     __syncthreads();
@@ -792,7 +797,8 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const Rec* __restrict__ 
 // is exactly the S(p) lowest indices of every bucket, independent of LDS arbitration order.
 static constexpr uint32_t kAmbCap = 12;
 
-__global__ __launch_bounds__(1024) void k_rank_mark(const Rec* __restrict__ recs,
+__global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__ keys16,
+                                                    const uint32_t* __restrict__ idx,
                                                     const uint32_t* __restrict__ range_start,
                                                     uint32_t shift, uint32_t ltot,
                                                     const uint32_t* __restrict__ boff,
@@ -817,10 +823,14 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const Rec* __restrict__ recs
     const uint32_t n_chunks = (hi - lo + nthreads - 1) / nthreads;
     uint32_t kept = 0;
 
-    auto fetch = [&](Rec& dst, uint32_t c) { dst = recs[min(lo + c * nthreads + tid, hi - 1)]; };
+    auto fetch = [&](Rec& dst, uint32_t c) {
+        const uint32_t j = min(lo + c * nthreads + tid, hi - 1);
+        dst.key = keys16[j];  // position inside the range
+        dst.val = idx[j];
+    };
     auto chunk = [&](const Rec& r, uint32_t c, uint32_t slot /* c % 3 */) {
         const bool valid = lo + c * nthreads + tid < hi;
-        const uint32_t li = valid ? r.key - pos0 : width;
+        const uint32_t li = valid ? r.key : width;
         const int32_t old = atomicSub(&s_q[li], 1);
         if (tid == 0) s_namb[slot == 2 ? 0 : slot + 1] = 0;  // counter of the NEXT chunk (last read two chunks ago)
         __syncthreads();
@@ -2792,7 +2802,8 @@ bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxR
 
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
-                            uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out) {
+                            uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
+                            uint32_t* idx_out) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles), block(kPartThreads);
@@ -2800,12 +2811,12 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
         (void)hipFuncSetAttribute((const void*)k_range_partition<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
         hipLaunchKernelGGL(k_range_partition<false>, grid, block, kPartLds, st, gstart_or_null, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, (Rec*)recs_out);
+                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out);
     } else {
         (void)hipFuncSetAttribute((const void*)k_range_partition<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
         hipLaunchKernelGGL(k_range_partition<true>, grid, block, kPartLds, st, starts, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, (Rec*)recs_out);
+                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out);
     }
 }
 
@@ -2836,23 +2847,24 @@ void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n
     hipLaunchKernelGGL(k_range_table, dim3(1), dim3(256), 0, st, scanned_hist, sort_tiles(n), n,
                        range_start, max_load);
 }
-void launch_range_offsets(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                          uint32_t ltot, uint32_t* boff) {
+void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
+                          uint32_t shift, uint32_t ltot, uint32_t* boff) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
     const size_t lds = (((size_t)1 << shift) + ((size_t)1 << shift) / 32 + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_range_offsets, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs,
-                       range_start, shift, ltot, boff);
+    hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, range_start, shift,
+                       ltot, boff);
 }
-void launch_rank_mark(hipStream_t st, const void* recs, const uint32_t* range_start, uint32_t shift,
-                      uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
+                      const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
+                      const uint32_t* selend,
                       unsigned long long* mask, unsigned long long* kept_total) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, (const Rec*)recs, range_start,
+    hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx, range_start,
                        shift, ltot, boff, selend, mask, kept_total);
 }
 
