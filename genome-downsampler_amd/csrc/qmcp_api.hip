@@ -65,6 +65,7 @@ struct qmcp_hip_ctx {
     DevBuf lookback;   // chained radix: (tile, digit) status granules, zeroed when (re)allocated
     DevBuf radixctl;   // [4][256] digit counts, [4][256] digit bases, 4 tickets, timeout flag
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
+    DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
     uint32_t radix_epoch = 0;      // unique per chained pass for the life of the context
     bool chained_radix_ok = true;  // cleared for good if a look-back ever times out
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
@@ -292,6 +293,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
         TRY(ensure(c, c->ranges, 260 * sizeof(uint32_t)));
+        if (n >= (1u << 22) && qmcp::range_path_supported(ltot))
+            TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     }
     HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
@@ -459,7 +462,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             qmcp::launch_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p,
                                    d_range_start, range_shift, ltot,
                                    (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p,
-                                   (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p);
+                                   (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p,
+                                   c->rankamb.p);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -763,7 +767,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

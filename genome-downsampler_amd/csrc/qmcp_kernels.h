@@ -95,10 +95,11 @@ void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n
                         uint32_t* range_start, uint32_t* max_load);
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff);
+size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot);  // one list slot per position
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
-                      const uint32_t* selend,
-                      unsigned long long* mask, unsigned long long* kept_total);
+                      const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
+                      void* scratch);
 
 }  // namespace qmcp
 #endif

@@ -783,19 +783,19 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
 }
 
 // One workgroup (16 waves) per range.  The quota array starts at q[p] = S(p) = selend - boff.
-// The range's records are walked in order (they are in read-index order), one chunk of
-// blockDim.x records at a time: every thread draws old = q[p]-- for its record, a barrier, then
-// reads q_after = q[p].  Chunks are ordered by the barrier, so a read is kept iff old > 0 --
-// except that threads of ONE chunk that hit the same position draw their `old` values in an
-// unspecified order, which matters only where the quota runs out inside the chunk
-// (0 < quota < colliders).  Exactly one thread of such a group draws old == 1 while seeing
-// q_after < 0; it lists the position, and the listed positions are resolved by index order:
-// per-wave ballots + a 16-entry count exchange give every member its rank inside the group, and
-// the lowest `quota` ranks keep.  If a chunk lists more positions than is worth resolving one by
-// one (tiny ranges with deep pile-ups), the chunk's decrements are undone and redone wave by
-// wave in order, each wave resolving its own collisions with ballots.  Either way the kept set
-// is exactly the S(p) lowest indices of every bucket, independent of LDS arbitration order.
-static constexpr uint32_t kAmbCap = 12;
+// The range's records are walked in order (they are in read-index order), a chunk of
+// kRankU x blockDim.x records at a time: every thread draws old = q[p]-- for its records, a
+// barrier, then reads q_after = q[p], a barrier.  Chunks are ordered by the barriers, so a read is
+// kept iff old > 0 -- except that threads of ONE chunk that hit the same position draw their
+// `old` values in an unspecified order, which matters only where the quota runs out inside the
+// chunk: exactly the threads with old > 0 that see q_after < 0 afterwards.  Those are not decided
+// on the spot.  The one of them that drew old == 1 appends (chunk, position, q_after) to a list,
+// and after the walk each wave takes list entries and settles them alone: the position's
+// -q_after LAST records of that chunk are the ones the quota did not reach, so the wave walks the
+// chunk's records backwards, skips that many matches and keeps the rest.  Every position runs out
+// at most once, so the list needs at most one entry per position.  The kept set is exactly the
+// S(p) lowest indices of every bucket, independent of LDS arbitration order.
+static constexpr int kRankU = 2;
 
 __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__ keys16,
                                                     const uint32_t* __restrict__ idx,
@@ -804,106 +804,113 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
                                                     const uint32_t* __restrict__ boff,
                                                     const uint32_t* __restrict__ selend,
                                                     unsigned long long* __restrict__ mask,
-                                                    unsigned long long* __restrict__ kept_total) {
+                                                    unsigned long long* __restrict__ kept_total,
+                                                    uint2* __restrict__ amb_lists) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1]; the last entry absorbs idle threads
-    __shared__ uint32_t s_amb[kAmbCap];
-    __shared__ uint32_t s_namb[3];
-    __shared__ uint32_t s_wcnt[16];
+    __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nw = nthreads >> 6;
     const uint32_t lane = tid & 63u, w = tid >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint2* const amb = amb_lists + (size_t)range * width;  // one slot per position of the range
     for (uint32_t i = tid; i < live; i += nthreads)
         s_q[i] = (int32_t)(selend[pos0 + i] - boff[pos0 + i]);
-    if (tid < 3) s_namb[tid] = 0;
+    if (tid == 0) s_namb = 0;
     const uint32_t lo = range_start[range], hi = range_start[range + 1];
     if (lo >= hi) return;  // uniform
     __syncthreads();
-    const uint32_t n_chunks = (hi - lo + nthreads - 1) / nthreads;
+    const uint32_t chunk_recs = kRankU * nthreads;
+    const uint32_t n_chunks = (hi - lo + chunk_recs - 1) / chunk_recs;
     uint32_t kept = 0;
 
-    auto fetch = [&](Rec& dst, uint32_t c) {
-        const uint32_t j = min(lo + c * nthreads + tid, hi - 1);
-        dst.key = keys16[j];  // position inside the range
-        dst.val = idx[j];
+    // thread tid owns record tid of each of the chunk's kRankU sub-chunks
+    struct Recs { uint32_t key[kRankU], val[kRankU]; };
+    auto fetch = [&](Recs& dst, uint32_t c) {
+#pragma unroll
+        for (int u = 0; u < kRankU; ++u) {
+            const uint32_t j = min(lo + c * chunk_recs + u * nthreads + tid, hi - 1);
+            dst.key[u] = keys16[j];  // position inside the range
+            dst.val[u] = idx[j];
+        }
     };
-    auto chunk = [&](const Rec& r, uint32_t c, uint32_t slot /* c % 3 */) {
-        const bool valid = lo + c * nthreads + tid < hi;
-        const uint32_t li = valid ? r.key : width;
-        const int32_t old = atomicSub(&s_q[li], 1);
-        if (tid == 0) s_namb[slot == 2 ? 0 : slot + 1] = 0;  // counter of the NEXT chunk (last read two chunks ago)
-        __syncthreads();
-        const int32_t aft = s_q[li];
-        bool keep = valid && old > 0;
-        if (keep && old == 1 && aft < 0) {
-            const uint32_t k = atomicAdd(&s_namb[slot], 1u);
-            if (k < kAmbCap) s_amb[k] = li;
+    auto chunk = [&](const Recs& r, uint32_t c) {
+        bool valid[kRankU];
+        uint32_t li[kRankU];
+        int32_t old[kRankU];
+#pragma unroll
+        for (int u = 0; u < kRankU; ++u) {
+            valid[u] = lo + c * chunk_recs + u * nthreads + tid < hi;
+            li[u] = valid[u] ? r.key[u] : width;
+            old[u] = atomicSub(&s_q[li[u]], 1);
         }
         __syncthreads();
-        const uint32_t namb = s_namb[slot];
-        if (namb != 0 && namb <= kAmbCap) {
-            for (uint32_t k = 0; k < namb; ++k) {
-                const bool member = valid && li == s_amb[k];
-                const uint64_t m = __ballot(member);
-                if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(m);
-                __syncthreads();
-                if (member) {
-                    uint32_t before = 0, total = 0;
-                    for (uint32_t x = 0; x < nw; ++x) {
-                        const uint32_t cx = s_wcnt[x];
-                        total += cx;
-                        before += x < w ? cx : 0u;
-                    }
-                    keep = (int32_t)(before + (uint32_t)__popcll(m & lt_mask)) < aft + (int32_t)total;
-                }
-                __syncthreads();
-            }
-        } else if (namb != 0) {
-            atomicAdd(&s_q[li], 1);  // undo the chunk
-            __syncthreads();
-            for (uint32_t x = 0; x < nw; ++x) {
-                if (w == x) {
-                    const int32_t o2 = atomicSub(&s_q[li], 1);
-                    const int32_t a2 = s_q[li];
-                    keep = valid && o2 > 0;
-                    uint64_t trig = __ballot(keep && a2 < 0);  // quota ran out inside this wave's step
-                    while (trig) {
-                        const int leader = __ffsll((long long)trig) - 1;
-                        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)li, leader);
-                        const uint64_t same = __ballot(valid && li == p0);
-                        const int32_t quota = __builtin_amdgcn_readlane(a2, leader) + (int32_t)__popcll(same);
-                        if (valid && li == p0) keep = (int32_t)__popcll(same & lt_mask) < quota;
-                        trig &= ~same;
-                    }
-                }
-                __syncthreads();
+        bool keep[kRankU];
+#pragma unroll
+        for (int u = 0; u < kRankU; ++u) {
+            const int32_t aft = s_q[li[u]];
+            // old > 0 and quota not exhausted by the end of the chunk: kept whatever the order was
+            keep[u] = valid[u] && old[u] > 0 && aft >= 0;
+            if (valid[u] && old[u] == 1 && aft < 0) {
+                const uint32_t k = atomicAdd(&s_namb, 1u);
+                amb[k] = make_uint2((c << 15) | li[u], (uint32_t)(-aft));  // c < 2^17, li < 2^15
             }
         }
-        if (keep) atomicOr(&mask[r.val >> 6], 1ull << (r.val & 63u));
-        kept += (uint32_t)__popcll(__ballot(keep));
+        __syncthreads();  // every q_after is read before the next chunk draws
+#pragma unroll
+        for (int u = 0; u < kRankU; ++u) {
+            if (keep[u]) atomicOr(&mask[r.val[u] >> 6], 1ull << (r.val[u] & 63u));
+            kept += (uint32_t)__popcll(__ballot(keep[u]));
+        }
     };
-    // Records are prefetched four chunks ahead into five registers that rotate by NAME (the loop is
-    // unrolled five times): no register copies, so the wait for a chunk's records is a counted
-    // s_waitcnt that leaves the younger loads (and the fire-and-forget mask atomics) in flight.
-    // With one 8-byte record per thread per chunk, four chunks ahead is what keeps enough bytes in
-    // flight per CU.  Chunks past the end run with every thread idle (dummy quota slot).
-    Rec A, B, C, D, F;
+    // Records are prefetched three chunks ahead into four register sets that rotate by NAME (the
+    // loop is unrolled four times): no register copies, so the wait for a chunk's records is a
+    // counted s_waitcnt that leaves the younger loads (and the fire-and-forget mask atomics) in
+    // flight.  Chunks past the end run with every thread idle (dummy quota slot).
+    Recs A, B, C, D;
     fetch(A, 0);
     fetch(B, 1);
     fetch(C, 2);
-    fetch(D, 3);
-    for (uint32_t c = 0; c < n_chunks; c += 5) {
-        fetch(F, c + 4);
-        chunk(A, c, c % 3);
-        fetch(A, c + 5);
-        chunk(B, c + 1, (c + 1) % 3);
-        fetch(B, c + 6);
-        chunk(C, c + 2, (c + 2) % 3);
-        fetch(C, c + 7);
-        chunk(D, c + 3, (c + 3) % 3);
-        fetch(D, c + 8);
-        chunk(F, c + 4, (c + 4) % 3);
+    for (uint32_t c = 0; c < n_chunks; c += 4) {
+        fetch(D, c + 3);
+        chunk(A, c);
+        fetch(A, c + 4);
+        chunk(B, c + 1);
+        fetch(B, c + 5);
+        chunk(C, c + 2);
+        fetch(C, c + 6);
+        chunk(D, c + 3);
+    }
+    // settle the listed (chunk, position) groups: one wave per entry, walking the chunk backwards
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t namb = s_namb;
+    const uint64_t gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // lanes above this one
+    for (uint32_t k = w; k < namb; k += nw) {
+        const uint2 ent = amb[k];
+        const uint32_t c = ent.x >> 15, p = ent.x & 0x7FFFu;
+        uint32_t skip = ent.y;  // matches still to be passed over, from the chunk's end
+        const uint32_t first = lo + c * chunk_recs;
+        const uint32_t last = min(first + chunk_recs, hi);
+        // all of the chunk's positions first (kSteps loads in flight), then the backward walk
+        constexpr int kSteps = kRankU * 16;  // blockDim.x == 1024: 64-record steps per chunk
+        uint32_t key[kSteps];
+#pragma unroll
+        for (int t = 0; t < kSteps; ++t) key[t] = keys16[min(first + t * 64u + lane, hi - 1)];
+#pragma unroll
+        for (int t = kSteps - 1; t >= 0; --t) {
+            const uint32_t j = first + t * 64u + lane;
+            const bool member = j < last && key[t] == p;
+            const uint64_t m = __ballot(member);
+            if (m == 0) continue;
+            const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
+            if (member && above >= skip) {
+                const uint32_t v = idx[j];
+                atomicOr(&mask[v >> 6], 1ull << (v & 63u));
+            }
+            const uint32_t in_step = (uint32_t)__popcll(m);
+            kept += in_step > skip ? in_step - skip : 0u;
+            skip = skip > in_step ? skip - in_step : 0u;
+        }
     }
     if (lane == 0 && kept) atomicAdd(kept_total, (unsigned long long)kept);
 }
@@ -2856,16 +2863,19 @@ void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t
     hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, range_start, shift,
                        ltot, boff);
 }
+size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot) {
+    return (size_t)((ltot >> shift) + 1) * ((size_t)1 << shift) * sizeof(uint2);
+}
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
-                      const uint32_t* selend,
-                      unsigned long long* mask, unsigned long long* kept_total) {
+                      const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
+                      void* scratch) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx, range_start,
-                       shift, ltot, boff, selend, mask, kept_total);
+                       shift, ltot, boff, selend, mask, kept_total, (uint2*)scratch);
 }
 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
