@@ -181,8 +181,9 @@ class Solver:
         self.close()
 
     def set_profiling(self, enabled):
-        """bracket every kernel launch with HIP events on the solver stream (resets the totals)"""
-        _check(_hip.qmcp_hip_set_profiling(self._ctx, int(bool(enabled))))
+        """bracket kernel launches with HIP events on the solver stream (resets the totals):
+        True / 1 every kernel, 2 only the selection sweep, False / 0 off"""
+        _check(_hip.qmcp_hip_set_profiling(self._ctx, 2 if enabled == 2 else int(bool(enabled))))
 
     def kernel_times(self):
         """{kernel: (launches, total_ms)} accumulated since set_profiling(True)"""

@@ -74,7 +74,10 @@ struct qmcp_hip_ctx {
     DevBuf scalars;  // popcount + sweep iteration counters
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every kernel, 2 the selection sweep only
+    size_t tables_count = 0;          // contig tables currently on the device (upload_tables)
+    void* tables_dev_roff = nullptr;
+    void* tables_dev_poff = nullptr;
     struct Span { const char* name; hipEvent_t a, b; };
     std::vector<Span> spans;          // spans of the solve in flight
     std::vector<hipEvent_t> ev_pool;  // recycled events
@@ -104,6 +107,7 @@ struct KernelSpan {
     KernelSpan(qmcp_hip_ctx* ctx, const char* nm, hipStream_t stream = nullptr)
         : c(ctx), name(nm), st(stream ? stream : ctx->stream) {
         if (!c->profiling) return;
+        if (c->profiling == 2 && std::strncmp(nm, "k_sweep", 7) != 0) return;
         a = pool_event(c);
         b = pool_event(c);
         if (a) (void)hipEventRecord(a, st);
@@ -191,8 +195,17 @@ int upload_tables(qmcp_hip_ctx* c, const uint64_t* roff, const Problem& pr) {
         HIP_TRY(hipHostMalloc((void**)&c->h_tables, 2 * bytes, hipHostMallocDefault));
         c->h_tables_cap = 2 * count;
     }
+    // the device copies stay valid across solves: skip the upload when nothing changed (a caller
+    // that solves the same genome repeatedly saves two small copies per call)
+    if (c->tables_count == count && c->tables_dev_roff == c->roff.p && c->tables_dev_poff == c->poff.p &&
+        std::memcmp(c->h_tables, roff, bytes) == 0 &&
+        std::memcmp(c->h_tables + count, pr.poff.data(), bytes) == 0)
+        return QMCP_OK;
     std::memcpy(c->h_tables, roff, bytes);
     std::memcpy(c->h_tables + count, pr.poff.data(), bytes);
+    c->tables_count = count;
+    c->tables_dev_roff = c->roff.p;
+    c->tables_dev_poff = c->poff.p;
     HIP_TRY(hipMemcpyAsync(c->roff.p, c->h_tables, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->poff.p, c->h_tables + count, bytes, hipMemcpyHostToDevice, c->stream));
     return QMCP_OK;
@@ -220,7 +233,7 @@ int run_prepare(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_end
                              want_keys ? (uint32_t*)c->vals[1].p : nullptr,
                              want_counts ? (uint32_t*)c->cstart.p : nullptr, (uint32_t*)c->stats.p,
                              part_shift, want_part_hist ? (uint32_t*)c->hist2.p : nullptr, nullptr,
-                             d_global_digit_hist);
+                             d_global_digit_hist, nullptr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_stats, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -267,8 +280,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     local.n_reads = n64;
     local.n_contigs = n_contigs;
     local.total_length = pr.ltot;
-    if (mask_words) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
     if (n == 0 || ltot == 0) {
+        if (mask_words) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
         if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (st) *st = local;
@@ -328,6 +341,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     uint32_t max_load = 0;
     bool have_gstart = true;
     if (!may_rank) {
+        HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
         TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, false, range_shift, d_ctl, hs));
         HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     } else {
@@ -345,7 +359,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             KernelSpan sp(c, "k_prepare");
             qmcp::launch_prepare(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
                                  (const uint64_t*)c->poff.p, n_contigs, nullptr, nullptr, nullptr,
-                                 (uint32_t*)c->stats.p, range_shift, (uint32_t*)c->hist2.p, nullptr, nullptr);
+                                 (uint32_t*)c->stats.p, range_shift, (uint32_t*)c->hist2.p, nullptr, nullptr,
+                                 (unsigned long long*)d_mask);  // also clears the keep mask
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
@@ -355,17 +370,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
         {
-            KernelSpan sp(c, "k_range_table");
-            qmcp::launch_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
-        }
-        HIP_TRY(hipEventRecord(c->ev_fork, s1));
-        {
             KernelSpan sp(c, "k_range_partition");
             qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
                                          (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
                                          (const uint32_t*)c->hist2.p, (uint16_t*)c->keys[0].p,
-                                         (uint32_t*)c->vals[0].p);
+                                         (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
         }
+        HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
         {
             // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
             KernelSpan sp(c, "k_range_offsets");
@@ -785,7 +796,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
 
 int qmcp_hip_set_profiling(qmcp_hip_ctx* c, int enabled) {
     if (!c) return fail(QMCP_EINVAL, "null context");
-    c->profiling = enabled != 0;
+    c->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     c->acc.clear();
     return QMCP_OK;
 }

@@ -18,7 +18,8 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     uint32_t* stats, uint32_t part_shift,
                     uint32_t* part_hist /* digit-major [256][tiles] of (gstart >> part_shift), or null */,
                     uint32_t* digit0_hist /* same shape, low byte of gstart; needs part_hist; or null */,
-                    uint32_t* global_digit_hist /* [4][256] whole-call digit counts of gstart, or null */);
+                    uint32_t* global_digit_hist /* [4][256] whole-call digit counts of gstart, or null */,
+                    unsigned long long* zero_mask /* keep mask to clear (ceil(n/64) words), or null */);
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
                          const uint64_t* keep_mask, void* keys, uint32_t* ecnt);
@@ -88,11 +89,9 @@ bool range_path_supported(uint32_t ltot);
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
-                            uint32_t* idx_out);
+                            uint32_t* idx_out, uint32_t* range_start /* [257] */, uint32_t* max_load);
 void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
-void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
-                        uint32_t* range_start, uint32_t* max_load);
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff);
 size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot);  // one list slot per position

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  uint32_t part_shift,
                                                  uint32_t* __restrict__ part_hist,
                                                  uint32_t* __restrict__ digit0_hist,
-                                                 uint32_t* __restrict__ global_digit_hist) {
+                                                 uint32_t* __restrict__ global_digit_hist,
+                                                 unsigned long long* __restrict__ zero_mask) {
     __shared__ uint32_t s_gh[4][256];  // whole-call digit histograms of the start key (all 4 bytes)
     if (global_digit_hist) {
         for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_gh[0][0])[i] = 0;
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             s_h0[threadIdx.x] = 0;
             __syncthreads();
         }
+        // the tile's 64 words of the output keep mask are cleared here (saves a memset launch)
+        if (zero_mask && threadIdx.x < 64 && tile * 64u + threadIdx.x < (n + 63u) / 64u)
+            zero_mask[tile * 64u + threadIdx.x] = 0ull;
         // all of the tile's loads first (32 in flight per thread), then the arithmetic
         const uint32_t tbase = tile * 4096u;
         const uint32_t tcount = min(4096u, n - tbase);
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t* __restrict__ keys, const uint64_t* __restrict__ contig_read_off,
     const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs, uint32_t n, uint32_t shift,
     uint32_t n_tiles, const uint32_t* __restrict__ offs, uint16_t* __restrict__ out_key,
-    uint32_t* __restrict__ out_idx) {
+    uint32_t* __restrict__ out_idx, uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
     uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [kPartWaves][256]
@@ -603,6 +607,27 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t base = tile0 * kSortTile;
     const uint32_t count = min((uint32_t)kPartRecs, n - base);
     for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
+    if (blockIdx.x == 0) {
+        // the first workgroup also publishes where every range's records begin (257 entries) and the
+        // heaviest range's load, for the per-range kernels and the host's balance test
+        uint32_t load = 0;
+        if (threadIdx.x < 256) {
+            const uint32_t d = threadIdx.x;
+            const uint32_t r_lo = offs[d * n_tiles];
+            const uint32_t r_hi = d + 1 < 256 ? offs[(d + 1) * n_tiles] : n;
+            range_start[d] = r_lo;
+            if (d == 255) range_start[256] = n;
+            load = r_hi - r_lo;
+        }
+        load = wave_max_u32(load);
+        if (lane == 0) s_gbase[w] = load;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = 0;
+            for (int x = 0; x < kPartWaves; ++x) m = max(m, s_gbase[x]);
+            max_load[0] = m;
+        }
+    }
     __syncthreads();
     // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
     // range = (wave, round, lane) = read-index order
@@ -707,23 +732,6 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
             out_idx[dst] = r.val;
         }
     }
-}
-
-// starts of the ranges in partitioned order (257 entries) and the heaviest range's load
-__global__ __launch_bounds__(256) void k_range_table(const uint32_t* __restrict__ scanned_hist,
-                                                     uint32_t n_tiles, uint32_t n,
-                                                     uint32_t* __restrict__ range_start,
-                                                     uint32_t* __restrict__ max_load) {
-    __shared__ uint32_t s_red[4];
-    const uint32_t d = threadIdx.x;
-    const uint32_t lo = scanned_hist[d * n_tiles];
-    const uint32_t hi = d + 1 < 256 ? scanned_hist[(d + 1) * n_tiles] : n;
-    range_start[d] = lo;
-    if (d == 255) range_start[256] = n;
-    const uint32_t m = wave_max_u32(hi - lo);
-    if ((d & 63) == 0) s_red[d >> 6] = m;
-    __syncthreads();
-    if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
 __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restrict__ keys16,
@@ -2556,13 +2564,13 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
                     uint32_t* stats, uint32_t part_shift, uint32_t* part_hist,
-                    uint32_t* digit0_hist, uint32_t* global_digit_hist) {
+                    uint32_t* digit0_hist, uint32_t* global_digit_hist, unsigned long long* zero_mask) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const uint32_t g = tiles_per_block_for(n_tiles);
     hipLaunchKernelGGL(k_prepare, dim3((n_tiles + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       part_shift, part_hist, digit0_hist, global_digit_hist);
+                       part_shift, part_hist, digit0_hist, global_digit_hist, zero_mask);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
@@ -2810,7 +2818,7 @@ bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxR
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
-                            uint32_t* idx_out) {
+                            uint32_t* idx_out, uint32_t* range_start, uint32_t* max_load) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles), block(kPartThreads);
@@ -2818,12 +2826,12 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
         (void)hipFuncSetAttribute((const void*)k_range_partition<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
         hipLaunchKernelGGL(k_range_partition<false>, grid, block, kPartLds, st, gstart_or_null, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out);
+                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out, range_start, max_load);
     } else {
         (void)hipFuncSetAttribute((const void*)k_range_partition<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
         hipLaunchKernelGGL(k_range_partition<true>, grid, block, kPartLds, st, starts, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out);
+                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out, range_start, max_load);
     }
 }
 
@@ -2848,11 +2856,6 @@ void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uin
     if (n == 0) return;
     hipLaunchKernelGGL(k_gstart, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, n, d_roff, d_poff,
                        n_contigs, gstart);
-}
-void launch_range_table(hipStream_t st, const uint32_t* scanned_hist, uint32_t n,
-                        uint32_t* range_start, uint32_t* max_load) {
-    hipLaunchKernelGGL(k_range_table, dim3(1), dim3(256), 0, st, scanned_hist, sort_tiles(n), n,
-                       range_start, max_load);
 }
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff) {

@@ -99,10 +99,11 @@ int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx);
 void qmcp_hip_destroy(qmcp_hip_ctx* ctx);
 
 /* Instrumentation (the reference's only timing is the "solve took" wall-clock log line,
- * src/app.cpp:132-139).  With profiling on, every kernel launch of a solve is bracketed by HIP
- * events on the solver stream; qmcp_hip_kernel_times writes one line per kernel,
- * "name<TAB>launches<TAB>total_ms", accumulated since profiling was last switched on, and
- * returns the number of lines (negative on error). */
+ * src/app.cpp:132-139).  With profiling on, kernel launches of a solve are bracketed by HIP events
+ * on the stream they run on: enabled == 1 every kernel, enabled == 2 only the selection sweep (the
+ * event records cost a few microseconds of device idle time per bracket).
+ * qmcp_hip_kernel_times writes one line per kernel, "name<TAB>launches<TAB>total_ms", accumulated
+ * since profiling was last switched on, and returns the number of lines (negative on error). */
 int qmcp_hip_set_profiling(qmcp_hip_ctx* ctx, int enabled);
 int qmcp_hip_kernel_times(qmcp_hip_ctx* ctx, char* buf, size_t cap);
 
