@@ -260,6 +260,13 @@ int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
 // a range's ranking is one wave's serial walk (~0.65 ns per read) against ~0.03 ns per read for
 // the radix sort it replaces
 constexpr uint64_t kRankBalance = 24;
+// ... and when the call is large enough for a per-range workgroup to have work (QMCP_HIP_RANK_MIN
+// overrides, for experiments)
+static uint32_t rank_min_reads() {
+    const char* e = std::getenv("QMCP_HIP_RANK_MIN");
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 17);
+}
+#define kRankMinReads rank_min_reads()
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
@@ -306,7 +313,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
         TRY(ensure(c, c->ranges, 260 * sizeof(uint32_t)));
-        if (n >= (1u << 22) && qmcp::range_path_supported(ltot))
+        if (n >= kRankMinReads && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     }
@@ -335,7 +342,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // the range partition's per-tile histogram is produced by the same pass when the range-ranked
     // path can be taken (uniformity is only known afterwards; the table is cheap)
     const uint32_t range_shift = qmcp::range_shift_for(ltot);
-    const bool may_rank = n >= (1u << 22) && qmcp::range_path_supported(ltot) && !try_chained;
+    const bool may_rank = n >= kRankMinReads && qmcp::range_path_supported(ltot) && !try_chained;
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 257;
     uint32_t max_load = 0;

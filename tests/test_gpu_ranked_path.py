@@ -127,3 +127,29 @@ def test_speculation_is_abandoned_cleanly(pkg, oracle, solver):
     got = solver.solve(s, e, L, 7)
     assert solver.last_stats.sort_passes == 1
     assert np.array_equal(got, oracle.solve(s, e, L, 7))
+
+
+@pytest.mark.parametrize("span", [1, 2, 63, 64, 65, 128, 129, 150, 192, 193, 256, 257, 300, 512])
+def test_ranked_route_for_every_span_class(pkg, oracle, solver, span):
+    """mid-size calls (>= 128 Ki reads) take the ranked route too: every register-count class of
+    the seven-wave sweep (spans up to 256) and the single-wave sweep beyond, deep and shallow"""
+    rng = np.random.default_rng(1000 + span)
+    n = 140_000 + span
+    for L, M in ((max(4 * span, 3_000), 30), (60_000 + span, 3)):
+        s, e = _uniform_reads(rng, n, L, span)
+        got = solver.solve(s, e, L, M)
+        assert solver.last_stats.path == pkg.PATH_UNIFORM and solver.last_stats.sort_passes == 1
+        assert np.array_equal(got, oracle.solve(s, e, L, M)), (span, L, M)
+
+
+def test_ranked_route_many_small_contigs(pkg, oracle, solver):
+    rng = np.random.default_rng(77)
+    lengths = rng.integers(400, 9_000, size=40).astype(np.uint32)
+    counts = rng.integers(1_000, 9_000, size=40)
+    span = 90
+    ss, ee = zip(*[_uniform_reads(rng, int(c), int(L), span) for c, L in zip(counts, lengths)])
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    got = solver.solve(s, e, lengths, 12, contig_read_offsets=offs)
+    assert solver.last_stats.sort_passes == 1 and solver.last_stats.n_contigs == 40
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 12, contig_read_offsets=offs))
