@@ -260,6 +260,8 @@ int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
 // a range's ranking is one wave's serial walk (~0.65 ns per read) against ~0.03 ns per read for
 // the radix sort it replaces
 constexpr uint64_t kRankBalance = 24;
+// mean coverage / M below which the sweep runs every block in the general form (lab/sweep_lab.hip)
+constexpr double kGenDepth = 9.0;  // lab: fast 668 vs general 653 cycles per block at 9 x M, 500 vs 652 at 12 x M
 // ... and when the call is large enough for a per-range workgroup to have work (QMCP_HIP_RANK_MIN
 // overrides, for experiments)
 static uint32_t rank_min_reads() {
@@ -272,6 +274,34 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
     return ms;
+}
+
+// The uniform-span sweep: seven waves per contig where the span allows it (fast form with checked
+// fallback on deep data, every block in the general form on shallow data -- both exact, the
+// choice is about speed only), else the single-wave kernel.  QMCP_HIP_SWEEP=fast|gen overrides.
+int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
+                         uint32_t span, uint32_t M, uint32_t* d_iters) {
+    // mean coverage in units of M: the fast form needs the binding jumps to come from the previous
+    // block, which holds while coverage is many times M
+    const double depth = (double)n * (double)span / ((double)ltot * (double)(M ? M : 1));
+    bool gen = depth < kGenDepth;
+    if (const char* e = std::getenv("QMCP_HIP_SWEEP")) {
+        if (std::strcmp(e, "gen") == 0) gen = true;
+        if (std::strcmp(e, "fast") == 0) gen = false;
+    }
+    const uint32_t* boff = (const uint32_t*)c->boff.p;
+    const uint64_t* poff = (const uint64_t*)c->poff.p;
+    uint32_t* selend = (uint32_t*)c->selend.p;
+    if (qmcp::sweep_uniform_mw_supported(span)) {
+        KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
+        const bool ok = gen ? qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters)
+                            : qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters);
+        if (ok) return QMCP_OK;
+    }
+    KernelSpan sp(c, "k_sweep_uniform", st);
+    if (!qmcp::launch_sweep_uniform(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters))
+        return fail(QMCP_ERANGE, "uniform span %u not supported", span);
+    return QMCP_OK;
 }
 
 int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
@@ -459,17 +489,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
-        {
-            // three waves per contig where the span allows it, else the single-wave kernel
-            KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
-                                                                       : "k_sweep_uniform");
-            if (!qmcp::launch_sweep_uniform_mw(s1, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
-                                               n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p,
-                                               d_iters) &&
-                !qmcp::launch_sweep_uniform(s1, (const uint32_t*)c->boff.p, (const uint64_t*)c->poff.p,
-                                            n_contigs, max_span, M, ltot, (uint32_t*)c->selend.p, d_iters))
-                return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
-        }
+        TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
         sweep_done = true;
@@ -588,15 +608,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     if (sweep_done) {
         // done above, from the early counts
     } else if (uniform) {
-        KernelSpan sp(c, qmcp::sweep_uniform_mw_supported(max_span) ? "k_sweep_uniform_mw"
-                                                                   : "k_sweep_uniform");
-        if (!qmcp::launch_sweep_uniform_mw(c->stream, (const uint32_t*)c->boff.p,
-                                           (const uint64_t*)c->poff.p, n_contigs, max_span, M, ltot,
-                                           (uint32_t*)c->selend.p, d_iters) &&
-            !qmcp::launch_sweep_uniform(c->stream, (const uint32_t*)c->boff.p,
-                                        (const uint64_t*)c->poff.p, n_contigs, max_span, M, ltot,
-                                        (uint32_t*)c->selend.p, d_iters))
-            return fail(QMCP_ERANGE, "uniform span %u not supported", max_span);
+        TRY(launch_uniform_sweep(c, c->stream, n, ltot, n_contigs, max_span, M, d_iters));
     } else {
         uint32_t ring = 64;
         while (ring <= max_span) ring <<= 1;

@@ -34,6 +34,10 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
                           uint32_t* vals_out);
 // three-wave pipelined form (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
+// the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
+bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                              uint32_t* selend, uint32_t* iter_stats);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats);

@@ -2129,6 +2129,290 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
     }
 }
 
+// ------------------------------------------------------------------ pipelined general form
+// The same seven-wave pipeline for data where the fast form rarely holds (mean coverage within a few
+// multiples of M): every block is solved in the GENERAL form, which needs no check and no rollback.
+// A block is an inclusive scan of the maps (a, b, u, v) above; the (a, b) half depends only on the
+// counts and ex -- not on the chain -- so the PREP waves run that half of the scan ahead of time and
+// hand the chain wave, for each of the six scan steps, the (a, b) the current lane holds before the
+// step (the "right operand" of the composition).  The chain wave is left with the (u, v) half:
+//     u' = min(uL + a_s, vL, u),   v' = min(uL + b_s, vL, v)          (uL, vL: DPP reads)
+// six instructions per step, plus the suffix-min of the previous block's h that feeds u and v.
+// About 90 instructions per block against 50 for the fast form -- and against ~200 for the
+// single-wave general block the fast kernel falls back to.
+template <int E>
+struct MgLayout {
+    static constexpr int kG = 4;              // blocks per group
+    static constexpr int kA = 0;              // [6] a before each scan step          PREP -> CHAIN
+    static constexpr int kB = 6;              // [6] b before each scan step          PREP -> CHAIN
+    static constexpr int kPa = 12;            // [1] a of all lower lanes (0: none)   PREP -> CHAIN
+    static constexpr int kPb = 13;            // [1] b of all lower lanes (inf: none) PREP -> CHAIN
+    static constexpr int kCnt = 14;           // [E] counts                           PREP -> CHAIN, CHECK
+    static constexpr int kEx = 14 + E;        // [E] ex at the jump landing           PREP -> CHAIN
+    static constexpr int kX0 = 14 + 2 * E;    // [E] bucket offsets                   PREP -> CHECK
+    static constexpr int kDn = 14 + 3 * E;    // [E] distances                        CHAIN -> CHECK
+    static constexpr int kDin = 14 + 4 * E;   // [1] block 0 only: d entering the group
+    static constexpr int kWords = 15 + 4 * E;
+    static constexpr int kSlots = 3;
+    static constexpr size_t kBytes = (size_t)kSlots * kG * kWords * 64 * sizeof(uint32_t) + 64;
+};
+
+template <int E>
+__global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __restrict__ boff,
+                                                           const uint64_t* __restrict__ contig_pos_off,
+                                                           uint32_t ell, uint32_t M, uint32_t ltot,
+                                                           uint32_t* __restrict__ selend,
+                                                           uint32_t* __restrict__ iter_stats) {
+    using Ly = MgLayout<E>;
+    constexpr int kG = Ly::kG;
+    extern __shared__ uint32_t s_mw[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t role = wv == 3 ? 1u : (wv >= 5 ? 2u : 0u);  // 0 PREP, 1 CHAIN, 2 CHECK
+    const uint32_t pblk = wv == 4 ? 3u : wv;                   // PREP: its block of the group
+    const uint32_t cblk = 2 * (wv - 5);                        // CHECK: first of its two blocks
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    if (L == 0) return;
+    const uint32_t n_blocks = (L + ell - 1) / ell;
+    const uint32_t n_groups = n_blocks / kG;
+    const uint32_t* __restrict__ cb = boff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    const uint32_t trash = ltot - base;
+    const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
+    __builtin_amdgcn_s_setprio(3);
+
+    uint32_t h[E];
+    {
+        const uint32_t b0 = cb[0];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            const uint32_t cov = cb[min(i + 1, L)] - b0;
+            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
+        }
+    }
+    uint32_t d_last = 0;
+
+#define MG_SLOT0(idx) (s_mw + (size_t)(idx) * kG * Ly::kWords * 64)
+#define MG_SLOT(idx) (MG_SLOT0(idx) + lane)
+#define MG_AT(slot, k, w) (slot)[((k) * Ly::kWords + (w)) * 64]
+
+    if (role == 0) {
+        // PREP: one block of every group; rows three stages ahead in three register sets (see
+        // k_sweep_uniform_mw); its own unrolled copy of the stage loop
+        constexpr uint32_t kD = 3;
+        RowRaw<E> R0[3], R1[3], R2[3];
+        auto issue_rows = [&](RowRaw<E> (&buf)[3], uint32_t g) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) row_issue<E>(cb, (g * kG + pblk + k) * ell, L, lane, buf[k]);
+        };
+        issue_rows(R0, 0);
+        issue_rows(R1, 1);
+        issue_rows(R2, 2);
+        auto pstage = [&](RowRaw<E> (&buf)[3], uint32_t t) {
+            if (t < n_groups) {
+                uint32_t* const slot = MG_SLOT(t % Ly::kSlots) + pblk * Ly::kWords * 64;
+                uint32_t Wr[3][E];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) row_finish<E>(buf[k], Wr[k]);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_rows(buf, t + kD);
+                __builtin_amdgcn_sched_barrier(0);
+                SweepLoads<E> ld;
+                rows_to_loads<E>(Wr[0], Wr[1], Wr[2], lane, last_lane, last_r, ld);
+                BlockTerms<E> bt;
+                block_terms<E>(ld, (t * kG + pblk) * ell, ell, L, M, lane, bt);
+                // the lane's own (a, b): composition of its E single-position maps
+                uint32_t a = bt.cnt[0], b = bt.cnt[0] + bt.exj[0];
+#pragma unroll
+                for (int r = 1; r < E; ++r) {
+                    const uint32_t a2 = bt.cnt[r], b2 = bt.cnt[r] + bt.exj[r];
+                    const uint32_t na = min(a + a2, b), nb = min(a + b2, b);
+                    a = na; b = nb;
+                }
+                // the (a, b) half of the wave scan, recording what each lane holds before every step
+#define MG_AB_STEP(s, ctrl, rmask)                                                     \
+                {                                                                      \
+                    MG_AT(slot, 0, Ly::kA + (s)) = a;                                  \
+                    MG_AT(slot, 0, Ly::kB + (s)) = b;                                  \
+                    const uint32_t aL = QMCP_DPP(0u, a, ctrl, rmask);                  \
+                    const uint32_t bL = QMCP_DPP(kInf, b, ctrl, rmask);                \
+                    const uint32_t na = min(aL + a, bL), nb = min(aL + b, bL);         \
+                    a = na; b = nb;                                                    \
+                }
+                MG_AB_STEP(0, 0x111, 0xF)
+                MG_AB_STEP(1, 0x112, 0xF)
+                MG_AB_STEP(2, 0x114, 0xF)
+                MG_AB_STEP(3, 0x118, 0xF)
+                MG_AB_STEP(4, 0x142, 0xA)
+                MG_AB_STEP(5, 0x143, 0xC)
+#undef MG_AB_STEP
+                MG_AT(slot, 0, Ly::kPa) = QMCP_DPP(0u, a, 0x138, 0xF);     // all lower lanes (lane 0: identity)
+                MG_AT(slot, 0, Ly::kPb) = QMCP_DPP(kInf, b, 0x138, 0xF);
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    MG_AT(slot, 0, Ly::kCnt + r) = bt.cnt[r];
+                    MG_AT(slot, 0, Ly::kEx + r) = bt.exj[r];
+                    MG_AT(slot, 0, Ly::kX0 + r) = ld.x0[r];
+                }
+            }
+            __syncthreads();
+        };
+        for (uint32_t t = 0;; t += kD) {
+            if (t >= n_groups + 2) break;
+            pstage(R0, t);
+            if (t + 1 >= n_groups + 2) break;
+            pstage(R1, t + 1);
+            if (t + 2 >= n_groups + 2) break;
+            pstage(R2, t + 2);
+        }
+    } else {
+        for (uint32_t t = 0; t < n_groups + 2; ++t) {
+            if (role == 1) {
+                if (t >= 1 && t <= n_groups) {
+                    const uint32_t g = t - 1;
+                    uint32_t* const slot = MG_SLOT(g % Ly::kSlots);
+                    const uint32_t* const slot0 = MG_SLOT0(g % Ly::kSlots);
+                    MG_AT(slot, 0, Ly::kDin) = d_last;
+#pragma unroll
+                    for (int k = 0; k < kG; ++k) {
+                        uint32_t cnt[E], exj[E];
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            cnt[r] = MG_AT(slot, k, Ly::kCnt + r);
+                            exj[r] = MG_AT(slot, k, Ly::kEx + r);
+                        }
+                        uint32_t as[6], bs[6];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) {
+                            as[q] = MG_AT(slot, k, Ly::kA + q);
+                            bs[q] = MG_AT(slot, k, Ly::kB + q);
+                        }
+                        const uint32_t pa = MG_AT(slot, k, Ly::kPa), pb = MG_AT(slot, k, Ly::kPb);
+                        // A(i) = min over j >= i of the previous block's h: in-lane suffix + wave suffix
+                        uint32_t A[E];
+                        uint32_t sm = kInf;
+#pragma unroll
+                        for (int r = E - 1; r >= 0; --r) { sm = min(sm, h[r]); A[r] = sm; }
+                        {
+                            uint32_t ws = sm;
+                            ws = min(ws, QMCP_DPP_UMIN(ws, 0x101, 0xF));
+                            ws = min(ws, QMCP_DPP_UMIN(ws, 0x102, 0xF));
+                            ws = min(ws, QMCP_DPP_UMIN(ws, 0x104, 0xF));
+                            ws = min(ws, QMCP_DPP_UMIN(ws, 0x108, 0xF));
+                            const uint32_t r1 = __builtin_amdgcn_readlane(ws, 16);
+                            const uint32_t r2 = __builtin_amdgcn_readlane(ws, 32);
+                            const uint32_t r3 = __builtin_amdgcn_readlane(ws, 48);
+                            const uint32_t row = lane >> 4;
+                            const uint32_t off1 = row < 1 ? 0u : 0xFFFFFFFFu;
+                            const uint32_t off2 = row < 2 ? 0u : 0xFFFFFFFFu;
+                            const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
+                            ws = min(min(ws, r1 | off1), min(r2 | off2, r3 | off3));
+                            const uint32_t after = min(QMCP_DPP(0xFFFFFFFFu, ws, 0x130, 0xF), kInf);
+#pragma unroll
+                            for (int r = 0; r < E; ++r) A[r] = min(A[r], after);
+                        }
+                        // the lane's own (u, v)
+                        uint32_t u = A[0], v = A[0] + exj[0];
+#pragma unroll
+                        for (int r = 1; r < E; ++r) {
+                            const uint32_t nu = min(min(u + cnt[r], v), A[r]);
+                            const uint32_t nv = min(min(u + cnt[r] + exj[r], v), A[r] + exj[r]);
+                            u = nu; v = nv;
+                        }
+                        // the (u, v) half of the wave scan
+#define MG_UV_STEP(s, ctrl, rmask)                                                     \
+                        {                                                              \
+                            const uint32_t uL = QMCP_DPP(kInf, u, ctrl, rmask);        \
+                            const uint32_t vL = QMCP_DPP(kInf, v, ctrl, rmask);        \
+                            const uint32_t nu = min(min(uL + as[s], vL), u);           \
+                            const uint32_t nv = min(min(uL + bs[s], vL), v);           \
+                            u = nu; v = nv;                                            \
+                        }
+                        MG_UV_STEP(0, 0x111, 0xF)
+                        MG_UV_STEP(1, 0x112, 0xF)
+                        MG_UV_STEP(2, 0x114, 0xF)
+                        MG_UV_STEP(3, 0x118, 0xF)
+                        MG_UV_STEP(4, 0x142, 0xA)
+                        MG_UV_STEP(5, 0x143, 0xC)
+#undef MG_UV_STEP
+                        const uint32_t pu = QMCP_DPP(kInf, u, 0x138, 0xF);
+                        const uint32_t pv = QMCP_DPP(kInf, v, 0x138, 0xF);
+                        // state entering this lane: the map of all lower lanes applied to (d_last, +inf)
+                        uint32_t dd = min(d_last + pa, pu);
+                        uint32_t m = min(d_last + pb, pv);
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            dd = min(min(dd + cnt[r], m), A[r]);
+                            MG_AT(slot, k, Ly::kDn + r) = dd;
+                            h[r] = dd + exj[r];
+                            m = min(m, h[r]);
+                        }
+                        d_last = slot0[((k * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
+                    }
+                }
+            } else {
+                if (t >= 2) {
+                    const uint32_t g = t - 2;
+                    uint32_t* const slot = MG_SLOT(g % Ly::kSlots);
+                    const uint32_t* const slot0 = MG_SLOT0(g % Ly::kSlots);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const uint32_t k = cblk + kk;
+                        uint32_t dn[E];
+#pragma unroll
+                        for (int r = 0; r < E; ++r) dn[r] = MG_AT(slot, k, Ly::kDn + r);
+                        const uint32_t d_blk = k == 0 ? MG_AT(slot, 0, Ly::kDin)
+                                                      : slot0[(((k - 1) * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
+                        uint32_t prev = QMCP_DPP(0u, dn[E - 1], 0x138, 0xF);
+                        prev = lane == 0 ? d_blk : prev;
+                        uint32_t sel[E];
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            sel[r] = MG_AT(slot, k, Ly::kX0 + r) + (MG_AT(slot, k, Ly::kCnt + r) - (dn[r] - prev));
+                            prev = dn[r];
+                        }
+                        const uint32_t blk_first = (g * kG + k) * ell;
+                        const uint32_t p0 = blk_first + lane * E;
+                        const bool full = lane * E + E <= ell && p0 + E <= L;
+                        if constexpr (E == 1) {
+                            csel[full ? p0 : trash] = sel[0];
+                        } else {
+                            typedef typename RowVec<E>::type V;
+                            V vv;
+#pragma unroll
+                            for (int r = 0; r < E; ++r) vv[r] = sel[r];
+                            *reinterpret_cast<V*>(csel + (full ? p0 : trash)) = vv;
+                            if (ell % E != 0 || blk_first + ell > L) {
+#pragma unroll
+                                for (int r = 0; r < E; ++r) {
+                                    const uint32_t i = lane * E + r;
+                                    if (!full && i < ell && blk_first + i < L) csel[blk_first + i] = sel[r];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#undef MG_AT
+#undef MG_SLOT
+#undef MG_SLOT0
+    if (role == 1) {
+        if (n_groups * kG < n_blocks)
+            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
+                              csel);
+        if (iter_stats && lane == 0) {
+            atomicAdd(&iter_stats[0], n_blocks);  // every block is in the general form here
+            atomicAdd(&iter_stats[1], n_blocks);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ general (mixed-span) sweep
 // Event-driven form of the canonical rule for arbitrary spans.  Reads are bucketed by start
 // and ordered (end desc, index asc) inside a bucket, so the selected reads of a bucket are
@@ -2647,6 +2931,29 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
         default: return false;  // wider spans: single-wave kernel
     }
 #undef QMCP_SWEEP_MW
+    return true;
+}
+
+bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                              uint32_t* selend, uint32_t* iter_stats) {
+    const uint32_t e = (ell + 63) / 64;
+#define QMCP_SWEEP_GEN(EE)                                                                             \
+    {                                                                                                   \
+        const size_t lds = MgLayout<EE>::kBytes;                                                        \
+        (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_contigs), dim3(448), lds, st, boff, d_poff,  \
+                           ell, M, ltot, selend, iter_stats);                                           \
+    }
+    switch (e) {
+        case 1: QMCP_SWEEP_GEN(1); break;
+        case 2: QMCP_SWEEP_GEN(2); break;
+        case 3: QMCP_SWEEP_GEN(3); break;
+        case 4: QMCP_SWEEP_GEN(4); break;
+        default: return false;
+    }
+#undef QMCP_SWEEP_GEN
     return true;
 }
 

@@ -80,6 +80,26 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
                ok ? "" : "(unsupported span)", best2, best2 * 1e6 / nb, best2 * 1e6 / nb * 2.4, it2[0] / reps, diff, first,
                hipGetErrorString(e));
     }
+    // the pipelined general form on the same data: identical selend required
+    {
+        std::vector<uint32_t> ref(Lt + 1), got(Lt + 1);
+        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it);
+        hipDeviceSynchronize();
+        hipMemcpy(ref.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
+        hipMemset(d_sel, 0xEE, (Lt + 1) * 4);
+        float best3 = 1e9;
+        for (int it = 0; it < reps; ++it) {
+            hipEventRecord(a);
+            launch_sweep_uniform_gen(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it);
+            hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best3) best3 = ms;
+        }
+        hipError_t e = hipDeviceSynchronize();
+        hipMemcpy(got.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
+        size_t diff = 0, first = 0;
+        for (uint64_t i = 0; i < Lt; ++i) if (ref[i] != got[i]) { if (!diff) first = i; ++diff; }
+        printf("   general pipeline: %.3f ms  %.1f ns/block ~%.0f cyc/block  mismatches %zu (first at %zu) %s\n",
+               best3, best3 * 1e6 / nb, best3 * 1e6 / nb * 2.4, diff, first, hipGetErrorString(e));
+    }
     hipFree(d_boff); hipFree(d_sel); hipFree(d_it); hipFree(d_poff);
 }
 
@@ -90,5 +110,12 @@ int main() {
     run_case("shallow 0.3/pos M=50 (cut points)", 0.3, 1000000, 150, 50, 1);
     run_case("mixed: deep with sparse holes", 12.5, 100003, 150, 100, 3);
     run_case("tiny contigs", 5.0, 1000, 150, 20, 5);
+    // depth sweep for the fast / general choice: mean coverage = mean * 150, in units of M = 50
+    run_case("depth 1.5 x M", 0.5, 400000, 150, 50, 1);
+    run_case("depth 3 x M", 1.0, 400000, 150, 50, 1);
+    run_case("depth 4.5 x M", 1.5, 400000, 150, 50, 1);
+    run_case("depth 6 x M", 2.0, 400000, 150, 50, 1);
+    run_case("depth 9 x M", 3.0, 400000, 150, 50, 1);
+    run_case("depth 12 x M", 4.0, 400000, 150, 50, 1);
     return 0;
 }
