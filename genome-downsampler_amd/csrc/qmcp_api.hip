@@ -328,10 +328,11 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // hipFree would stall on the work in flight)
     {
         const uint32_t tiles = qmcp::sort_tiles(n);
-        const uint32_t spine_a = qmcp::scan_spine_entries(256u * tiles);
+        const uint32_t tiles_seg = qmcp::seg_tile_bound(n);  // second partition level: tiles aligned to super-ranges
+        const uint32_t spine_a = qmcp::scan_spine_entries(256u * tiles_seg);
         const uint32_t spine_b = qmcp::scan_spine_entries(ltot + 1) + 1;
         TRY(ensure(c, c->spine, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
-        TRY(ensure(c, c->hist, (size_t)256 * tiles * sizeof(uint32_t)));
+        TRY(ensure(c, c->hist, (size_t)256 * tiles_seg * sizeof(uint32_t)));
         TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
         TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
@@ -342,9 +343,9 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
-        TRY(ensure(c, c->ranges, 260 * sizeof(uint32_t)));
+        TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= kRankMinReads && qmcp::range_path_supported(ltot))
-            TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot)));
+            TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     }
     HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
@@ -374,7 +375,9 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     const uint32_t range_shift = qmcp::range_shift_for(ltot);
     const bool may_rank = n >= kRankMinReads && qmcp::range_path_supported(ltot) && !try_chained;
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
-    uint32_t* d_max_load = d_range_start + 257;
+    uint32_t* d_max_load = d_range_start + 65540;
+    uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
+    const bool two_level = qmcp::range_path_two_level(ltot);
     uint32_t max_load = 0;
     bool have_gstart = true;
     if (!may_rank) {
@@ -396,7 +399,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             KernelSpan sp(c, "k_prepare");
             qmcp::launch_prepare(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
                                  (const uint64_t*)c->poff.p, n_contigs, nullptr, nullptr, nullptr,
-                                 (uint32_t*)c->stats.p, range_shift, (uint32_t*)c->hist2.p, nullptr, nullptr,
+                                 (uint32_t*)c->stats.p, two_level ? range_shift + 8 : range_shift,
+                                 (uint32_t*)c->hist2.p, nullptr, nullptr,
                                  (unsigned long long*)d_mask);  // also clears the keep mask
         }
         HIP_TRY(hipGetLastError());
@@ -406,12 +410,25 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::sort_tiles(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
-        {
+        if (!two_level) {
             KernelSpan sp(c, "k_range_partition");
             qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
                                          (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
                                          (const uint32_t*)c->hist2.p, (uint16_t*)c->keys[0].p,
                                          (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
+        } else {
+            // more than 256 ranges (genomes beyond 8.39 M positions): first into <= 256 super-ranges as
+            // {global start, index} records, then every super-range into its final ranges
+            {
+                KernelSpan sp(c, "k_range_partition(level 1)");
+                qmcp::launch_partition_level1(s1, d_starts, (const uint64_t*)c->roff.p,
+                                              (const uint64_t*)c->poff.p, n_contigs, n, range_shift + 8,
+                                              (const uint32_t*)c->hist2.p, c->keys[1].p, d_seg_tables, d_max_load);
+            }
+            KernelSpan sp(c, "partition level 2 (tables, hist, scan, scatter)");
+            qmcp::launch_partition_level2(s1, c->keys[1].p, n, range_shift, d_seg_tables, (uint32_t*)c->hist.p,
+                                          (uint32_t*)c->spine.p, (uint16_t*)c->keys[0].p,
+                                          (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
         }
         HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
         {
@@ -501,7 +518,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                                    d_range_start, range_shift, ltot,
                                    (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p,
                                    (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p,
-                                   c->rankamb.p);
+                                   c->rankamb.p, qmcp::rank_scratch_by_records(range_shift, ltot, n));
             HIP_TRY(hipGetLastError());
         }
     }

@@ -90,6 +90,16 @@ void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, con
 // then per-range LDS histograms (counts) and per-range ordered ranking against S(p) (keep mask)
 uint32_t range_shift_for(uint32_t ltot);
 bool range_path_supported(uint32_t ltot);
+bool range_path_two_level(uint32_t ltot);  // more than 256 ranges: two partition levels
+uint32_t seg_tile_bound(uint32_t n);
+void launch_partition_level1(hipStream_t st, const uint32_t* starts, const uint64_t* d_roff,
+                             const uint64_t* d_poff, uint32_t n_contigs, uint32_t n, uint32_t shift_hi,
+                             const uint32_t* offs, void* recs_out, uint32_t* super_start,
+                             uint32_t* max_super_load);
+void launch_partition_level2(hipStream_t st, const void* recs_in, uint32_t n, uint32_t shift,
+                             uint32_t* tables /* 771 words */, uint32_t* hist, uint32_t* spine,
+                             uint16_t* keys16_out, uint32_t* idx_out, uint32_t* range_start /* 65537 */,
+                             uint32_t* max_load);
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
@@ -98,11 +108,12 @@ void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uin
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff);
-size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot);  // one list slot per position
+size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot, uint32_t n);  // list slots: per position or per read
+bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n);
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
-                      void* scratch);
+                      void* scratch, bool scratch_by_records);
 
 }  // namespace qmcp
 #endif

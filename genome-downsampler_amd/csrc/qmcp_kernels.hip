@@ -588,14 +588,27 @@ static constexpr int kPartWaves = kPartThreads / 64;
 static constexpr size_t kPartLds = (size_t)kPartRecs * sizeof(Rec) + kPartWaves * 256 * sizeof(uint32_t) +
                                    256 * sizeof(uint32_t) + 64;
 
-// FROM_STARTS: the key (global start position) is built here from the read's start and its
-// contig's offset, so k_prepare need not write it (4 B/read less traffic); otherwise read from `keys`.
-template <bool FROM_STARTS>
+// MODE 0: keys = global start positions (k_prepare wrote them); MODE 1: keys = contig-relative
+// starts, the global start is built here from the contig's offset (so k_prepare need not write it:
+// 4 B/read less traffic); MODE 2: second level of a two-level partition -- the input are the
+// {global start, index} records of the first level, already grouped into <= 256 super-ranges, and
+// every super-range is partitioned on its own (tiles aligned to its first record; the offset table
+// is laid out [super-range][range digit][tile of the super-range], so one plain exclusive scan
+// over it yields absolute destinations).
+// OUT_REC: emit {global start, index} records (first level) instead of the two final streams.
+struct SegTables {                   // device tables of the two-level route (257 entries each)
+    const uint32_t* super_start;     // first record of every super-range in first-level order
+    const uint32_t* tile_base;       // 4096-record tiles of all lower super-ranges
+    const uint32_t* pass_base;       // partition passes (kPartTiles tiles) of all lower super-ranges
+};
+
+template <int MODE, bool OUT_REC>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
-    const uint32_t* __restrict__ keys, const uint64_t* __restrict__ contig_read_off,
-    const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs, uint32_t n, uint32_t shift,
-    uint32_t n_tiles, const uint32_t* __restrict__ offs, uint16_t* __restrict__ out_key,
-    uint32_t* __restrict__ out_idx, uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
+    const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, SegTables seg,
+    const uint64_t* __restrict__ contig_read_off, const uint64_t* __restrict__ contig_pos_off,
+    uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles, const uint32_t* __restrict__ offs,
+    uint16_t* __restrict__ out_key, uint32_t* __restrict__ out_idx, Rec* __restrict__ out_rec,
+    uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
     uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [kPartWaves][256]
@@ -603,11 +616,31 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     uint32_t* s_wave = s_gbase + 256;                                  // [4] (+ pad to 16)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t tile0 = blockIdx.x * kPartTiles;                    // first 4096-tile of this pass
-    const uint32_t base = tile0 * kSortTile;
-    const uint32_t count = min((uint32_t)kPartRecs, n - base);
+    // this pass: records [base, base + count), none at or beyond `bound`; its row of the offset
+    // table: entry of digit d = offs[off0 + d * off_stride]
+    uint32_t base, bound, off0, off_stride;
+    if (MODE == 2) {
+        uint32_t lo = 0, hi = 256;  // last super-range whose first pass is <= blockIdx.x
+        if (blockIdx.x >= seg.pass_base[256]) return;  // the grid is an upper bound
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg.pass_base[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        const uint32_t pass = blockIdx.x - seg.pass_base[lo];
+        const uint32_t t_h = seg.tile_base[lo + 1] - seg.tile_base[lo];
+        base = seg.super_start[lo] + pass * kPartRecs;
+        bound = seg.super_start[lo + 1];
+        off0 = seg.tile_base[lo] * 256u + pass * kPartTiles;
+        off_stride = t_h;
+    } else {
+        base = blockIdx.x * kPartRecs;
+        bound = n;
+        off0 = blockIdx.x * kPartTiles;
+        off_stride = n_tiles;
+    }
+    const uint32_t count = min((uint32_t)kPartRecs, bound - base);
     for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
-    if (blockIdx.x == 0) {
+    if (MODE != 2 && blockIdx.x == 0) {
         // the first workgroup also publishes where every range's records begin (257 entries) and the
         // heaviest range's load, for the per-range kernels and the host's balance test
         uint32_t load = 0;
@@ -630,17 +663,21 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     }
     __syncthreads();
     // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
-    // range = (wave, round, lane) = read-index order
+    // range = (wave, round, lane) = input order
     const uint32_t wbase = base + w * (kSortItems * 64);
     Rec rec[kSortItems];
     uint32_t rank[kSortItems];
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
-        rec[k].key = i < n ? keys[i] : 0u;
-        rec[k].val = i;
+        if (MODE == 2) {
+            rec[k] = i < bound ? recs_in[i] : Rec{0u, 0u};
+        } else {
+            rec[k].key = i < bound ? keys[i] : 0u;
+            rec[k].val = i;
+        }
     }
-    if (FROM_STARTS) {
+    if (MODE == 1) {
         // `keys` holds contig-relative starts: add the contig's position offset.  Almost every pass
         // lies inside one contig (reads are grouped by contig); otherwise search per read.
         auto contig_of = [&](uint32_t i) {
@@ -660,14 +697,14 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
 #pragma unroll
             for (int k = 0; k < kSortItems; ++k) {
                 const uint32_t i = wbase + k * 64 + lane;
-                if (i < n) rec[k].key += (uint32_t)contig_pos_off[contig_of(i)];
+                if (i < bound) rec[k].key += (uint32_t)contig_pos_off[contig_of(i)];
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
-        const bool valid = i < n;
+        const bool valid = i < bound;
         const uint32_t d = (rec[k].key >> shift) & 255u;
         uint64_t peers = __ballot(valid);
         if (!valid) peers = ~peers;
@@ -708,13 +745,13 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         uint32_t run = tile_off;
 #pragma unroll
         for (int x = 0; x < kPartWaves; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
-        s_gbase[d] = offs[d * n_tiles + tile0] - tile_off;
+        s_gbase[d] = offs[off0 + d * off_stride] - tile_off;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
-        if (i < n) {
+        if (i < bound) {
             const uint32_t d = (rec[k].key >> shift) & 255u;
             s_rec[s_cnt[w * 256 + d] + rank[k]] = rec[k];
         }
@@ -724,14 +761,82 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t j = k * kPartThreads + threadIdx.x;
         if (j < count) {
-            // two streams: the position inside the range (< 2^15: 16 bits) and the read index; the
-            // per-range kernels stream 2 + 0 and 2 + 4 bytes per read instead of 8 and 8
             const Rec r = s_rec[j];
             const uint32_t dst = s_gbase[(r.key >> shift) & 255u] + j;
-            out_key[dst] = (uint16_t)(r.key & ((1u << shift) - 1u));
-            out_idx[dst] = r.val;
+            if (OUT_REC) {
+                out_rec[dst] = r;
+            } else {
+                // two streams: the position inside the range (< 2^15: 16 bits) and the read index; the
+                // per-range kernels stream 2 + 0 and 2 + 4 bytes per read instead of 8 and 8
+                out_key[dst] = (uint16_t)(r.key & ((1u << shift) - 1u));
+                out_idx[dst] = r.val;
+            }
         }
     }
+}
+
+// ---- two-level route (more than 256 ranges: genomes beyond 8.39 M positions) ----
+// tile and pass tables of the super-ranges, from where the first level put them
+__global__ __launch_bounds__(256) void k_seg_tables(const uint32_t* __restrict__ super_start,
+                                                    uint32_t* __restrict__ tile_base,
+                                                    uint32_t* __restrict__ pass_base,
+                                                    uint32_t* __restrict__ max_load) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t h = threadIdx.x;
+    const uint32_t n_h = super_start[h + 1] - super_start[h];
+    const uint32_t t_h = (n_h + kSortTile - 1) / kSortTile;
+    const uint32_t p_h = (t_h + kPartTiles - 1) / kPartTiles;
+    uint32_t tot;
+    const uint32_t tb = block_excl_scan_256(t_h, s_wave, tot);
+    tile_base[h] = tb;
+    if (h == 255) tile_base[256] = tot;
+    const uint32_t pb = block_excl_scan_256(p_h, s_wave, tot);
+    pass_base[h] = pb;
+    if (h == 255) pass_base[256] = tot;
+    if (h == 0) max_load[0] = 0;
+}
+
+// per-tile histogram of the second-level digit, tiles aligned to the super-ranges
+__global__ __launch_bounds__(kSortThreads) void k_seg_hist(const Rec* __restrict__ recs, SegTables seg,
+                                                           uint32_t shift, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    if (blockIdx.x >= seg.tile_base[256]) return;  // the grid is an upper bound
+    uint32_t lo = 0, hi = 256;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg.tile_base[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const uint32_t t = blockIdx.x - seg.tile_base[lo];
+    const uint32_t t_h = seg.tile_base[lo + 1] - seg.tile_base[lo];
+    const uint32_t base = seg.super_start[lo] + t * kSortTile, bound = seg.super_start[lo + 1];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = base + k * kSortThreads + threadIdx.x;
+        if (i < bound) atomicAdd(&s_h[(recs[i].key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[seg.tile_base[lo] * 256u + threadIdx.x * t_h + t] = s_h[threadIdx.x];
+}
+
+// where every final range begins (65 536 + 1 entries), and the heaviest range's load
+__global__ __launch_bounds__(256) void k_seg_range_table(const uint32_t* __restrict__ scanned, SegTables seg,
+                                                         uint32_t n, uint32_t* __restrict__ range_start,
+                                                         uint32_t* __restrict__ max_load) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t h = blockIdx.x, d = threadIdx.x;
+    const uint32_t t_h = seg.tile_base[h + 1] - seg.tile_base[h];
+    const uint32_t row = seg.tile_base[h] * 256u;
+    const uint32_t lo = t_h ? scanned[row + d * t_h] : seg.super_start[h];
+    const uint32_t hi = d + 1 < 256 ? (t_h ? scanned[row + (d + 1) * t_h] : seg.super_start[h])
+                                    : seg.super_start[h + 1];
+    range_start[h * 256u + d] = lo;
+    if (h == 255 && d == 255) range_start[65536] = n;
+    const uint32_t m = wave_max_u32(hi - lo);
+    if ((d & 63) == 0) s_red[d >> 6] = m;
+    __syncthreads();
+    if (d == 0) atomicMax(max_load, max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
 }
 
 __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restrict__ keys16,
@@ -813,14 +918,16 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
                                                     const uint32_t* __restrict__ selend,
                                                     unsigned long long* __restrict__ mask,
                                                     unsigned long long* __restrict__ kept_total,
-                                                    uint2* __restrict__ amb_lists) {
+                                                    uint2* __restrict__ amb_lists, int lists_by_records) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1]; the last entry absorbs idle threads
     __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nw = nthreads >> 6;
     const uint32_t lane = tid & 63u, w = tid >> 6;
-    uint2* const amb = amb_lists + (size_t)range * width;  // one slot per position of the range
+    // list slots: one per position of the range, or (when the call has fewer reads than positions)
+    // one per record of the range -- a listed position has at least one record
+    uint2* const amb = amb_lists + (lists_by_records ? (size_t)range_start[range] : (size_t)range * width);
     for (uint32_t i = tid; i < live; i += nthreads)
         s_q[i] = (int32_t)(selend[pos0 + i] - boff[pos0 + i]);
     if (tid == 0) s_namb = 0;
@@ -3115,12 +3222,27 @@ void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, con
 
 // range-ranked uniform path: geometry, partition table, counts, rank + mark
 uint32_t range_shift_for(uint32_t ltot) {
-    // smallest shift whose ranges (positions 0..ltot inclusive) fit the 256 digits of one pass
+    // smallest shift whose ranges (positions 0..ltot inclusive) fit the 256 digits of one pass; beyond
+    // 256 ranges of 32 Ki positions a second partition level supplies eight more digit bits
     uint32_t shift = 0;
-    while (shift <= kMaxRangeShift && (ltot >> shift) >= 256u) ++shift;
-    return shift;  // > kMaxRangeShift: not supported
+    while (shift < kMaxRangeShift && (ltot >> shift) >= 256u) ++shift;
+    return shift;
 }
-bool range_path_supported(uint32_t ltot) { return range_shift_for(ltot) <= kMaxRangeShift; }
+bool range_path_two_level(uint32_t ltot) { return (ltot >> kMaxRangeShift) >= 256u; }
+bool range_path_supported(uint32_t ltot) { return (ltot >> kMaxRangeShift) < 65536u; }  // always, for 32-bit positions < 2^31
+
+template <int MODE, bool OUT_REC>
+static void launch_partition_t(hipStream_t st, dim3 grid, const uint32_t* keys, const Rec* recs_in,
+                               SegTables seg, const uint64_t* d_roff, const uint64_t* d_poff,
+                               uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles,
+                               const uint32_t* offs, uint16_t* k16, uint32_t* idx, Rec* out_rec,
+                               uint32_t* range_start, uint32_t* max_load) {
+    (void)hipFuncSetAttribute((const void*)k_range_partition<MODE, OUT_REC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
+    hipLaunchKernelGGL((k_range_partition<MODE, OUT_REC>), grid, dim3(kPartThreads), kPartLds, st, keys,
+                       recs_in, seg, d_roff, d_poff, n_contigs, n, shift, n_tiles, offs, k16, idx, out_rec,
+                       range_start, max_load);
+}
 
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
@@ -3128,18 +3250,45 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
                             uint32_t* idx_out, uint32_t* range_start, uint32_t* max_load) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
-    const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles), block(kPartThreads);
-    if (gstart_or_null) {
-        (void)hipFuncSetAttribute((const void*)k_range_partition<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
-        hipLaunchKernelGGL(k_range_partition<false>, grid, block, kPartLds, st, gstart_or_null, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out, range_start, max_load);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_range_partition<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
-        hipLaunchKernelGGL(k_range_partition<true>, grid, block, kPartLds, st, starts, d_roff, d_poff,
-                           n_contigs, n, shift, n_tiles, offs, keys16_out, idx_out, range_start, max_load);
-    }
+    const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles);
+    const SegTables none{nullptr, nullptr, nullptr};
+    if (gstart_or_null)
+        launch_partition_t<0, false>(st, grid, gstart_or_null, nullptr, none, d_roff, d_poff, n_contigs, n, shift,
+                                     n_tiles, offs, keys16_out, idx_out, nullptr, range_start, max_load);
+    else
+        launch_partition_t<1, false>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift,
+                                     n_tiles, offs, keys16_out, idx_out, nullptr, range_start, max_load);
+}
+
+// Two-level route.  Level 1: stable partition of the reads into <= 256 super-ranges of 2^(shift+8)
+// positions, as {global start, index} records; its first workgroup publishes super_start[257].
+void launch_partition_level1(hipStream_t st, const uint32_t* starts, const uint64_t* d_roff,
+                             const uint64_t* d_poff, uint32_t n_contigs, uint32_t n, uint32_t shift_hi,
+                             const uint32_t* offs, void* recs_out, uint32_t* super_start,
+                             uint32_t* max_super_load) {
+    const uint32_t n_tiles = sort_tiles(n);
+    if (n_tiles == 0) return;
+    const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles);
+    const SegTables none{nullptr, nullptr, nullptr};
+    launch_partition_t<1, true>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift_hi, n_tiles,
+                                offs, nullptr, nullptr, (Rec*)recs_out, super_start, max_super_load);
+}
+// Level 2: every super-range is partitioned on its own into its (<= 256) final ranges.
+// tables: [0,257) super_start  [257,514) tile_base  [514,771) pass_base (written here)
+uint32_t seg_tile_bound(uint32_t n) { return sort_tiles(n) + 256; }  // upper bound of the tile count
+void launch_partition_level2(hipStream_t st, const void* recs_in, uint32_t n, uint32_t shift,
+                             uint32_t* tables, uint32_t* hist, uint32_t* spine, uint16_t* keys16_out,
+                             uint32_t* idx_out, uint32_t* range_start, uint32_t* max_load) {
+    const SegTables seg{tables, tables + 257, tables + 514};
+    const uint32_t t_bound = seg_tile_bound(n);
+    hipLaunchKernelGGL(k_seg_tables, dim3(1), dim3(256), 0, st, tables, tables + 257, tables + 514, max_load);
+    (void)hipMemsetAsync(hist, 0, (size_t)256 * t_bound * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_seg_hist, dim3(t_bound), dim3(kSortThreads), 0, st, (const Rec*)recs_in, seg, shift, hist);
+    launch_exclusive_scan(st, hist, 256u * t_bound, hist, spine, false);
+    launch_partition_t<2, false>(st, dim3((t_bound + kPartTiles - 1) / kPartTiles + 256), nullptr,
+                                 (const Rec*)recs_in, seg, nullptr, nullptr, 0, n, shift, 0, hist, keys16_out,
+                                 idx_out, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_seg_range_table, dim3(256), dim3(256), 0, st, hist, seg, n, range_start, max_load);
 }
 
 // global start position per read (what k_prepare writes when asked to): for the routes that need
@@ -3173,19 +3322,23 @@ void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t
     hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, range_start, shift,
                        ltot, boff);
 }
-size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot) {
-    return (size_t)((ltot >> shift) + 1) * ((size_t)1 << shift) * sizeof(uint2);
+bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n) {
+    return (size_t)n < (size_t)((ltot >> shift) + 1) * ((size_t)1 << shift);
+}
+size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot, uint32_t n) {
+    const size_t by_pos = (size_t)((ltot >> shift) + 1) * ((size_t)1 << shift);
+    return (by_pos < (size_t)n ? by_pos : (size_t)n) * sizeof(uint2) + 64;
 }
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
-                      void* scratch) {
+                      void* scratch, bool scratch_by_records) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx, range_start,
-                       shift, ltot, boff, selend, mask, kept_total, (uint2*)scratch);
+                       shift, ltot, boff, selend, mask, kept_total, (uint2*)scratch, scratch_by_records ? 1 : 0);
 }
 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,

@@ -153,3 +153,30 @@ def test_ranked_route_many_small_contigs(pkg, oracle, solver):
     got = solver.solve(s, e, lengths, 12, contig_read_offsets=offs)
     assert solver.last_stats.sort_passes == 1 and solver.last_stats.n_contigs == 40
     assert np.array_equal(got, oracle.solve(s, e, lengths, 12, contig_read_offsets=offs))
+
+
+def test_two_level_partition_beyond_256_ranges(pkg, oracle, solver):
+    """genomes beyond 8.39 M positions need more than 256 ranges of 32 Ki: the reads go first into
+    super-ranges, then every super-range into its ranges; contigs straddle both kinds of border"""
+    rng = np.random.default_rng(31)
+    lengths = np.array([9_000_001, 5_000_000, 8_388_608 + 5, 123], np.uint32)   # Ltot ~ 22.4 M
+    counts = np.array([900_000, 480_000, 850_000, 0])                           # the tiny contig has no reads
+    span = 150
+    ss, ee = zip(*[_uniform_reads(rng, int(c), int(L), span) for c, L in zip(counts[:3], lengths[:3])])
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    got, passes, sorted_route, _ = _solve_both_routes(solver, s, e, lengths, 6, offs)
+    assert passes == 1 and solver.last_stats.n_contigs == 4
+    assert np.array_equal(got, sorted_route)
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 6, contig_read_offsets=offs))
+
+
+def test_two_level_partition_piled_up_super_range(pkg, oracle, solver):
+    """one super-range holds almost everything, most super-ranges are empty"""
+    rng = np.random.default_rng(37)
+    L, span, n = 40_000_000, 101, 600_000
+    s = rng.integers(20_000_000, 20_400_000, size=n, dtype=np.uint32)
+    s[:2000] = rng.integers(0, L - span, size=2000, dtype=np.uint32)     # a few reads everywhere else
+    e = (s + np.uint32(span - 1)).astype(np.uint32)
+    got = solver.solve(s, e, L, 9)
+    assert np.array_equal(got, oracle.solve(s, e, L, 9))
