@@ -2249,7 +2249,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
 // single-wave general block the fast kernel falls back to.
 template <int E>
 struct MgLayout {
-    static constexpr int kG = 4;              // blocks per group
+    static constexpr int kG = E <= 3 ? 8 : 4; // blocks per group (LDS: 3 slots x kG x kWords x 256 B)
     static constexpr int kA = 0;              // [6] a before each scan step          PREP -> CHAIN
     static constexpr int kB = 6;              // [6] b before each scan step          PREP -> CHAIN
     static constexpr int kPa = 12;            // [1] a of all lower lanes (0: none)   PREP -> CHAIN
@@ -2258,10 +2258,10 @@ struct MgLayout {
     static constexpr int kEx = 14 + E;        // [E] ex at the jump landing           PREP -> CHAIN
     static constexpr int kX0 = 14 + 2 * E;    // [E] bucket offsets                   PREP -> CHECK
     static constexpr int kDn = 14 + 3 * E;    // [E] distances                        CHAIN -> CHECK
-    static constexpr int kDin = 14 + 4 * E;   // [1] block 0 only: d entering the group
-    static constexpr int kWords = 15 + 4 * E;
+    static constexpr int kWords = 14 + 4 * E;
     static constexpr int kSlots = 3;
-    static constexpr size_t kBytes = (size_t)kSlots * kG * kWords * 64 * sizeof(uint32_t) + 64;
+    // + per slot one row of 64 words: d entering the group (CHAIN -> CHECK)
+    static constexpr size_t kBytes = ((size_t)kSlots * kG * kWords + kSlots) * 64 * sizeof(uint32_t);
 };
 
 template <int E>
@@ -2276,8 +2276,9 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t role = wv == 3 ? 1u : (wv >= 5 ? 2u : 0u);  // 0 PREP, 1 CHAIN, 2 CHECK
-    const uint32_t pblk = wv == 4 ? 3u : wv;                   // PREP: its block of the group
-    const uint32_t cblk = 2 * (wv - 5);                        // CHECK: first of its two blocks
+    constexpr int kPB = kG / 4, kCB = kG / 2;                  // blocks per PREP wave / per CHECK wave
+    const uint32_t pblk = kPB * (wv == 4 ? 3u : wv);           // PREP: first of its blocks of the group
+    const uint32_t cblk = kCB * (wv - 5);                      // CHECK: first of its blocks
     const uint32_t c_id = blockIdx.x;
     const uint32_t base = (uint32_t)contig_pos_off[c_id];
     const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
@@ -2305,64 +2306,69 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
 #define MG_SLOT0(idx) (s_mw + (size_t)(idx) * kG * Ly::kWords * 64)
 #define MG_SLOT(idx) (MG_SLOT0(idx) + lane)
 #define MG_AT(slot, k, w) (slot)[((k) * Ly::kWords + (w)) * 64]
+#define MG_DIN(idx) (s_mw + ((size_t)Ly::kSlots * kG * Ly::kWords + (idx)) * 64 + lane)[0]
 
     if (role == 0) {
         // PREP: one block of every group; rows three stages ahead in three register sets (see
         // k_sweep_uniform_mw); its own unrolled copy of the stage loop
         constexpr uint32_t kD = 3;
-        RowRaw<E> R0[3], R1[3], R2[3];
-        auto issue_rows = [&](RowRaw<E> (&buf)[3], uint32_t g) {
+        constexpr int kRows = kPB + 2;  // rows its blocks need
+        RowRaw<E> R0[kRows], R1[kRows], R2[kRows];
+        auto issue_rows = [&](RowRaw<E> (&buf)[kRows], uint32_t g) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) row_issue<E>(cb, (g * kG + pblk + k) * ell, L, lane, buf[k]);
+            for (int k = 0; k < kRows; ++k) row_issue<E>(cb, (g * kG + pblk + k) * ell, L, lane, buf[k]);
         };
         issue_rows(R0, 0);
         issue_rows(R1, 1);
         issue_rows(R2, 2);
-        auto pstage = [&](RowRaw<E> (&buf)[3], uint32_t t) {
+        auto pstage = [&](RowRaw<E> (&buf)[kRows], uint32_t t) {
             if (t < n_groups) {
-                uint32_t* const slot = MG_SLOT(t % Ly::kSlots) + pblk * Ly::kWords * 64;
-                uint32_t Wr[3][E];
+                uint32_t Wr[kRows][E];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) row_finish<E>(buf[k], Wr[k]);
+                for (int k = 0; k < kRows; ++k) row_finish<E>(buf[k], Wr[k]);
                 __builtin_amdgcn_sched_barrier(0);
                 issue_rows(buf, t + kD);
                 __builtin_amdgcn_sched_barrier(0);
-                SweepLoads<E> ld;
-                rows_to_loads<E>(Wr[0], Wr[1], Wr[2], lane, last_lane, last_r, ld);
-                BlockTerms<E> bt;
-                block_terms<E>(ld, (t * kG + pblk) * ell, ell, L, M, lane, bt);
-                // the lane's own (a, b): composition of its E single-position maps
-                uint32_t a = bt.cnt[0], b = bt.cnt[0] + bt.exj[0];
 #pragma unroll
-                for (int r = 1; r < E; ++r) {
-                    const uint32_t a2 = bt.cnt[r], b2 = bt.cnt[r] + bt.exj[r];
-                    const uint32_t na = min(a + a2, b), nb = min(a + b2, b);
-                    a = na; b = nb;
-                }
-                // the (a, b) half of the wave scan, recording what each lane holds before every step
-#define MG_AB_STEP(s, ctrl, rmask)                                                     \
-                {                                                                      \
-                    MG_AT(slot, 0, Ly::kA + (s)) = a;                                  \
-                    MG_AT(slot, 0, Ly::kB + (s)) = b;                                  \
-                    const uint32_t aL = QMCP_DPP(0u, a, ctrl, rmask);                  \
-                    const uint32_t bL = QMCP_DPP(kInf, b, ctrl, rmask);                \
-                    const uint32_t na = min(aL + a, bL), nb = min(aL + b, bL);         \
-                    a = na; b = nb;                                                    \
-                }
-                MG_AB_STEP(0, 0x111, 0xF)
-                MG_AB_STEP(1, 0x112, 0xF)
-                MG_AB_STEP(2, 0x114, 0xF)
-                MG_AB_STEP(3, 0x118, 0xF)
-                MG_AB_STEP(4, 0x142, 0xA)
-                MG_AB_STEP(5, 0x143, 0xC)
+                for (int kk = 0; kk < kPB; ++kk) {
+                    uint32_t* const slot = MG_SLOT(t % Ly::kSlots) + (pblk + kk) * Ly::kWords * 64;
+                    SweepLoads<E> ld;
+                    rows_to_loads<E>(Wr[kk], Wr[kk + 1], Wr[kk + 2], lane, last_lane, last_r, ld);
+                    BlockTerms<E> bt;
+                    block_terms<E>(ld, (t * kG + pblk + kk) * ell, ell, L, M, lane, bt);
+                    // the lane's own (a, b): composition of its E single-position maps
+                    uint32_t a = bt.cnt[0], b = bt.cnt[0] + bt.exj[0];
+#pragma unroll
+                    for (int r = 1; r < E; ++r) {
+                        const uint32_t a2 = bt.cnt[r], b2 = bt.cnt[r] + bt.exj[r];
+                        const uint32_t na = min(a + a2, b), nb = min(a + b2, b);
+                        a = na; b = nb;
+                    }
+                    // the (a, b) half of the wave scan, recording what each lane holds before every step
+#define MG_AB_STEP(s, ctrl, rmask)                                                         \
+                    {                                                                      \
+                        MG_AT(slot, 0, Ly::kA + (s)) = a;                                  \
+                        MG_AT(slot, 0, Ly::kB + (s)) = b;                                  \
+                        const uint32_t aL = QMCP_DPP(0u, a, ctrl, rmask);                  \
+                        const uint32_t bL = QMCP_DPP(kInf, b, ctrl, rmask);                \
+                        const uint32_t na = min(aL + a, bL), nb = min(aL + b, bL);         \
+                        a = na; b = nb;                                                    \
+                    }
+                    MG_AB_STEP(0, 0x111, 0xF)
+                    MG_AB_STEP(1, 0x112, 0xF)
+                    MG_AB_STEP(2, 0x114, 0xF)
+                    MG_AB_STEP(3, 0x118, 0xF)
+                    MG_AB_STEP(4, 0x142, 0xA)
+                    MG_AB_STEP(5, 0x143, 0xC)
 #undef MG_AB_STEP
-                MG_AT(slot, 0, Ly::kPa) = QMCP_DPP(0u, a, 0x138, 0xF);     // all lower lanes (lane 0: identity)
-                MG_AT(slot, 0, Ly::kPb) = QMCP_DPP(kInf, b, 0x138, 0xF);
+                    MG_AT(slot, 0, Ly::kPa) = QMCP_DPP(0u, a, 0x138, 0xF);     // all lower lanes (lane 0: identity)
+                    MG_AT(slot, 0, Ly::kPb) = QMCP_DPP(kInf, b, 0x138, 0xF);
 #pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    MG_AT(slot, 0, Ly::kCnt + r) = bt.cnt[r];
-                    MG_AT(slot, 0, Ly::kEx + r) = bt.exj[r];
-                    MG_AT(slot, 0, Ly::kX0 + r) = ld.x0[r];
+                    for (int r = 0; r < E; ++r) {
+                        MG_AT(slot, 0, Ly::kCnt + r) = bt.cnt[r];
+                        MG_AT(slot, 0, Ly::kEx + r) = bt.exj[r];
+                        MG_AT(slot, 0, Ly::kX0 + r) = ld.x0[r];
+                    }
                 }
             }
             __syncthreads();
@@ -2382,7 +2388,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                     const uint32_t g = t - 1;
                     uint32_t* const slot = MG_SLOT(g % Ly::kSlots);
                     const uint32_t* const slot0 = MG_SLOT0(g % Ly::kSlots);
-                    MG_AT(slot, 0, Ly::kDin) = d_last;
+                    MG_DIN(g % Ly::kSlots) = d_last;
 #pragma unroll
                     for (int k = 0; k < kG; ++k) {
                         uint32_t cnt[E], exj[E];
@@ -2466,12 +2472,12 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                     uint32_t* const slot = MG_SLOT(g % Ly::kSlots);
                     const uint32_t* const slot0 = MG_SLOT0(g % Ly::kSlots);
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
+                    for (int kk = 0; kk < kCB; ++kk) {
                         const uint32_t k = cblk + kk;
                         uint32_t dn[E];
 #pragma unroll
                         for (int r = 0; r < E; ++r) dn[r] = MG_AT(slot, k, Ly::kDn + r);
-                        const uint32_t d_blk = k == 0 ? MG_AT(slot, 0, Ly::kDin)
+                        const uint32_t d_blk = k == 0 ? MG_DIN(g % Ly::kSlots)
                                                       : slot0[(((k - 1) * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
                         uint32_t prev = QMCP_DPP(0u, dn[E - 1], 0x138, 0xF);
                         prev = lane == 0 ? d_blk : prev;
@@ -2507,6 +2513,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
         }
     }
 #undef MG_AT
+#undef MG_DIN
 #undef MG_SLOT
 #undef MG_SLOT0
     if (role == 1) {
