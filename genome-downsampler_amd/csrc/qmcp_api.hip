@@ -644,7 +644,14 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                 qmcp::launch_reverse_min_scan(c->stream, (uint32_t*)c->next_head.p, n + 1,
                                               (uint32_t*)c->spine.p);
             }
-            KernelSpan sp(c, "k_sweep_general_cached");
+            // spans up to 448: the window of live buckets fits the wave's registers (8 per lane)
+            const bool in_regs = max_span + 64 <= 512 && std::getenv("QMCP_HIP_GENERAL_LDS") == nullptr;
+            KernelSpan sp(c, in_regs ? "k_sweep_general_reg" : "k_sweep_general_cached");
+            if (!in_regs ||
+                !qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p,
+                                                (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                                (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
+                                                n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p))
             qmcp::launch_sweep_general_cached(c->stream, wide, (const uint32_t*)c->boff.p,
                                               (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                               (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,

@@ -55,6 +55,10 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
                                  const uint64_t* d_poff, uint32_t n_contigs, uint32_t span_bits,
                                  uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring);
 // `sorted` is a Rec{key,val} array (wide == false) or u64 keys with `svals` beside them
+bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
+                              const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
+                              uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
+                              uint32_t* selend);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
                  unsigned long long* n_kept);

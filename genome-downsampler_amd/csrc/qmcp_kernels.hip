@@ -2802,6 +2802,152 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
 // One thread per start position walks that bucket's selected prefix [boff[q], selend[q]) --
 // at most M entries, usually 0..2 -- and sets the kept reads' bits: the sorted records of the
 // other ~95 % of the reads are never touched.
+// Register-resident form of the cached event sweep, for max_span + 64 <= 64 * B: the window of
+// live buckets is at most 64 * B positions wide, so every lane OWNS B of them (bucket q belongs to
+// lane q % 64, slot (q / 64) % B) and keeps their head group, cached second group, read pointers
+// and selected count in registers.  A selection event is then: every lane's best over its own B
+// slots (register compares), a fused-DPP wave maximum, and a register update in the winning lane
+// -- no LDS round trip on the serial path (the LDS version pays three or four per event).  Only
+// the expiry counts of reads that end beyond the current 64-position chunk go through an LDS
+// ring (fire-and-forget adds, read back one chunk later).  The chunk loop is unrolled B times so
+// that the slot a chunk's buckets enter is a compile-time index.
+template <typename Sorted, int B>
+__global__ __launch_bounds__(64) void k_sweep_general_reg(
+    const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
+    const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend) {
+    constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
+    __shared__ uint32_t s_exp[kRing];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    if (L == 0) return;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    for (uint32_t i = lane; i < kRing; i += 64) s_exp[i] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ cb = boff + base;
+    const uint32_t* __restrict__ ce = eoff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    // per owned bucket: head group (end + 1, run), cached second group, next unread group, bucket
+    // end, reads selected so far
+    uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bend1[B], taken[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
+    uint32_t cur = 0;
+    const uint32_t n_chunks = (L + 63) / 64;
+
+    auto load_group = [&](uint32_t j, uint32_t b1, uint32_t q, uint32_t& gx, uint32_t& gy) {
+        // group starting at sorted index j of the bucket of position q ending at b1 (gy = 0: none)
+        gx = 0; gy = 0;
+        if (j < b1) {
+            const uint64_t kk = skeys.key(j);
+            gy = min(next_head[j + 1], b1) - j;
+            gx = q + (max_span - (uint32_t)(kk & code_mask));  // end + 1
+        }
+    };
+
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += B) {
+#pragma unroll
+        for (int e = 0; e < B; ++e) {
+            const uint32_t c = c0 + e;
+            if (c >= n_chunks) break;
+            const uint32_t p0 = c * 64;
+            // ---- the chunk's 64 buckets enter slot e (lane = position p0 + lane)
+            const uint32_t q = p0 + lane;
+            uint32_t need = 0, exp_c = 0;
+            if (c >= (uint32_t)B && q - kRing < L) csel[q - kRing] = cb[q - kRing] + taken[e];  // recycled slot
+            g0x[e] = g0y[e] = g1x[e] = g1y[e] = 0; nextj[e] = bend1[e] = taken[e] = 0;
+            if (q < L) {
+                exp_c = s_exp[q % kRing];
+                s_exp[q % kRing] = 0;
+                const uint32_t b0 = cb[q], b1 = cb[q + 1];
+                need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
+                bend1[e] = b1;
+                load_group(b0, b1, q, g0x[e], g0y[e]);
+                load_group(b0 + g0y[e], b1, q, g1x[e], g1y[e]);
+                nextj[e] = b0 + g0y[e] + g1y[e];
+            }
+            // ---- walk the chunk's positions
+            const uint32_t chunk = min(64u, L - p0);
+            for (uint32_t j = 0; j < chunk; ++j) {
+                const uint32_t p = p0 + j;
+                const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
+                uint32_t k = need_p > cur ? need_p - cur : 0u;
+                while (k > 0) {
+                    // this lane's best live head: key = (end + 1 - p) << 16 | (0xFFFF - (p - q')):
+                    // largest end, then largest start; the bucket of slot b sits at
+                    // q' = p0 - 64 * ((e - b + B) % B) + lane
+                    uint32_t best = 0, my_run = 0, my_slot = 0;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const uint32_t back = 64u * (uint32_t)((e - b + B) % B);   // chunks ago, in positions
+                        const uint32_t t = j + back - lane;                           // p - q' (wraps if q' > p)
+                        const bool live = g0x[b] > p && (back != 0 || lane <= j) && p0 + lane >= back;
+                        const uint32_t key = live ? (((g0x[b] - p) << 16) | (0xFFFFu - t)) : 0u;
+                        if (key > best) { best = key; my_run = g0y[b]; my_slot = b; }
+                    }
+                    uint32_t top = best;
+                    top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+                    top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+                    top = __builtin_amdgcn_readlane(top, 63);
+                    if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+                    const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
+                    const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
+                    const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group
+                    const uint32_t take = min(k, run);
+                    // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+                    if (bend < p0 + 64) {
+                        exp_c += (lane == bend - p0) ? take : 0u;
+                    } else if (lane == 0) {
+                        atomicAdd(&s_exp[bend % kRing], take);
+                    }
+                    // the winning lane updates its own bucket in registers; the slot is made uniform so
+                    // that only that slot's code runs
+                    const uint32_t wslot = __builtin_amdgcn_readlane(my_slot, src);
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        if (wslot == (uint32_t)b) {
+                            if (lane == src) {
+                                taken[b] += take;
+                                if (take < run) {
+                                    g0y[b] = run - take;
+                                } else if (g1y[b] != 0) {
+                                    g0x[b] = g1x[b]; g0y[b] = g1y[b]; g1y[b] = 0;   // promote the cached group
+                                } else {
+                                    // both cached groups used: fetch the bucket's next group, if any
+                                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);
+                                    load_group(nextj[b], bend1[b], p0 + lane - back, g0x[b], g0y[b]);
+                                    nextj[b] += g0y[b];
+                                }
+                            }
+                        }
+                    }
+                    cur += take;
+                    k -= take;
+                }
+                // reads ending at p stop covering p + 1
+                cur -= __builtin_amdgcn_readlane(exp_c, j);
+            }
+        }
+    }
+    // flush the buckets still owned
+    const uint32_t last_c = n_chunks - 1;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // the most recent chunk that filled slot b
+        if (last_c >= (uint32_t)b) {
+            const uint32_t cc = last_c - ((last_c - (uint32_t)b) % (uint32_t)B);
+            const uint32_t qq = cc * 64 + lane;
+            if (qq < L) csel[qq] = cb[qq] + taken[b];
+        }
+    }
+}
+
 template <typename Keys>
 __global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t ltot,
                                               const uint32_t* __restrict__ boff,
@@ -3141,6 +3287,31 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span,
                            M, selend, ring);
     }
+}
+
+// register-resident event sweep: buckets per lane B = ceil((max_span + 64) / 64), up to 8
+bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
+                              const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
+                              uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
+                              uint32_t* selend) {
+    const uint32_t b = (max_span + 64 + 63) / 64;
+#define QMCP_GEN_REG(BB)                                                                              \
+    if (wide)                                                                                          \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
+                           eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
+                           max_span, M, selend);                                                       \
+    else                                                                                               \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
+                           eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
+                           M, selend);
+    if (b <= 2) { QMCP_GEN_REG(2) }
+    else if (b == 3) { QMCP_GEN_REG(3) }
+    else if (b == 4) { QMCP_GEN_REG(4) }
+    else if (b <= 6) { QMCP_GEN_REG(6) }
+    else if (b <= 8) { QMCP_GEN_REG(8) }
+    else return false;
+#undef QMCP_GEN_REG
+    return true;
 }
 
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
