@@ -2815,7 +2815,11 @@ template <typename Sorted, int B>
 __global__ __launch_bounds__(64) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
-    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend) {
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend
+#ifdef QMCP_GEN_STAMP
+    , unsigned long long* __restrict__ stamps  // lab builds: [0] entry cycles [1] events [2] event cycles [3] fetches [4] fetch cycles [5] walk cycles
+#endif
+    ) {
     constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
     __shared__ uint32_t s_exp[kRing];
     const uint32_t lane = threadIdx.x;
@@ -2853,6 +2857,9 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
             const uint32_t c = c0 + e;
             if (c >= n_chunks) break;
             const uint32_t p0 = c * 64;
+#ifdef QMCP_GEN_STAMP
+            const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
             // ---- the chunk's 64 buckets enter slot e (lane = position p0 + lane)
             const uint32_t q = p0 + lane;
             uint32_t need = 0, exp_c = 0;
@@ -2868,25 +2875,43 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
                 load_group(b0 + g0y[e], b1, q, g1x[e], g1y[e]);
                 nextj[e] = b0 + g0y[e] + g1y[e];
             }
+#ifdef QMCP_GEN_STAMP
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
+            unsigned long long st_ev = 0, st_nev = 0, st_fe = 0, st_nfe = 0;
+#endif
+            // ---- this lane's best head over the buckets it owns, kept up to date incrementally.
+            // key = (end + 1 - pbase) << 16 | (q' - pbase), pbase = p0 - 64 (B - 1): largest end first,
+            // then largest start; valid for this chunk.  Its head group is live at p iff end >= p; if the
+            // lane's best is dead so is everything else it owns (smaller ends).
+            const uint32_t pbase = p0 - 64u * (uint32_t)(B - 1);  // (wraps for the first chunks: consistently)
+            uint32_t lbest = 0, lrun = 0, lslot = 0, key_e = 0;
+            auto lane_best = [&](bool with_entering) {
+                lbest = 0; lrun = 0; lslot = 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);   // chunks ago, in positions
+                    const uint32_t qrel = 64u * (uint32_t)(B - 1) - back + lane; // q' - pbase
+                    const uint32_t key = g0y[b] != 0 ? (((g0x[b] - pbase) << 16) | qrel) : 0u;
+                    if (b == e) key_e = key;
+                    const bool started = b != e || with_entering;
+                    if (started && key > lbest) { lbest = key; lrun = g0y[b]; lslot = b; }
+                }
+            };
+            lane_best(false);
             // ---- walk the chunk's positions
             const uint32_t chunk = min(64u, L - p0);
             for (uint32_t j = 0; j < chunk; ++j) {
                 const uint32_t p = p0 + j;
+                // the bucket of position p starts now
+                if (lane == j && key_e > lbest) { lbest = key_e; lrun = g0y[e]; lslot = e; }
                 const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
                 uint32_t k = need_p > cur ? need_p - cur : 0u;
                 while (k > 0) {
-                    // this lane's best live head: key = (end + 1 - p) << 16 | (0xFFFF - (p - q')):
-                    // largest end, then largest start; the bucket of slot b sits at
-                    // q' = p0 - 64 * ((e - b + B) % B) + lane
-                    uint32_t best = 0, my_run = 0, my_slot = 0;
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const uint32_t back = 64u * (uint32_t)((e - b + B) % B);   // chunks ago, in positions
-                        const uint32_t t = j + back - lane;                           // p - q' (wraps if q' > p)
-                        const bool live = g0x[b] > p && (back != 0 || lane <= j) && p0 + lane >= back;
-                        const uint32_t key = live ? (((g0x[b] - p) << 16) | (0xFFFFu - t)) : 0u;
-                        if (key > best) { best = key; my_run = g0y[b]; my_slot = b; }
-                    }
+#ifdef QMCP_GEN_STAMP
+                    const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
+#endif
+                    const uint32_t best = (lbest >> 16) > p - pbase ? lbest : 0u;  // live: end + 1 > p
                     uint32_t top = best;
                     top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
                     top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
@@ -2897,8 +2922,8 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
                     top = __builtin_amdgcn_readlane(top, 63);
                     if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
                     const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
-                    const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
-                    const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group
+                    const uint32_t run = __builtin_amdgcn_readlane(lrun, src);
+                    const uint32_t bend = pbase + (top >> 16) - 1;  // end of the winning group
                     const uint32_t take = min(k, run);
                     // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
                     if (bend < p0 + 64) {
@@ -2908,7 +2933,7 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
                     }
                     // the winning lane updates its own bucket in registers; the slot is made uniform so
                     // that only that slot's code runs
-                    const uint32_t wslot = __builtin_amdgcn_readlane(my_slot, src);
+                    const uint32_t wslot = __builtin_amdgcn_readlane(lslot, src);
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
                         if (wslot == (uint32_t)b) {
@@ -2921,18 +2946,50 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
                                 } else {
                                     // both cached groups used: fetch the bucket's next group, if any
                                     const uint32_t back = 64u * (uint32_t)((e - b + B) % B);
+#ifdef QMCP_GEN_STAMP
+                                    const unsigned long long st_f0 = __builtin_amdgcn_s_memtime();
+#endif
                                     load_group(nextj[b], bend1[b], p0 + lane - back, g0x[b], g0y[b]);
                                     nextj[b] += g0y[b];
+#ifdef QMCP_GEN_STAMP
+                                    __builtin_amdgcn_s_waitcnt(0);
+                                    st_fe += __builtin_amdgcn_s_memtime() - st_f0;
+                                    st_nfe += 1;
+#endif
                                 }
                             }
                         }
                     }
+                    if (lane == src) lane_best(lane <= j);  // its bucket changed: the lane's best again
                     cur += take;
                     k -= take;
+#ifdef QMCP_GEN_STAMP
+                    st_ev += __builtin_amdgcn_s_memtime() - st_v0;
+                    st_nev += 1;
+#endif
                 }
                 // reads ending at p stop covering p + 1
                 cur -= __builtin_amdgcn_readlane(exp_c, j);
             }
+#ifdef QMCP_GEN_STAMP
+            {
+                const unsigned long long st_w = __builtin_amdgcn_s_memtime() - st_e1;
+                // fetch counters live in the winning lanes: reduce over the wave
+                unsigned long long fe = 0, nfe = 0;
+                for (int l = 0; l < 64; ++l) {
+                    fe += __shfl((unsigned long long)st_fe, l, 64);
+                    nfe += __shfl((unsigned long long)st_nfe, l, 64);
+                }
+                if (lane == 0 && stamps) {
+                    atomicAdd(&stamps[0], st_e1 - st_e0);
+                    atomicAdd(&stamps[1], st_nev);
+                    atomicAdd(&stamps[2], st_ev);
+                    atomicAdd(&stamps[3], nfe);
+                    atomicAdd(&stamps[4], fe);
+                    atomicAdd(&stamps[5], st_w);
+                }
+            }
+#endif
         }
     }
     // flush the buckets still owned
@@ -3295,15 +3352,20 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
                               uint32_t* selend) {
     const uint32_t b = (max_span + 64 + 63) / 64;
+#ifdef QMCP_GEN_STAMP
+#define QMCP_GEN_STAMP_ARG , (unsigned long long*)nullptr
+#else
+#define QMCP_GEN_STAMP_ARG
+#endif
 #define QMCP_GEN_REG(BB)                                                                              \
     if (wide)                                                                                          \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
-                           max_span, M, selend);                                                       \
+                           max_span, M, selend QMCP_GEN_STAMP_ARG);                                    \
     else                                                                                               \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
-                           M, selend);
+                           M, selend QMCP_GEN_STAMP_ARG);
     if (b <= 2) { QMCP_GEN_REG(2) }
     else if (b == 3) { QMCP_GEN_REG(3) }
     else if (b == 4) { QMCP_GEN_REG(4) }
@@ -3311,6 +3373,7 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
     else if (b <= 8) { QMCP_GEN_REG(8) }
     else return false;
 #undef QMCP_GEN_REG
+#undef QMCP_GEN_STAMP_ARG
     return true;
 }
 
