@@ -21,7 +21,7 @@ all: lib oracle harness
 
 lib: $(LIBDIR)/libqmcp_hip.so $(LIBDIR)/libqmcp_host.so
 
-$(LIBDIR)/qmcp_kernels.o: $(CSRC)/qmcp_kernels.hip $(CSRC)/qmcp_kernels.h
+$(LIBDIR)/qmcp_kernels.o: $(CSRC)/qmcp_kernels.hip $(CSRC)/qmcp_kernels.h $(wildcard $(CSRC)/kernels/*.inc.hip)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,277 @@
+// prepare_scan.inc.hip -- part of qmcp_kernels.hip (one translation unit; included inside namespace qmcp).
+// ------------------------------------------------------------------ prepare
+// One pass over the reads: validate (start <= end < contig length), reduce min/max span,
+// write the global start position of every read (the bucketing key of the uniform path) and
+// count reads per start position.  Reference counterpart: the read loop of
+// create_b_function (quasi_mcp_cpu_max_flow_solver.cpp:61-67) -- here O(1) per read.
+//
+// stats[0] = min span, stats[1] = max span, stats[2] = error flag
+__global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ starts,
+                                                 const uint32_t* __restrict__ ends, uint32_t n,
+                                                 const uint64_t* __restrict__ contig_read_off,
+                                                 const uint64_t* __restrict__ contig_pos_off,
+                                                 uint32_t n_contigs,
+                                                 const uint64_t* __restrict__ keep_mask,
+                                                 uint32_t* __restrict__ gstart_out,
+                                                 uint32_t* __restrict__ cstart,
+                                                 uint32_t* __restrict__ stats,
+                                                 uint32_t n_tiles, uint32_t tiles_per_block,
+                                                 uint32_t part_shift,
+                                                 uint32_t* __restrict__ part_hist,
+                                                 uint32_t* __restrict__ digit0_hist,
+                                                 uint32_t* __restrict__ global_digit_hist,
+                                                 unsigned long long* __restrict__ zero_mask) {
+    __shared__ uint32_t s_gh[4][256];  // whole-call digit histograms of the start key (all 4 bytes)
+    if (global_digit_hist) {
+        for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_gh[0][0])[i] = 0;
+    }
+    __shared__ uint64_t s_roff[65];
+    __shared__ uint64_t s_poff[65];
+    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_h0[256];
+    const uint32_t nc = min(n_contigs, 64u);
+    for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
+        s_roff[i] = contig_read_off[i];
+        s_poff[i] = contig_pos_off[i];
+    }
+    __syncthreads();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
+    // Work is laid out in the radix tiles (4096 reads) so that per-tile histograms fall out of
+    // the same pass: the range partition's (digit = global start >> part_shift) and, optionally,
+    // the first LSD radix pass's (digit = low byte of the global start).
+    const uint32_t t0 = blockIdx.x * tiles_per_block;
+    for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
+        const uint32_t tile = t0 + g;
+        if (part_hist) {
+            s_h[threadIdx.x] = 0;
+            s_h0[threadIdx.x] = 0;
+            __syncthreads();
+        }
+        // the tile's 64 words of the output keep mask are cleared here (saves a memset launch)
+        if (zero_mask && threadIdx.x < 64 && tile * 64u + threadIdx.x < (n + 63u) / 64u)
+            zero_mask[tile * 64u + threadIdx.x] = 0ull;
+        // all of the tile's loads first (32 in flight per thread), then the arithmetic
+        const uint32_t tbase = tile * 4096u;
+        const uint32_t tcount = min(4096u, n - tbase);
+        uint32_t sv[16], ev[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t j = k * 256u + threadIdx.x;
+            const uint32_t i = tbase + min(j, tcount - 1);  // clamped: every lane loads
+            sv[k] = starts[i];
+            ev[k] = ends[i];
+        }
+        // reads are grouped by contig, so almost every tile lies inside one contig
+        auto contig_of = [&](uint32_t i) {
+            uint32_t lo = 0, hi = n_contigs;  // last c with roff[c] <= i
+            if (n_contigs <= 64) {
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_roff[mid] <= i) lo = mid; else hi = mid;
+                }
+            } else {
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (contig_read_off[mid] <= i) lo = mid; else hi = mid;
+                }
+            }
+            return lo;
+        };
+        const uint32_t c_first = n_contigs > 1 ? contig_of(tbase) : 0u;
+        const uint32_t c_last = n_contigs > 1 ? contig_of(tbase + tcount - 1) : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t j = k * 256u + threadIdx.x;
+            if (j >= tcount) break;
+            const uint32_t i = tbase + j;
+            const uint32_t s = sv[k], e = ev[k];
+            const uint32_t c = c_first == c_last ? c_first : contig_of(i);
+            uint64_t p0, p1;
+            if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
+            else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
+            const uint32_t len_c = (uint32_t)(p1 - p0);
+            const uint32_t gs = (uint32_t)p0 + s;
+            if (s > e || e >= len_c) {
+                // the call will fail, but kernels queued behind this one before the host knows must
+                // stay in bounds: the read is counted under the digit the partition will compute
+                bad = 1;
+                if (gstart_out) gstart_out[i] = gs;
+                if (part_hist) atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+                continue;
+            }
+            const uint32_t span = e - s + 1;
+            mn = min(mn, span);
+            mx = max(mx, span);
+            if (gstart_out) gstart_out[i] = gs;
+            if (part_hist) {
+                atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+                if (digit0_hist) atomicAdd(&s_h0[gs & 255u], 1u);
+            }
+            if (global_digit_hist) {
+                // digit 0 is taken from s_h0 below when it exists; otherwise count it here too
+                if (!(part_hist && digit0_hist)) atomicAdd(&s_gh[0][gs & 255u], 1u);
+                atomicAdd(&s_gh[1][(gs >> 8) & 255u], 1u);
+                atomicAdd(&s_gh[2][(gs >> 16) & 255u], 1u);
+                atomicAdd(&s_gh[3][(gs >> 24) & 255u], 1u);
+            }
+            if (cstart) {
+                bool on = true;
+                if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
+                if (on) atomicAdd(&cstart[gs], 1u);
+            }
+        }
+        if (part_hist) {
+            __syncthreads();
+            part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
+            if (digit0_hist) {
+                digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
+                if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
+            }
+            __syncthreads();
+        }
+    }
+    if (global_digit_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) {
+            const uint32_t v = (&s_gh[0][0])[i];
+            if (v) atomicAdd(&global_digit_hist[i], v);
+        }
+    }
+    // block reduction, then at most one atomic per statistic per workgroup -- and none when the
+    // global value already dominates (same-address atomics serialise; thousands of them cost
+    // more than streaming the reads)
+    __shared__ uint32_t s_red[3][4];
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    bad = wave_max_u32(bad);
+    if ((threadIdx.x & 63) == 0) {
+        s_red[0][threadIdx.x >> 6] = mn;
+        s_red[1][threadIdx.x >> 6] = mx;
+        s_red[2][threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_red[0][0], s_red[0][1]), min(s_red[0][2], s_red[0][3]));
+        mx = max(max(s_red[1][0], s_red[1][1]), max(s_red[1][2], s_red[1][3]));
+        bad = s_red[2][0] | s_red[2][1] | s_red[2][2] | s_red[2][3];
+        if (mn < __hip_atomic_load(&stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(&stats[0], mn);
+        if (mx > __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&stats[1], mx);
+        if (bad) atomicOr(&stats[2], 1u);
+    }
+}
+
+// Mixed-span path: per-position end counts and the composite bucketing key
+// (gstart << span_bits) | (max_span - span): ascending key == (start asc, end desc).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_general_keys(const uint32_t* __restrict__ gstart,
+                                                      const uint32_t* __restrict__ starts,
+                                                      const uint32_t* __restrict__ ends,
+                                                      uint32_t n, uint32_t span_bits,
+                                                      uint32_t max_span,
+                                                      const uint64_t* __restrict__ keep_mask,
+                                                      KeyT* __restrict__ keys,
+                                                      uint32_t* __restrict__ ecnt) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t span = ends[i] - starts[i] + 1;
+        const uint32_t gs = gstart[i];
+        if (keys) keys[i] = ((KeyT)gs << span_bits) | (KeyT)(max_span - span);
+        if (ecnt) {
+            bool on = true;
+            if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
+            if (on) atomicAdd(&ecnt[gs + span - 1], 1u);
+        }
+    }
+}
+template __global__ void k_general_keys<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                  uint32_t, uint32_t, uint32_t, const uint64_t*,
+                                                  uint32_t*, uint32_t*);
+template __global__ void k_general_keys<uint64_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                  uint32_t, uint32_t, uint32_t, const uint64_t*,
+                                                  uint64_t*, uint32_t*);
+
+// ------------------------------------------------------------------ exclusive scan (u32)
+// Three launches: tile sums -> spine scan (one workgroup) -> tile scan with carried offset.
+// out may alias in.  out has n+1 entries when write_total is set (out[n] = grand total).
+static constexpr int kScanThreads = 256;
+static constexpr int kScanItems = 16;
+static constexpr int kScanTile = kScanThreads * kScanItems;  // 4096
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wave,
+                                                        uint32_t& block_total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan_add(v);
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = s_wave[k];
+        if (k < w) base += x;
+        tot += x;
+    }
+    block_total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t* __restrict__ in,
+                                                                  uint32_t n,
+                                                                  uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k * kScanThreads + threadIdx.x;
+        if (i < n) acc += in[i];
+    }
+    acc = wave_sum_u32(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// single workgroup, exclusive in place; spine[n_tiles] = total
+__global__ __launch_bounds__(kScanThreads) void k_scan_spine(uint32_t* __restrict__ spine,
+                                                              uint32_t n_tiles) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_tiles ? spine[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_256(v, s_wave, tot);
+        if (i < n_tiles) spine[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) spine[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint32_t* __restrict__ in,
+                                                              uint32_t n,
+                                                              const uint32_t* __restrict__ spine,
+                                                              uint32_t* __restrict__ out,
+                                                              int write_total) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        v[k] = i < n ? in[i] : 0;
+        sum += v[k];
+    }
+    uint32_t tot;
+    uint32_t run = spine[blockIdx.x] + block_excl_scan_256(sum, s_wave, tot);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+    if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = spine[gridDim.x];
+}

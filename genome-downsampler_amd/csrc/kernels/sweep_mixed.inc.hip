@@ -1,0 +1,474 @@
+// sweep_mixed.inc.hip -- part of qmcp_kernels.hip (one translation unit; included inside namespace qmcp).
+// ------------------------------------------------------------------ general (mixed-span) sweep
+// Event-driven form of the canonical rule for arbitrary spans.  Reads are bucketed by start
+// and ordered (end desc, index asc) inside a bucket, so the selected reads of a bucket are
+// always a prefix; the pool of candidates at position p is the set of bucket heads of the
+// last max_span start positions, compared by (end desc, start desc).
+// One wave per contig.  Two rings of `ring_size` (power of two > max_span) entries live in
+// LDS: the prefix pointer of every bucket still inside the window, and the number of
+// selected reads by end position (what stops covering when the sweep passes that end).
+// A bucket's pointer is flushed to selend (as an absolute offset) when its slot is recycled.
+struct SortedRec { const Rec* r; __device__ uint64_t key(uint32_t j) const { return r[j].key; } };
+struct SortedK64 { const uint64_t* k; __device__ uint64_t key(uint32_t j) const { return k[j]; } };
+
+template <typename Sorted>
+__global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict__ boff,
+                                                      const uint32_t* __restrict__ eoff,
+                                                      Sorted skeys,
+                                                      const uint64_t* __restrict__ contig_pos_off,
+                                                      uint32_t span_bits, uint32_t max_span,
+                                                      uint32_t M, uint32_t* __restrict__ selend,
+                                                      uint32_t ring_size) {
+    extern __shared__ uint32_t s_ring[];
+    uint32_t* s_ptr = s_ring;              // [ring_size] bucket prefix pointers
+    uint32_t* s_exp = s_ring + ring_size;  // [ring_size] selected reads by end position
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    const uint32_t rmask = ring_size - 1;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    for (uint32_t i = lane; i < 2 * ring_size; i += 64) s_ring[i] = 0;
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t p = 0; p < L; ++p) {
+        const uint32_t gp = base + p;
+        if (lane == 0) {
+            if (p >= ring_size) {
+                const uint32_t q = p - ring_size;  // long dead: ring_size > max_span
+                selend[base + q] = boff[base + q] + s_ptr[p & rmask];
+            }
+            s_ptr[p & rmask] = 0;
+        }
+        __syncthreads();
+        const uint32_t cov = boff[gp + 1] - eoff[gp];
+        const uint32_t need = min(cov, M);
+        uint32_t k = need > cur ? need - cur : 0u;
+        while (k > 0) {
+            // best head among buckets q in (p - max_span, p]
+            uint64_t best = 0;
+            for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
+                const uint32_t q = p - t;
+                const uint32_t gq = base + q;
+                const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
+                const uint32_t ptr = s_ptr[q & rmask];
+                if (b0 + ptr < b1) {
+                    const uint64_t key = skeys.key(b0 + ptr);
+                    const uint32_t span = max_span - (uint32_t)(key & code_mask);
+                    const uint32_t end = q + span - 1;
+                    if (end >= p) {
+                        const uint64_t pri = ((uint64_t)(end + 1) << 32) | (uint64_t)(q + 1);
+                        best = pri > best ? pri : best;
+                    }
+                }
+            }
+            best = wave_max_u64(best);
+            // need <= cov guarantees a candidate; guard anyway so the loop always ends
+            if (best == 0) break;
+            const uint32_t bend = (uint32_t)(best >> 32) - 1;
+            const uint32_t bq = (uint32_t)(best & 0xFFFFFFFFu) - 1;
+            const uint32_t gq = base + bq;
+            const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
+            const uint32_t ptr = s_ptr[bq & rmask];
+            // length of the run of equal-end reads at the head of the winning bucket (<= 64)
+            bool same = false;
+            const uint32_t j = b0 + ptr + lane;
+            if (j < b1) {
+                const uint64_t key = skeys.key(j);
+                const uint32_t span = max_span - (uint32_t)(key & code_mask);
+                same = (bq + span - 1) == bend;
+            }
+            const uint64_t ball = __ballot(same);
+            const uint32_t run = (~ball == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~ball) - 1);
+            const uint32_t take = min(k, run);
+            __syncthreads();
+            if (lane == 0) {
+                s_ptr[bq & rmask] = ptr + take;
+                s_exp[bend & rmask] += take;
+            }
+            __syncthreads();
+            cur += take;
+            k -= take;
+        }
+        // reads ending at p stop covering p+1
+        const uint32_t ex = s_exp[p & rmask];
+        cur -= ex;
+        __syncthreads();
+        if (lane == 0) s_exp[p & rmask] = 0;
+    }
+    __syncthreads();
+    // flush the buckets still in the ring
+    const uint32_t first = L > ring_size ? L - ring_size : 0u;
+    for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + s_ptr[q & rmask];
+}
+// ------------------------------------------------------------------ mixed-span sweep, LDS-cached
+// Same rule as k_sweep_general, organised so that the serial loop touches LDS only:
+//   * a preprocessing pass marks run heads of equal composite keys (a "group": reads with the
+//     same start and end) and a reverse min-scan turns them into next_head[], so the length of
+//     the run starting at j is next_head[j + 1] - j;
+//   * positions are taken 64 at a time: bucket bounds, coverage and the first TWO groups of
+//     every entering bucket are loaded with wave-wide (not serially dependent) loads into an LDS
+//     ring of `ring` slots (power of two >= max_span + 64, so that a slot is only recycled once
+//     its previous bucket is dead even for the last position of a chunk), and the previous
+//     occupants of those slots flush their selected counts to selend;
+//   * a selection event is a wave-wide maximum over the cached bucket heads, key
+//     (end - p + 1) << 16 | (0xFFFF - (p - q)): largest end, then largest start; it takes
+//     min(deficit, run) reads from the winning group.  Only when a bucket has used up both cached
+//     groups is its next group fetched from memory.
+// One wave per contig; spans up to kMaxCachedSpan.
+struct GenSlots {  // layout of the LDS ring, in 32-bit words per slot
+    // G0 / G1: (end + 1, run) of the bucket's head group and of the cached second group,
+    // 8 bytes each so one ds_read_b64 fetches both fields
+    enum { kG0 = 0, kG1 = 2, kNextJ = 4, kB1 = 5, kTaken = 6, kExp = 7, kWords = 8 };
+};
+
+template <typename Sorted>
+__global__ __launch_bounds__(256) void k_group_heads(Sorted skeys, uint32_t n,
+                                                     uint32_t* __restrict__ next_head) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += stride) {
+        uint32_t v = 0xFFFFFFFFu;
+        if (j == n) v = n;
+        else if (j == 0 || skeys.key(j - 1) != skeys.key(j)) v = j;
+        next_head[j] = v;
+    }
+}
+
+template <typename Sorted>
+__global__ __launch_bounds__(64) void k_sweep_general_cached(
+    const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
+    const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend, uint32_t ring) {
+    extern __shared__ uint32_t s_gen[];
+    uint2* s_g0 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG0 * ring);
+    uint2* s_g1 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG1 * ring);
+    uint32_t* s_nextj = s_gen + GenSlots::kNextJ * ring;
+    uint32_t* s_b1 = s_gen + GenSlots::kB1 * ring;
+    uint32_t* s_taken = s_gen + GenSlots::kTaken * ring;
+    uint32_t* s_exp = s_gen + GenSlots::kExp * ring;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    const uint32_t rmask = ring - 1;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    for (uint32_t i = lane; i < GenSlots::kWords * ring; i += 64) s_gen[i] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ cb = boff + base;
+    const uint32_t* __restrict__ ce = eoff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    uint32_t cur = 0;
+    // One wave per workgroup: its LDS operations execute in program order, so lane-0 updates
+    // are visible to every lane's next read without barriers.
+    for (uint32_t p0 = 0; p0 < L; p0 += 64) {
+        // ---- enter the chunk's 64 buckets (lane = position p0 + lane)
+        const uint32_t q = p0 + lane;
+        const uint32_t slot = q & rmask;
+        uint32_t need = 0;
+        uint32_t exp_c = 0;  // selected reads ending at position p0 + lane
+        if (q < L) {
+            if (q >= ring) csel[q - ring] = cb[q - ring] + s_taken[slot];  // recycled slot
+            exp_c = s_exp[slot];
+            s_exp[slot] = 0;
+            const uint32_t b0 = cb[q], b1 = cb[q + 1];
+            need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
+            uint2 g0 = make_uint2(0, 0), g1 = make_uint2(0, 0);
+            uint32_t nj = b1;
+            if (b0 < b1) {
+                const uint64_t k0 = skeys.key(b0);
+                g0.y = min(next_head[b0 + 1], b1) - b0;
+                g0.x = q + (max_span - (uint32_t)(k0 & code_mask));  // end + 1
+                const uint32_t j1 = b0 + g0.y;
+                nj = j1;
+                if (j1 < b1) {
+                    const uint64_t k1 = skeys.key(j1);
+                    g1.y = min(next_head[j1 + 1], b1) - j1;
+                    g1.x = q + (max_span - (uint32_t)(k1 & code_mask));
+                    nj = j1 + g1.y;
+                }
+            }
+            s_g0[slot] = g0;
+            s_g1[slot] = g1;
+            s_nextj[slot] = nj;
+            s_b1[slot] = b1;
+            s_taken[slot] = 0;
+        }
+        // ---- walk the chunk's positions; per-position need / expiry come from lane registers
+        const uint32_t chunk = min(64u, L - p0);
+        for (uint32_t j = 0; j < chunk; ++j) {
+            const uint32_t p = p0 + j;
+            const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
+            uint32_t k = need_p > cur ? need_p - cur : 0u;
+            while (k > 0) {
+                // best live head among buckets q' in (p - max_span, p]:
+                // key = (end + 1 - p) << 16 | (0xFFFF - (p - q')): largest end, then largest start
+                uint32_t best = 0, my_run = 0;
+                for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
+                    const uint2 g = s_g0[(p - t) & rmask];
+                    if (g.x > p) {
+                        const uint32_t key = ((g.x - p) << 16) | (0xFFFFu - t);
+                        if (key > best) { best = key; my_run = g.y; }
+                    }
+                }
+                uint32_t top = best;
+                top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+                top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+                top = __builtin_amdgcn_readlane(top, 63);
+                if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+                const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
+                const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
+                const uint32_t bq = p - (0xFFFFu - (top & 0xFFFFu));
+                const uint32_t bslot = bq & rmask;
+                const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group
+                const uint32_t take = min(k, run);
+                // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+                if (bend < p0 + 64) {
+                    exp_c += (lane == bend - p0) ? take : 0u;
+                } else if (lane == 0) {
+                    atomicAdd(&s_exp[bend & rmask], take);
+                }
+                if (lane == 0) {
+                    atomicAdd(&s_taken[bslot], take);
+                    if (take < run) {
+                        s_g0[bslot].y = run - take;
+                    } else {
+                        const uint2 g1 = s_g1[bslot];
+                        if (g1.y != 0) {
+                            // group used up: promote the cached second group (refilled lazily)
+                            s_g0[bslot] = g1;
+                            s_g1[bslot].y = 0;
+                        } else {
+                            // both cached groups used: fetch the bucket's next group, if any
+                            const uint32_t nj = s_nextj[bslot];
+                            const uint32_t b1 = s_b1[bslot];
+                            uint2 g0 = make_uint2(0, 0);
+                            if (nj < b1) {
+                                const uint64_t kk = skeys.key(nj);
+                                g0.y = min(next_head[nj + 1], b1) - nj;
+                                g0.x = bq + (max_span - (uint32_t)(kk & code_mask));
+                                s_nextj[bslot] = nj + g0.y;
+                            }
+                            s_g0[bslot] = g0;
+                        }
+                    }
+                }
+                cur += take;
+                k -= take;
+            }
+            // reads ending at p stop covering p + 1
+            cur -= __builtin_amdgcn_readlane(exp_c, j);
+        }
+    }
+    // flush the buckets still in the ring
+    const uint32_t first = L > ring ? L - ring : 0u;
+    for (uint32_t qq = first + lane; qq < L; qq += 64) csel[qq] = cb[qq] + s_taken[qq & rmask];
+}
+
+// ------------------------------------------------------------------ mixed-span sweep, register-resident
+// Register-resident form of the cached event sweep, for max_span + 64 <= 64 * B: the window of
+// live buckets is at most 64 * B positions wide, so every lane OWNS B of them (bucket q belongs to
+// lane q % 64, slot (q / 64) % B) and keeps their head group, cached second group, read pointers
+// and selected count in registers.  A selection event is then: every lane's best over its own B
+// slots (register compares), a fused-DPP wave maximum, and a register update in the winning lane
+// -- no LDS round trip on the serial path (the LDS version pays three or four per event).  Only
+// the expiry counts of reads that end beyond the current 64-position chunk go through an LDS
+// ring (fire-and-forget adds, read back one chunk later).  The chunk loop is unrolled B times so
+// that the slot a chunk's buckets enter is a compile-time index.
+template <typename Sorted, int B>
+__global__ __launch_bounds__(64) void k_sweep_general_reg(
+    const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
+    const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend
+#ifdef QMCP_GEN_STAMP
+    , unsigned long long* __restrict__ stamps  // lab builds: [0] entry cycles [1] events [2] event cycles [3] fetches [4] fetch cycles [5] walk cycles
+#endif
+    ) {
+    constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
+    __shared__ uint32_t s_exp[kRing];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c_id = blockIdx.x;
+    const uint32_t base = (uint32_t)contig_pos_off[c_id];
+    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    if (L == 0) return;
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    for (uint32_t i = lane; i < kRing; i += 64) s_exp[i] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ cb = boff + base;
+    const uint32_t* __restrict__ ce = eoff + base;
+    uint32_t* __restrict__ csel = selend + base;
+    // per owned bucket: head group (end + 1, run), cached second group, next unread group, bucket
+    // end, reads selected so far
+    uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bend1[B], taken[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
+    uint32_t cur = 0;
+    const uint32_t n_chunks = (L + 63) / 64;
+
+    auto load_group = [&](uint32_t j, uint32_t b1, uint32_t q, uint32_t& gx, uint32_t& gy) {
+        // group starting at sorted index j of the bucket of position q ending at b1 (gy = 0: none)
+        gx = 0; gy = 0;
+        if (j < b1) {
+            const uint64_t kk = skeys.key(j);
+            gy = min(next_head[j + 1], b1) - j;
+            gx = q + (max_span - (uint32_t)(kk & code_mask));  // end + 1
+        }
+    };
+
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += B) {
+#pragma unroll
+        for (int e = 0; e < B; ++e) {
+            const uint32_t c = c0 + e;
+            if (c >= n_chunks) break;
+            const uint32_t p0 = c * 64;
+#ifdef QMCP_GEN_STAMP
+            const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
+            // ---- the chunk's 64 buckets enter slot e (lane = position p0 + lane)
+            const uint32_t q = p0 + lane;
+            uint32_t need = 0, exp_c = 0;
+            if (c >= (uint32_t)B && q - kRing < L) csel[q - kRing] = cb[q - kRing] + taken[e];  // recycled slot
+            g0x[e] = g0y[e] = g1x[e] = g1y[e] = 0; nextj[e] = bend1[e] = taken[e] = 0;
+            if (q < L) {
+                exp_c = s_exp[q % kRing];
+                s_exp[q % kRing] = 0;
+                const uint32_t b0 = cb[q], b1 = cb[q + 1];
+                need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
+                bend1[e] = b1;
+                load_group(b0, b1, q, g0x[e], g0y[e]);
+                load_group(b0 + g0y[e], b1, q, g1x[e], g1y[e]);
+                nextj[e] = b0 + g0y[e] + g1y[e];
+            }
+#ifdef QMCP_GEN_STAMP
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
+            unsigned long long st_ev = 0, st_nev = 0, st_fe = 0, st_nfe = 0;
+#endif
+            // ---- this lane's best head over the buckets it owns, kept up to date incrementally.
+            // key = (end + 1 - pbase) << 16 | (q' - pbase), pbase = p0 - 64 (B - 1): largest end first,
+            // then largest start; valid for this chunk.  Its head group is live at p iff end >= p; if the
+            // lane's best is dead so is everything else it owns (smaller ends).
+            const uint32_t pbase = p0 - 64u * (uint32_t)(B - 1);  // (wraps for the first chunks: consistently)
+            uint32_t lbest = 0, lrun = 0, lslot = 0, key_e = 0;
+            auto lane_best = [&](bool with_entering) {
+                lbest = 0; lrun = 0; lslot = 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);   // chunks ago, in positions
+                    const uint32_t qrel = 64u * (uint32_t)(B - 1) - back + lane; // q' - pbase
+                    const uint32_t key = g0y[b] != 0 ? (((g0x[b] - pbase) << 16) | qrel) : 0u;
+                    if (b == e) key_e = key;
+                    const bool started = b != e || with_entering;
+                    if (started && key > lbest) { lbest = key; lrun = g0y[b]; lslot = b; }
+                }
+            };
+            lane_best(false);
+            // ---- walk the chunk's positions
+            const uint32_t chunk = min(64u, L - p0);
+            for (uint32_t j = 0; j < chunk; ++j) {
+                const uint32_t p = p0 + j;
+                // the bucket of position p starts now
+                if (lane == j && key_e > lbest) { lbest = key_e; lrun = g0y[e]; lslot = e; }
+                const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
+                uint32_t k = need_p > cur ? need_p - cur : 0u;
+                while (k > 0) {
+#ifdef QMCP_GEN_STAMP
+                    const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
+#endif
+                    const uint32_t best = (lbest >> 16) > p - pbase ? lbest : 0u;  // live: end + 1 > p
+                    uint32_t top = best;
+                    top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+                    top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+                    top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+                    top = __builtin_amdgcn_readlane(top, 63);
+                    if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+                    const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
+                    const uint32_t run = __builtin_amdgcn_readlane(lrun, src);
+                    const uint32_t bend = pbase + (top >> 16) - 1;  // end of the winning group
+                    const uint32_t take = min(k, run);
+                    // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+                    if (bend < p0 + 64) {
+                        exp_c += (lane == bend - p0) ? take : 0u;
+                    } else if (lane == 0) {
+                        atomicAdd(&s_exp[bend % kRing], take);
+                    }
+                    // the winning lane updates its own bucket in registers; the slot is made uniform so
+                    // that only that slot's code runs
+                    const uint32_t wslot = __builtin_amdgcn_readlane(lslot, src);
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        if (wslot == (uint32_t)b) {
+                            if (lane == src) {
+                                taken[b] += take;
+                                if (take < run) {
+                                    g0y[b] = run - take;
+                                } else if (g1y[b] != 0) {
+                                    g0x[b] = g1x[b]; g0y[b] = g1y[b]; g1y[b] = 0;   // promote the cached group
+                                } else {
+                                    // both cached groups used: fetch the bucket's next group, if any
+                                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);
+#ifdef QMCP_GEN_STAMP
+                                    const unsigned long long st_f0 = __builtin_amdgcn_s_memtime();
+#endif
+                                    load_group(nextj[b], bend1[b], p0 + lane - back, g0x[b], g0y[b]);
+                                    nextj[b] += g0y[b];
+#ifdef QMCP_GEN_STAMP
+                                    __builtin_amdgcn_s_waitcnt(0);
+                                    st_fe += __builtin_amdgcn_s_memtime() - st_f0;
+                                    st_nfe += 1;
+#endif
+                                }
+                            }
+                        }
+                    }
+                    if (lane == src) lane_best(lane <= j);  // its bucket changed: the lane's best again
+                    cur += take;
+                    k -= take;
+#ifdef QMCP_GEN_STAMP
+                    st_ev += __builtin_amdgcn_s_memtime() - st_v0;
+                    st_nev += 1;
+#endif
+                }
+                // reads ending at p stop covering p + 1
+                cur -= __builtin_amdgcn_readlane(exp_c, j);
+            }
+#ifdef QMCP_GEN_STAMP
+            {
+                const unsigned long long st_w = __builtin_amdgcn_s_memtime() - st_e1;
+                // fetch counters live in the winning lanes: reduce over the wave
+                unsigned long long fe = 0, nfe = 0;
+                for (int l = 0; l < 64; ++l) {
+                    fe += __shfl((unsigned long long)st_fe, l, 64);
+                    nfe += __shfl((unsigned long long)st_nfe, l, 64);
+                }
+                if (lane == 0 && stamps) {
+                    atomicAdd(&stamps[0], st_e1 - st_e0);
+                    atomicAdd(&stamps[1], st_nev);
+                    atomicAdd(&stamps[2], st_ev);
+                    atomicAdd(&stamps[3], nfe);
+                    atomicAdd(&stamps[4], fe);
+                    atomicAdd(&stamps[5], st_w);
+                }
+            }
+#endif
+        }
+    }
+    // flush the buckets still owned
+    const uint32_t last_c = n_chunks - 1;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // the most recent chunk that filled slot b
+        if (last_c >= (uint32_t)b) {
+            const uint32_t cc = last_c - ((last_c - (uint32_t)b) % (uint32_t)B);
+            const uint32_t qq = cc * 64 + lane;
+            if (qq < L) csel[qq] = cb[qq] + taken[b];
+        }
+    }
+}
+

@@ -268,7 +268,6 @@ static uint32_t rank_min_reads() {
     const char* e = std::getenv("QMCP_HIP_RANK_MIN");
     return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 17);
 }
-#define kRankMinReads rank_min_reads()
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
@@ -344,7 +343,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
-        if (n >= kRankMinReads && qmcp::range_path_supported(ltot))
+        if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
         TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
     }
@@ -373,7 +372,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // the range partition's per-tile histogram is produced by the same pass when the range-ranked
     // path can be taken (uniformity is only known afterwards; the table is cheap)
     const uint32_t range_shift = qmcp::range_shift_for(ltot);
-    const bool may_rank = n >= kRankMinReads && qmcp::range_path_supported(ltot) && !try_chained;
+    const bool may_rank = n >= rank_min_reads() && qmcp::range_path_supported(ltot) && !try_chained;
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 65540;
     uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
