@@ -56,7 +56,7 @@ struct qmcp_hip_ctx {
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t ev_in = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: small read-backs beside the work queued on `stream`
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr;   // main stream -> side stream: statistics and heaviest load are final
     // arena (grow-only, reused across solves like a reference solver instance's members)
     DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
     DevBuf keys[2], vals[2];
@@ -803,7 +803,6 @@ int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx) {
         e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         qmcp_hip_destroy(c);
         return fail(QMCP_EHIP, "context setup: %s", hipGetErrorString(e));
@@ -830,7 +829,6 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_tables) (void)hipHostFree(c->h_tables);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -32,7 +32,7 @@ void launch_radix_hist(hipStream_t st, bool wide, const void* keys_in, uint32_t 
 void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
                           uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
                           uint32_t* vals_out);
-// three-wave pipelined form (spans <= 256); false if the span needs the single-wave kernel
+// seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
