@@ -1,0 +1,46 @@
+"""Seeded random uniform-span cases through every route the host can pick (ranked one- and two-level,
+sort-based; fast and general sweep pipelines; single-wave sweep), each bit-identical to the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    span = int(rng.choice([1, 7, 64, 100, 150, 151, 200, 256, 300]))
+    n_contigs = int(rng.integers(1, 6))
+    big = rng.random() < 0.15                      # beyond 8.39 M positions: two partition levels
+    lengths, counts = [], []
+    for _ in range(n_contigs):
+        L = int(rng.integers(span, 40_000)) if not big else int(rng.integers(3_000_000, 6_000_000))
+        lengths.append(max(L, span))
+        counts.append(int(rng.integers(0, 120_000)))
+    if rng.random() < 0.3:
+        counts[int(rng.integers(0, n_contigs))] = 0   # a contig without reads
+    if sum(counts) == 0:
+        counts[0] = 1000
+    ss, ee = [], []
+    for L, c in zip(lengths, counts):
+        hi = L - span + 1
+        if rng.random() < 0.4 and hi > 50:            # hot spots: a few start positions hold most reads
+            spots = rng.integers(0, hi, size=int(rng.integers(1, 6)))
+            s = np.where(rng.random(c) < 0.7, rng.choice(spots, size=c), rng.integers(0, hi, size=c))
+        else:
+            s = rng.integers(0, hi, size=c)
+        s = s.astype(np.uint32)
+        ss.append(s)
+        ee.append((s + np.uint32(span - 1)).astype(np.uint32))
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    M = int(rng.choice([1, 2, 5, 17, 50, 100, 300, 5000]))
+    return s, e, np.array(lengths, np.uint32), offs, M
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_uniform_span_case(pkg, oracle, solver, seed):
+    rng = np.random.default_rng(90_000 + seed)
+    s, e, lengths, offs, M = _case(rng)
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sort_passes)
+    assert solver.last_stats.n_kept == int(np.unpackbits(want.view(np.uint8)).sum())
