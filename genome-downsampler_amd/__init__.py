@@ -41,7 +41,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("n_reads", C.c_uint64), ("n_kept", C.c_uint64), ("total_length", C.c_uint64),
         ("n_contigs", C.c_uint32), ("path", C.c_uint32), ("min_span", C.c_uint32),
-        ("max_span", C.c_uint32), ("sort_passes", C.c_uint32), ("reserved0", C.c_uint32),
+        ("max_span", C.c_uint32), ("sort_passes", C.c_uint32), ("sweep_stretches", C.c_uint32),
         ("ms_total", C.c_float), ("ms_prepare", C.c_float), ("ms_scan", C.c_float),
         ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_mark", C.c_float),
         ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),

@@ -74,19 +74,44 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
                            (uint32_t*)keys_out, vals_out);
 }
 
+// Cut-point segmentation: window count for a genome of ltot positions (0: not worth it).  Windows
+// hold at least 64 blocks, so a stretch is long enough to amortise a pipeline start.
+uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs) {
+    if (n_contigs >= 256 || ell == 0) return 0;
+    const uint64_t w = (uint64_t)ltot / (64ull * ell);
+    const uint32_t cap = (uint32_t)kSegMaxCandidates - 256;
+    return (uint32_t)(w < 2 ? 0 : (w > cap ? cap : w));
+}
+size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
+    return (size_t)n_windows + 1 + 3 * ((size_t)n_contigs + n_windows);
+}
+// fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
+const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                                      uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
+                                      uint32_t n_windows, uint32_t* seg_words) {
+    uint32_t* cut = seg_words;
+    uint32_t* seg = seg_words + n_windows;
+    const uint32_t win = (ltot + n_windows - 1) / n_windows;
+    hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, d_poff, n_contigs, ltot, ell, M, win, cut);
+    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
+                       ltot, seg);
+    return seg;
+}
+
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
 
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                             uint32_t* selend, uint32_t* iter_stats) {
+                             uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_MW(EE)                                                                              \
     {                                                                                                   \
         const size_t lds = MwLayout<EE>::kBytes;                                                        \
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_mw<EE>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_contigs), dim3(448), lds, st, boff, d_poff,   \
-                           ell, M, ltot, selend, iter_stats);                                           \
+        hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,       \
+                           ell, M, ltot, selend, iter_stats, seg);                                           \
     }
     switch (e) {
         case 1: QMCP_SWEEP_MW(1); break;
@@ -101,15 +126,16 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                              uint32_t* selend, uint32_t* iter_stats) {
+                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_GEN(EE)                                                                             \
     {                                                                                                   \
         const size_t lds = MgLayout<EE>::kBytes;                                                        \
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_contigs), dim3(448), lds, st, boff, d_poff,  \
-                           ell, M, ltot, selend, iter_stats);                                           \
+        hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,      \
+                           ell, M, ltot, selend, iter_stats, seg);                                           \
     }
     switch (e) {
         case 1: QMCP_SWEEP_GEN(1); break;
@@ -124,11 +150,12 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
 
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                          uint32_t* selend, uint32_t* iter_stats) {
+                          uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP(EE)                                                                          \
-    hipLaunchKernelGGL(k_sweep_uniform<EE>, dim3(n_contigs), dim3(64), 0, st, boff, d_poff, ell, \
-                       M, ltot, selend, iter_stats)
+    hipLaunchKernelGGL(k_sweep_uniform<EE>, dim3(n_wg), dim3(64), 0, st, boff, d_poff, ell, \
+                       M, ltot, selend, iter_stats, seg)
     switch (e) {
         case 1: QMCP_SWEEP(1); break;
         case 2: QMCP_SWEEP(2); break;

@@ -180,7 +180,7 @@ template <int E>
 __device__ __forceinline__ void block_emit(const uint32_t (&x0)[E], const uint32_t (&cnt)[E],
                                            const uint32_t (&dn)[E], const uint32_t (&hn)[E],
                                            uint32_t d_in, uint32_t a, uint32_t trash, uint32_t ell,
-                                           uint32_t L, uint32_t lane, uint32_t last_lane,
+                                           uint32_t Lrun, uint32_t lane, uint32_t last_lane,
                                            uint32_t last_r, uint32_t (&h)[E], uint32_t& d_last,
                                            uint32_t* __restrict__ csel) {
     uint32_t prev = d_in, pick = 0;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void block_emit(const uint32_t (&x0)[E], const uint32
         const uint32_t i = lane * E + r;
         const uint32_t p = a + i;
         // unconditional store: slots outside the contig write the spare entry selend[ltot]
-        csel[(i < ell && p < L) ? p : trash] = x0[r] + (cnt[r] - (dn[r] - prev));
+        csel[(i < ell && p < Lrun) ? p : trash] = x0[r] + (cnt[r] - (dn[r] - prev));
         prev = dn[r];
         if ((uint32_t)r == last_r) pick = dn[r];
         h[r] = hn[r];
@@ -203,7 +203,7 @@ template <int E>
 __device__ __forceinline__ bool sweep_block_fast(const BlockPrep<E>& pr, uint32_t a,
                                                  const SweepLoads<E>& nxt_ld, uint32_t a_next,
                                                  BlockPrep<E>& nx, uint32_t trash, uint32_t ell,
-                                                 uint32_t L, uint32_t M, uint32_t lane,
+                                                 uint32_t L, uint32_t Lrun, uint32_t M, uint32_t lane,
                                                  uint32_t last_lane, uint32_t last_r,
                                                  uint32_t (&h)[E], uint32_t& d_last,
                                                  uint32_t* __restrict__ csel) {
@@ -275,14 +275,14 @@ __device__ __forceinline__ bool sweep_block_fast(const BlockPrep<E>& pr, uint32_
         undercut |= run < dn[r];
         run = min(run, hn[r]);
     }
-    block_emit<E>(pr.x0, pr.cnt, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+    block_emit<E>(pr.x0, pr.cnt, dn, hn, d_in, a, trash, ell, Lrun, lane, last_lane, last_r, h, d_last, csel);
     return __any(undercut);
 }
 
 // General form of the same block: maps carrying (d, m) -- see Map4 above.
 template <int E>
 __device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint32_t a,
-                                                 uint32_t trash, uint32_t ell, uint32_t L,
+                                                 uint32_t trash, uint32_t ell, uint32_t L, uint32_t Lrun,
                                                  uint32_t M, uint32_t lane, uint32_t last_lane,
                                                  uint32_t last_r, uint32_t (&h)[E],
                                                  uint32_t& d_last, uint32_t* __restrict__ csel) {
@@ -324,14 +324,14 @@ __device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint3
         hn[r] = dd + t.exj[r];
         m = min(m, hn[r]);
     }
-    block_emit<E>(cur.x0, t.cnt, dn, hn, d_in, a, trash, ell, L, lane, last_lane, last_r, h, d_last, csel);
+    block_emit<E>(cur.x0, t.cnt, dn, hn, d_in, a, trash, ell, Lrun, lane, last_lane, last_r, h, d_last, csel);
 }
 
 // blocks [b_begin, b_end) in the general form, loads of block b+1 in flight under block b
 template <int E>
 __device__ __forceinline__ void sweep_full_run(const uint32_t* __restrict__ cb, uint32_t b_begin,
                                                uint32_t b_end, uint32_t trash, uint32_t ell,
-                                               uint32_t L, uint32_t M, uint32_t lane,
+                                               uint32_t L, uint32_t Lrun, uint32_t M, uint32_t lane,
                                                uint32_t last_lane, uint32_t last_r,
                                                uint32_t (&h)[E], uint32_t& d_last,
                                                uint32_t* __restrict__ csel) {
@@ -339,10 +339,50 @@ __device__ __forceinline__ void sweep_full_run(const uint32_t* __restrict__ cb, 
     sweep_load<E>(cb, b_begin * ell, ell, L, lane, T0);
     for (uint32_t b = b_begin; b < b_end; b += 2) {
         sweep_load<E>(cb, (b + 1) * ell, ell, L, lane, T1);
-        sweep_block_full<E>(T0, b * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+        sweep_block_full<E>(T0, b * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
         sweep_load<E>(cb, (b + 2) * ell, ell, L, lane, T0);
         if (b + 1 < b_end)
-            sweep_block_full<E>(T1, (b + 1) * ell, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+            sweep_block_full<E>(T1, (b + 1) * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
+    }
+}
+
+// What one sweep workgroup works on: a whole contig, or -- when the host found cut points
+// (positions whose coverage is <= M: every read covering them is kept, so the sweep's state behind
+// them does not depend on what came before) -- the stretch of a contig between two cut points.
+//   base   global position where the stretch starts
+//   Lrun   its length: blocks are solved, and results stored, only up to here
+//   L      distance to the CONTIG's end: loads and jump landings are valid up to here (the last block
+//          of a stretch looks past its end)
+// `seg` (null: one workgroup per contig) = [count, then {start, end, contig end} of each stretch].
+struct SweepSeg { uint32_t base, Lrun, L; };
+__device__ __forceinline__ bool sweep_segment(const uint64_t* __restrict__ contig_pos_off,
+                                              const uint32_t* __restrict__ seg, uint32_t idx, SweepSeg& s) {
+    if (seg == nullptr) {
+        s.base = (uint32_t)contig_pos_off[idx];
+        s.L = (uint32_t)(contig_pos_off[idx + 1] - contig_pos_off[idx]);
+        s.Lrun = s.L;
+        return s.L != 0;
+    }
+    if (idx >= seg[0]) return false;  // the grid is an upper bound
+    const uint32_t* q = seg + 1 + 3 * idx;
+    s.base = q[0];
+    s.Lrun = q[1] - q[0];
+    s.L = q[2] - q[0];
+    return s.Lrun != 0;
+}
+// ex = cov - min(cov, M) at the first block's positions: the h of the (virtual) block before it,
+// whose distances are all equal.  The window of starts may reach back past the stretch, and even past
+// the contig's start: no read starts within ell - 1 of a contig's end (it would cross it), so the
+// global prefix counts need no clamp at contig borders.
+template <int E>
+__device__ __forceinline__ void sweep_initial_h(const uint32_t* __restrict__ boff, const SweepSeg& sg,
+                                                uint32_t ell, uint32_t M, uint32_t lane, uint32_t (&h)[E]) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t hi = sg.base + min(i + 1, sg.L);  // prefix index p + 1
+        const uint32_t cov = boff[hi] - boff[hi >= ell ? hi - ell : 0u];
+        h[r] = (i < ell && i < sg.L) ? (cov > M ? cov - M : 0u) : kInf;
     }
 }
 
@@ -351,28 +391,21 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
                                                       const uint64_t* __restrict__ contig_pos_off,
                                                       uint32_t ell, uint32_t M, uint32_t ltot,
                                                       uint32_t* __restrict__ selend,
-                                                      uint32_t* __restrict__ iter_stats) {
+                                                      uint32_t* __restrict__ iter_stats,
+                                                      const uint32_t* __restrict__ seg) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
-    if (L == 0) return;
-    const uint32_t n_blocks = (L + ell - 1) / ell;
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
+    const uint32_t base = sg.base, L = sg.L, Lrun = sg.Lrun;
+    const uint32_t n_blocks = (Lrun + ell - 1) / ell;
     // this wave is a serial dependency chain that may share its SIMD with streaming kernels:
     // win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
 
     uint32_t h[E];  // previous block's h(j) = d(j) + ex(j + ell), aligned with this block's slots
     // virtual block -1: d == 0 and the jump from j = i - ell lands on p = i
-    {
-        const uint32_t b0 = boff[base];
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint32_t i = lane * E + r;
-            const uint32_t cov = boff[base + min(i + 1, L)] - b0;
-            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
-        }
-    }
+    sweep_initial_h<E>(boff, sg, ell, M, lane, h);
     uint32_t d_last = 0;
     uint32_t n_full = 0;  // blocks that needed the 4-component form
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
         if (penalty > 0) {
             // sparse / low-coverage stretch: the fast form keeps failing here, do not try it
             const uint32_t run = min(penalty, n_groups - g);
-            sweep_full_run<E>(cb, g * 4, (g + run) * 4, trash, ell, L, M, lane, last_lane, last_r, h,
+            sweep_full_run<E>(cb, g * 4, (g + run) * 4, trash, ell, L, Lrun, M, lane, last_lane, last_r, h,
                               d_last, csel);
             n_full += run * 4;
             g += run;
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
             // block k solves with terms prepared during block k-1 and prepares block k+1 from
             // loads issued three blocks earlier; S_k is re-loaded for block k+4 once consumed
 #define QMCP_FAST(PR, pos, LD_NEXT, PR_NEXT)                                                        \
-    sweep_block_fast<E>(PR, pos, LD_NEXT, (pos) + ell, PR_NEXT, trash, ell, L, M, lane, last_lane,  \
+    sweep_block_fast<E>(PR, pos, LD_NEXT, (pos) + ell, PR_NEXT, trash, ell, L, Lrun, M, lane, last_lane,  \
                         last_r, h, d_last, csel)
             sweep_load<E>(cb, a + 4 * ell, ell, L, lane, S0);
             bad = QMCP_FAST(PA, a, S1, PB);
@@ -442,7 +475,7 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
 #pragma unroll
             for (int r = 0; r < E; ++r) h[r] = h_save[r];
             d_last = d_save;
-            sweep_full_run<E>(cb, g * 4, g * 4 + 4, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+            sweep_full_run<E>(cb, g * 4, g * 4 + 4, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
             n_full += 4;
             ++g;
             penalty = good > 0 ? 1u : min(2 * penalty + 1, 63u);
@@ -452,9 +485,10 @@ __global__ __launch_bounds__(64) void k_sweep_uniform(const uint32_t* __restrict
     }
     // tail: at most three blocks, general form
     if (n_groups * 4 < n_blocks)
-        sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last, csel);
+        sweep_full_run<E>(cb, n_groups * 4, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
     if (iter_stats && lane == 0) {
         atomicAdd(&iter_stats[0], n_full);
         atomicAdd(&iter_stats[1], n_blocks);
+        atomicAdd(&iter_stats[2], 1u);  // stretches swept
     }
 }

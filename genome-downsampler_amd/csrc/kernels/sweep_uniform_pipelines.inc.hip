@@ -119,7 +119,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                                                           const uint64_t* __restrict__ contig_pos_off,
                                                           uint32_t ell, uint32_t M, uint32_t ltot,
                                                           uint32_t* __restrict__ selend,
-                                                          uint32_t* __restrict__ iter_stats) {
+                                                          uint32_t* __restrict__ iter_stats,
+                                                          const uint32_t* __restrict__ seg) {
     using Ly = MwLayout<E>;
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
     const uint32_t pblk = 2 * (wv == 4 ? 3u : wv);            // PREP: first of its two blocks
     const uint32_t cblk = 4 * (wv - 5);                       // CHECK: first of its four blocks
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
-    if (L == 0) return;
-    const uint32_t n_blocks = (L + ell - 1) / ell;
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;  // uniform over the workgroup
+    const uint32_t base = sg.base, L = sg.L, Lrun = sg.Lrun;
+    const uint32_t n_blocks = (Lrun + ell - 1) / ell;
     const uint32_t n_groups = n_blocks / kG;
     const uint32_t* __restrict__ cb = boff + base;
     uint32_t* __restrict__ csel = selend + base;
@@ -150,15 +151,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
 
     // chain state (meaningful in the CHAIN wave only)
     uint32_t h[E];
-    {
-        const uint32_t b0 = cb[0];
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint32_t i = lane * E + r;
-            const uint32_t cov = cb[min(i + 1, L)] - b0;
-            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
-        }
-    }
+    sweep_initial_h<E>(boff, sg, ell, M, lane, h);
     uint32_t d_last = 0;
     uint32_t n_full = 0;
     uint32_t penalty = 0;
@@ -182,7 +175,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
             warm = false;
             const uint32_t run = min(penalty, n_groups - g0);
             if (role == 1) {
-                sweep_full_run<E>(cb, g0 * kG, (g0 + run) * kG, trash, ell, L, M, lane, last_lane, last_r,
+                sweep_full_run<E>(cb, g0 * kG, (g0 + run) * kG, trash, ell, L, Lrun, M, lane, last_lane, last_r,
                                   h, d_last, csel);
                 n_full += run * kG;
             }
@@ -407,7 +400,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                             // lanes without E valid slots write the spare words behind the table
                             const uint32_t blk_first = (g * kG + cblk + kk) * ell;
                             const uint32_t p0 = blk_first + lane * E;
-                            const bool full = lane * E + E <= ell && p0 + E <= L;
+                            const bool full = lane * E + E <= ell && p0 + E <= Lrun;
                             if constexpr (E == 1) {
                                 csel[full ? p0 : trash] = sel[kk][0];
                             } else {
@@ -418,11 +411,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                                 *reinterpret_cast<V*>(csel + (full ? p0 : trash)) = v;
                                 // a lane with only some valid slots exists only if E does not divide the
                                 // span or the block is cut by the contig's end (uniform test)
-                                if (ell % E != 0 || blk_first + ell > L) {
+                                if (ell % E != 0 || blk_first + ell > Lrun) {
 #pragma unroll
                                     for (int r = 0; r < E; ++r) {
                                         const uint32_t i = lane * E + r;
-                                        if (!full && i < ell && blk_first + i < L) csel[blk_first + i] = sel[kk][r];
+                                        if (!full && i < ell && blk_first + i < Lrun) csel[blk_first + i] = sel[kk][r];
                                     }
                                 }
                             }
@@ -458,7 +451,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                 for (int r = 0; r < E; ++r) h[r] = MW_AT(blk, 0, Ly::kDn + r) + MW_AT(blk, 0, Ly::kEx + r);
                 d_last = MW_SLOT0(failed % Ly::kSlots)[(((bad_blk - 1) * Ly::kWords + Ly::kDn + last_r) * 64) + last_lane];
             }
-            sweep_full_run<E>(cb, failed * kG + bad_blk, failed * kG + kG, trash, ell, L, M, lane, last_lane,
+            sweep_full_run<E>(cb, failed * kG + bad_blk, failed * kG + kG, trash, ell, L, Lrun, M, lane, last_lane,
                               last_r, h, d_last, csel);
             n_full += kG - bad_blk;
         }
@@ -495,11 +488,12 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
 #endif
     if (role == 1) {
         if (n_groups * kG < n_blocks)
-            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
+            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last,
                               csel);
         if (iter_stats && lane == 0) {
             atomicAdd(&iter_stats[0], n_full);
             atomicAdd(&iter_stats[1], n_blocks);
+            atomicAdd(&iter_stats[2], 1u);  // stretches swept
         }
     }
 }
@@ -537,7 +531,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                            const uint64_t* __restrict__ contig_pos_off,
                                                            uint32_t ell, uint32_t M, uint32_t ltot,
                                                            uint32_t* __restrict__ selend,
-                                                           uint32_t* __restrict__ iter_stats) {
+                                                           uint32_t* __restrict__ iter_stats,
+                                                           const uint32_t* __restrict__ seg) {
     using Ly = MgLayout<E>;
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
@@ -548,10 +543,10 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     const uint32_t pblk = kPB * (wv == 4 ? 3u : wv);           // PREP: first of its blocks of the group
     const uint32_t cblk = kCB * (wv - 5);                      // CHECK: first of its blocks
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
-    if (L == 0) return;
-    const uint32_t n_blocks = (L + ell - 1) / ell;
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;  // uniform over the workgroup
+    const uint32_t base = sg.base, L = sg.L, Lrun = sg.Lrun;
+    const uint32_t n_blocks = (Lrun + ell - 1) / ell;
     const uint32_t n_groups = n_blocks / kG;
     const uint32_t* __restrict__ cb = boff + base;
     uint32_t* __restrict__ csel = selend + base;
@@ -560,15 +555,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     __builtin_amdgcn_s_setprio(3);
 
     uint32_t h[E];
-    {
-        const uint32_t b0 = cb[0];
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint32_t i = lane * E + r;
-            const uint32_t cov = cb[min(i + 1, L)] - b0;
-            h[r] = (i < ell && i < L) ? (cov > M ? cov - M : 0u) : kInf;
-        }
-    }
+    sweep_initial_h<E>(boff, sg, ell, M, lane, h);
     uint32_t d_last = 0;
 
 #define MG_SLOT0(idx) (s_mw + (size_t)(idx) * kG * Ly::kWords * 64)
@@ -757,7 +744,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                         }
                         const uint32_t blk_first = (g * kG + k) * ell;
                         const uint32_t p0 = blk_first + lane * E;
-                        const bool full = lane * E + E <= ell && p0 + E <= L;
+                        const bool full = lane * E + E <= ell && p0 + E <= Lrun;
                         if constexpr (E == 1) {
                             csel[full ? p0 : trash] = sel[0];
                         } else {
@@ -766,11 +753,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
 #pragma unroll
                             for (int r = 0; r < E; ++r) vv[r] = sel[r];
                             *reinterpret_cast<V*>(csel + (full ? p0 : trash)) = vv;
-                            if (ell % E != 0 || blk_first + ell > L) {
+                            if (ell % E != 0 || blk_first + ell > Lrun) {
 #pragma unroll
                                 for (int r = 0; r < E; ++r) {
                                     const uint32_t i = lane * E + r;
-                                    if (!full && i < ell && blk_first + i < L) csel[blk_first + i] = sel[r];
+                                    if (!full && i < ell && blk_first + i < Lrun) csel[blk_first + i] = sel[r];
                                 }
                             }
                         }
@@ -786,11 +773,12 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
 #undef MG_SLOT0
     if (role == 1) {
         if (n_groups * kG < n_blocks)
-            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, M, lane, last_lane, last_r, h, d_last,
+            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last,
                               csel);
         if (iter_stats && lane == 0) {
             atomicAdd(&iter_stats[0], n_blocks);  // every block is in the general form here
             atomicAdd(&iter_stats[1], n_blocks);
+            atomicAdd(&iter_stats[2], 1u);  // stretches swept
         }
     }
 }

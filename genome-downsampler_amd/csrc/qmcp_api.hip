@@ -72,6 +72,7 @@ struct qmcp_hip_ctx {
     size_t h_tables_cap = 0;
     uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
     DevBuf scalars;  // popcount + sweep iteration counters
+    DevBuf segs;     // cut-point windows and the sweep's stretch table
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
     int profiling = 0;  // 0 off, 1 every kernel, 2 the selection sweep only
@@ -278,6 +279,14 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // The uniform-span sweep: seven waves per contig where the span allows it (fast form with checked
 // fallback on deep data, every block in the general form on shallow data -- both exact, the
 // choice is about speed only), else the single-wave kernel.  QMCP_HIP_SWEEP=fast|gen overrides.
+// Cut-point segmentation of the uniform sweeps (QMCP_HIP_CUTS=0|1 overrides): looked for where mean
+// coverage is a small multiple of M -- deep data has no cut points, and the look costs two launches.
+uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, bool shallow) {
+    bool on = shallow;
+    if (const char* e = std::getenv("QMCP_HIP_CUTS")) on = e[0] == '1';
+    return on ? qmcp::sweep_segment_windows(ltot, span, n_contigs) : 0u;
+}
+
 int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
                          uint32_t span, uint32_t M, uint32_t* d_iters) {
     // mean coverage in units of M: the fast form needs the binding jumps to come from the previous
@@ -291,14 +300,23 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     const uint32_t* boff = (const uint32_t*)c->boff.p;
     const uint64_t* poff = (const uint64_t*)c->poff.p;
     uint32_t* selend = (uint32_t*)c->selend.p;
+    // shallow or gapped data: split the contigs at cut points so that more than n_contigs chains run
+    const uint32_t* seg = nullptr;
+    uint32_t n_seg_max = 0;
+    const uint32_t windows = sweep_cut_windows(ltot, span, n_contigs, gen);
+    if (windows != 0) {
+        KernelSpan sp(c, "k_find_cuts", st);
+        seg = qmcp::launch_sweep_segments(st, boff, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
+        n_seg_max = n_contigs + windows;
+    }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
-        const bool ok = gen ? qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters)
-                            : qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters);
+        const bool ok = gen ? qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max)
+                            : qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max);
         if (ok) return QMCP_OK;
     }
     KernelSpan sp(c, "k_sweep_uniform", st);
-    if (!qmcp::launch_sweep_uniform(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters))
+    if (!qmcp::launch_sweep_uniform(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max))
         return fail(QMCP_ERANGE, "uniform span %u not supported", span);
     return QMCP_OK;
 }
@@ -342,6 +360,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
+        TRY(ensure(c, c->segs, qmcp::sweep_segment_words(n_contigs < 256 ? n_contigs : 0, 768) * sizeof(uint32_t)));
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
@@ -694,7 +713,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
-    local.reserved0 = c->last_iters;
+    local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu);
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);
@@ -819,7 +838,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -32,18 +32,30 @@ void launch_radix_hist(hipStream_t st, bool wide, const void* keys_in, uint32_t 
 void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const uint32_t* vals_in,
                           uint32_t n, uint32_t shift, const uint32_t* offs, void* keys_out,
                           uint32_t* vals_out);
+// Cut points (coverage <= M) split a contig's sweep exactly.  sweep_segment_windows: how many
+// windows to look for cuts in (0: not worth it); launch_sweep_segments fills `seg_words`
+// (sweep_segment_words() uint32) and returns the stretch table the sweep launchers take as `seg`
+// together with n_seg_max = n_contigs + n_windows workgroups (null: one workgroup per contig).
+uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs);
+size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows);
+const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
+                                      uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
+                                      uint32_t n_windows, uint32_t* seg_words);
 // seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                              uint32_t* selend, uint32_t* iter_stats);
+                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
+                              uint32_t n_seg_max);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                             uint32_t* selend, uint32_t* iter_stats);
+                             uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
+                             uint32_t n_seg_max);
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                          uint32_t* selend, uint32_t* iter_stats);
+                          uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
+                          uint32_t n_seg_max);
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,

@@ -17,6 +17,7 @@
 //   radix_sort, radix_chained  LSD radix passes (sort-based routes), the opt-in chained pass
 //   ranked_route             range partition (one or two levels), per-range offsets, ordered ranking
 //   sweep_uniform            block forms of the uniform-span sweep, single-wave kernel
+//   sweep_segments           cut points (coverage <= M): contigs split into independently swept stretches
 //   sweep_uniform_pipelines  seven-wave pipelines: fast form with checked fallback, all-general form
 //   sweep_mixed              mixed-span event sweeps (register-resident, LDS-cached, plain)
 //   mark_and_next_rows       keep-mask emission for the sort-based routes, coverage probes, FILTER,
@@ -43,6 +44,7 @@ static constexpr uint32_t kInf = 0x40000000u;
 #include "kernels/ranked_route.inc.hip"
 #include "kernels/radix_chained.inc.hip"
 #include "kernels/sweep_uniform.inc.hip"
+#include "kernels/sweep_segments.inc.hip"
 #include "kernels/sweep_uniform_pipelines.inc.hip"
 #include "kernels/sweep_mixed.inc.hip"
 #include "kernels/mark_and_next_rows.inc.hip"

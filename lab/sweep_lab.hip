@@ -25,7 +25,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
     const int reps = 5;
     for (int it = 0; it < reps; ++it) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it);
+        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr);
         hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
     }
     uint32_t it2[2]; hipMemcpy(it2, d_it, 8, hipMemcpyDeviceToHost);
@@ -49,7 +49,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
             // the table was just written by other CUs)
             hipMemsetAsync(d_flush, it, 768u << 20, 0);
             hipEventRecord(a);
-            launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it);
+            launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float msc; hipEventElapsedTime(&msc, a, b);
             if (msc < cold) cold = msc;
         }
@@ -57,7 +57,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         hipMemset(d_it, 0, 128);
         for (int it = 0; it < reps; ++it) {
             hipEventRecord(a);
-            ok = launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it);
+            ok = launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best2) best2 = ms;
         }
         hipError_t e = hipDeviceSynchronize();
@@ -83,14 +83,14 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
     // the pipelined general form on the same data: identical selend required
     {
         std::vector<uint32_t> ref(Lt + 1), got(Lt + 1);
-        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it);
+        hipLaunchKernelGGL((k_sweep_uniform<3>), dim3(contigs), dim3(64), 0, 0, d_boff, d_poff, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr);
         hipDeviceSynchronize();
         hipMemcpy(ref.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
         hipMemset(d_sel, 0xEE, (Lt + 1) * 4);
         float best3 = 1e9;
         for (int it = 0; it < reps; ++it) {
             hipEventRecord(a);
-            launch_sweep_uniform_gen(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it);
+            launch_sweep_uniform_gen(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best3) best3 = ms;
         }
         hipError_t e = hipDeviceSynchronize();
