@@ -25,14 +25,18 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
     const uint32_t hi = (uint32_t)min((uint64_t)(w + 1) * win, (uint64_t)ltot);
     if (threadIdx.x == 0) s_first = kNoCut;
     __syncthreads();
-    for (uint32_t q0 = lo; q0 < hi; q0 += 256) {
-        const uint32_t q = q0 + threadIdx.x;
-        if (q < hi) {
-            const uint32_t cov = boff[q] - boff[q >= ell ? q - ell : 0u];  // coverage of position q - 1
-            if (cov <= M) {
-                bool contig_start = false;
-                for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= (uint32_t)contig_pos_off[c] == q;
-                if (!contig_start) atomicMin(&s_first, q);
+    // four strips of 256 positions per round: the first position wins, whichever strip it is in
+    for (uint32_t q0 = lo; q0 < hi; q0 += 1024) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t q = q0 + k * 256 + threadIdx.x;
+            if (q < hi) {
+                const uint32_t cov = boff[q] - boff[q >= ell ? q - ell : 0u];  // coverage of position q - 1
+                if (cov <= M) {
+                    bool contig_start = false;
+                    for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= (uint32_t)contig_pos_off[c] == q;
+                    if (!contig_start) atomicMin(&s_first, q);
+                }
             }
         }
         __syncthreads();

@@ -44,3 +44,40 @@ def test_random_uniform_span_case(pkg, oracle, solver, seed):
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sort_passes)
     assert solver.last_stats.n_kept == int(np.unpackbits(want.view(np.uint8)).sum())
+
+
+def _shallow_case(rng):
+    """coverage within a few times the cap, patchy: the data cut points split"""
+    span = int(rng.choice([30, 64, 100, 150, 151, 256, 300]))
+    n_contigs = int(rng.integers(1, 5))
+    M = int(rng.choice([1, 2, 5, 17, 50]))
+    lengths, counts, ss = [], [], []
+    for _ in range(n_contigs):
+        L = int(rng.integers(20_000, 400_000))
+        depth = float(rng.choice([0.3, 0.8, 1.0, 1.5, 3.0]))
+        c = min(int(L * M * depth / span), 400_000)
+        hi = L - span + 1
+        s = rng.integers(0, hi, size=c)
+        if rng.random() < 0.5:                        # patches: starts folded into part of every period
+            period = int(rng.integers(2 * span, 20 * span))
+            fill = float(rng.uniform(0.2, 0.9))
+            s = np.minimum((s // period) * period + ((s % period) * fill).astype(np.int64), hi - 1)
+        lengths.append(L)
+        counts.append(c)
+        ss.append(s.astype(np.uint32))
+    s = np.concatenate(ss)
+    e = (s + np.uint32(span - 1)).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    return s, e, np.array(lengths, np.uint32), offs, M
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shallow_case_split_at_cut_points(pkg, oracle, solver, seed, monkeypatch):
+    rng = np.random.default_rng(70_000 + seed)
+    s, e, lengths, offs, M = _shallow_case(rng)
+    monkeypatch.setenv("QMCP_HIP_CUTS", "1")
+    if seed % 3 == 0:
+        monkeypatch.setenv("QMCP_HIP_SWEEP", "fast")   # the checked fast form with its fallbacks, segmented
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
