@@ -272,12 +272,24 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
 // Register-resident form of the cached event sweep, for max_span + 64 <= 64 * B: the window of
 // live buckets is at most 64 * B positions wide, so every lane OWNS B of them (bucket q belongs to
 // lane q % 64, slot (q / 64) % B) and keeps their head group, cached second group, read pointers
-// and selected count in registers.  A selection event is then: every lane's best over its own B
-// slots (register compares), a fused-DPP wave maximum, and a register update in the winning lane
-// -- no LDS round trip on the serial path (the LDS version pays three or four per event).  Only
-// the expiry counts of reads that end beyond the current 64-position chunk go through an LDS
-// ring (fire-and-forget adds, read back one chunk later).  The chunk loop is unrolled B times so
+// and selected count in registers, plus one packed key per bucket:
+//     (end + 1 - pbase) << 16 | (start - pbase) << 7 | min(run, 127)      pbase = p0 - 64 (B - 1)
+// largest end first, then largest start (the canonical rule; the run bits never decide, starts are
+// distinct).  The wave maximum of the live keys therefore names the winning lane, its slot, the
+// group's end and (capped) run all at once -- no second lookup.
+// The walk over a chunk of 64 positions is event-driven: lane j holds need(p0 + j) and the
+// coverage by selected reads at p0 + j given the selections so far (an exclusive prefix sum of the
+// chunk's expiry counts at entry, then += take on the lanes a selected group covers), so the next
+// position with a deficit is one ballot away and positions without one cost nothing.  A selection
+// event is: ballot, lane candidates (register compares), a fused-DPP wave maximum, scalar decode,
+// two masked vector updates and the register update in the winning lane -- no LDS round trip on the
+// serial path.  Only the expiry counts of reads that end beyond the chunk go through an LDS ring
+// (fire-and-forget adds, read back when their chunk enters).  The chunk loop is unrolled B times so
 // that the slot a chunk's buckets enter is a compile-time index.
+__device__ __forceinline__ uint32_t reg_sweep_key(uint32_t gx, uint32_t gy, uint32_t qrel, uint32_t pbase) {
+    return gy != 0 ? (((gx - pbase) << 16) | (qrel << 7) | min(gy, 127u)) : 0u;
+}
+
 template <typename Sorted, int B>
 __global__ __launch_bounds__(64) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
@@ -287,7 +299,9 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
     , unsigned long long* __restrict__ stamps  // lab builds: [0] entry cycles [1] events [2] event cycles [3] fetches [4] fetch cycles [5] walk cycles
 #endif
     ) {
+    static_assert(B >= 2 && B <= 8, "key fields: 10 bits of end, 9 bits of start");
     constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
+    constexpr uint32_t kBack = 64u * (uint32_t)(B - 1);  // p0 - pbase
     __shared__ uint32_t s_exp[kRing];
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
     uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bend1[B], taken[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
-    uint32_t cur = 0;
+    uint32_t cur = 0;  // selected reads covering the chunk's first position, before its own selections
     const uint32_t n_chunks = (L + 63) / 64;
 
     auto load_group = [&](uint32_t j, uint32_t b1, uint32_t q, uint32_t& gx, uint32_t& gy) {
@@ -347,97 +361,90 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
             const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
             unsigned long long st_ev = 0, st_nev = 0, st_fe = 0, st_nfe = 0;
 #endif
-            // ---- this lane's best head over the buckets it owns, kept up to date incrementally.
-            // key = (end + 1 - pbase) << 16 | (q' - pbase), pbase = p0 - 64 (B - 1): largest end first,
-            // then largest start; valid for this chunk.  Its head group is live at p iff end >= p; if the
-            // lane's best is dead so is everything else it owns (smaller ends).
-            const uint32_t pbase = p0 - 64u * (uint32_t)(B - 1);  // (wraps for the first chunks: consistently)
-            uint32_t lbest = 0, lrun = 0, lslot = 0, key_e = 0;
-            auto lane_best = [&](bool with_entering) {
-                lbest = 0; lrun = 0; lslot = 0;
+            // ---- keys of the owned buckets, relative to this chunk (the first chunks' pbase wraps:
+            // consistently, every difference below is small and positive)
+            const uint32_t pbase = p0 - kBack;
+            uint32_t key[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const uint32_t back = 64u * (uint32_t)((e - b + B) % B);  // chunks ago, in positions
+                key[b] = reg_sweep_key(g0x[b], g0y[b], kBack - back + lane, pbase);
+            }
+            // ---- selected coverage at every position of the chunk, before the selections made there
+            uint32_t curv = cur - (wave_incl_scan_add(exp_c) - exp_c);
+            for (;;) {
+                const unsigned long long pend = __ballot(need > curv);
+                if (pend == 0) break;
+#ifdef QMCP_GEN_STAMP
+                const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
+#endif
+                const uint32_t j = (uint32_t)__ffsll((long long)pend) - 1;  // first position with a deficit
+                const uint32_t k = __builtin_amdgcn_readlane(need - curv, j);
+                // this lane's best head: the buckets it owns, the entering one once its position is reached
+                uint32_t m = lane <= j ? key[e] : 0u;
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    if (b != e) m = max(m, key[b]);
+                // live at p iff end >= p; if the lane's best is dead so is all else it owns (smaller ends)
+                uint32_t top = (m >> 16) > kBack + j ? m : 0u;
+                top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+                top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+                top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+                top = __builtin_amdgcn_readlane(top, 63);
+                if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+                const uint32_t qrel = (top >> 7) & 511u;
+                const uint32_t src = qrel & 63u;
+                uint32_t wslot = (uint32_t)e + 1u + (qrel >> 6);  // slot of the chunk that bucket entered in
+                wslot = wslot >= (uint32_t)B ? wslot - (uint32_t)B : wslot;
+                const uint32_t take = min(k, top & 127u);        // <= the group's true run
+                const uint32_t bend_rel = (top >> 16) - 1u - kBack;  // group's end - p0  (>= j: it is live)
+                // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+                if (bend_rel < 64u) {
+                    exp_c += (lane == bend_rel) ? take : 0u;
+                } else if (lane == 0) {
+                    atomicAdd(&s_exp[(p0 + bend_rel) % kRing], take);
+                }
+                curv += (lane >= j && lane <= bend_rel) ? take : 0u;
+                // the winning lane updates its own bucket in registers (compile-time slot: one copy of
+                // this code per slot, all but one skipped)
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
-                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);   // chunks ago, in positions
-                    const uint32_t qrel = 64u * (uint32_t)(B - 1) - back + lane; // q' - pbase
-                    const uint32_t key = g0y[b] != 0 ? (((g0x[b] - pbase) << 16) | qrel) : 0u;
-                    if (b == e) key_e = key;
-                    const bool started = b != e || with_entering;
-                    if (started && key > lbest) { lbest = key; lrun = g0y[b]; lslot = b; }
-                }
-            };
-            lane_best(false);
-            // ---- walk the chunk's positions
-            const uint32_t chunk = min(64u, L - p0);
-            for (uint32_t j = 0; j < chunk; ++j) {
-                const uint32_t p = p0 + j;
-                // the bucket of position p starts now
-                if (lane == j && key_e > lbest) { lbest = key_e; lrun = g0y[e]; lslot = e; }
-                const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
-                uint32_t k = need_p > cur ? need_p - cur : 0u;
-                while (k > 0) {
+                    if (wslot == (uint32_t)b) {
+                        if (lane == src) {
+                            const uint32_t back = 64u * (uint32_t)((e - b + B) % B);
+                            const uint32_t run = g0y[b];
+                            taken[b] += take;
+                            if (take < run) {
+                                g0y[b] = run - take;
+                            } else if (g1y[b] != 0) {
+                                g0x[b] = g1x[b]; g0y[b] = g1y[b]; g1y[b] = 0;   // promote the cached group
+                            } else {
+                                // both cached groups used: fetch the bucket's next group, if any
 #ifdef QMCP_GEN_STAMP
-                    const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
+                                const unsigned long long st_f0 = __builtin_amdgcn_s_memtime();
 #endif
-                    const uint32_t best = (lbest >> 16) > p - pbase ? lbest : 0u;  // live: end + 1 > p
-                    uint32_t top = best;
-                    top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
-                    top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
-                    top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
-                    top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
-                    top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
-                    top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
-                    top = __builtin_amdgcn_readlane(top, 63);
-                    if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
-                    const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
-                    const uint32_t run = __builtin_amdgcn_readlane(lrun, src);
-                    const uint32_t bend = pbase + (top >> 16) - 1;  // end of the winning group
-                    const uint32_t take = min(k, run);
-                    // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
-                    if (bend < p0 + 64) {
-                        exp_c += (lane == bend - p0) ? take : 0u;
-                    } else if (lane == 0) {
-                        atomicAdd(&s_exp[bend % kRing], take);
-                    }
-                    // the winning lane updates its own bucket in registers; the slot is made uniform so
-                    // that only that slot's code runs
-                    const uint32_t wslot = __builtin_amdgcn_readlane(lslot, src);
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        if (wslot == (uint32_t)b) {
-                            if (lane == src) {
-                                taken[b] += take;
-                                if (take < run) {
-                                    g0y[b] = run - take;
-                                } else if (g1y[b] != 0) {
-                                    g0x[b] = g1x[b]; g0y[b] = g1y[b]; g1y[b] = 0;   // promote the cached group
-                                } else {
-                                    // both cached groups used: fetch the bucket's next group, if any
-                                    const uint32_t back = 64u * (uint32_t)((e - b + B) % B);
+                                load_group(nextj[b], bend1[b], p0 + lane - back, g0x[b], g0y[b]);
+                                nextj[b] += g0y[b];
 #ifdef QMCP_GEN_STAMP
-                                    const unsigned long long st_f0 = __builtin_amdgcn_s_memtime();
+                                __builtin_amdgcn_s_waitcnt(0);
+                                st_fe += __builtin_amdgcn_s_memtime() - st_f0;
+                                st_nfe += 1;
 #endif
-                                    load_group(nextj[b], bend1[b], p0 + lane - back, g0x[b], g0y[b]);
-                                    nextj[b] += g0y[b];
-#ifdef QMCP_GEN_STAMP
-                                    __builtin_amdgcn_s_waitcnt(0);
-                                    st_fe += __builtin_amdgcn_s_memtime() - st_f0;
-                                    st_nfe += 1;
-#endif
-                                }
                             }
+                            key[b] = reg_sweep_key(g0x[b], g0y[b], kBack - back + lane, pbase);
                         }
                     }
-                    if (lane == src) lane_best(lane <= j);  // its bucket changed: the lane's best again
-                    cur += take;
-                    k -= take;
-#ifdef QMCP_GEN_STAMP
-                    st_ev += __builtin_amdgcn_s_memtime() - st_v0;
-                    st_nev += 1;
-#endif
                 }
-                // reads ending at p stop covering p + 1
-                cur -= __builtin_amdgcn_readlane(exp_c, j);
+#ifdef QMCP_GEN_STAMP
+                st_ev += __builtin_amdgcn_s_memtime() - st_v0;
+                st_nev += 1;
+#endif
             }
+            // reads ending at the chunk's last position stop covering the next chunk
+            cur = __builtin_amdgcn_readlane(curv - exp_c, 63);
 #ifdef QMCP_GEN_STAMP
             {
                 const unsigned long long st_w = __builtin_amdgcn_s_memtime() - st_e1;
@@ -471,4 +478,3 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
         }
     }
 }
-
