@@ -86,13 +86,13 @@ size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
     return (size_t)n_windows + 1 + 3 * ((size_t)n_contigs + n_windows);
 }
 // fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
-const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
-                                      uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
-                                      uint32_t n_windows, uint32_t* seg_words) {
+const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
+                                      const uint64_t* d_poff, uint32_t n_contigs, uint32_t ltot, uint32_t ell,
+                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words) {
     uint32_t* cut = seg_words;
     uint32_t* seg = seg_words + n_windows;
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
-    hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, d_poff, n_contigs, ltot, ell, M, win, cut);
+    hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, eoff, d_poff, n_contigs, ltot, ell, M, win, cut);
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, seg);
     return seg;
@@ -174,20 +174,21 @@ bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* 
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* sorted, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
-                          uint32_t ring_size) {
+                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const size_t lds = 2 * (size_t)ring_size * sizeof(uint32_t);
     if (wide) {
         (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedK64>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<SortedK64>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+        hipLaunchKernelGGL(k_sweep_general<SortedK64>, dim3(n_wg), dim3(64), lds, st, boff, eoff,
                            SortedK64{(const uint64_t*)sorted}, d_poff, span_bits, max_span, M, selend,
-                           ring_size);
+                           ring_size, seg);
     } else {
         (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedRec>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<SortedRec>, dim3(n_contigs), dim3(64), lds, st, boff, eoff,
+        hipLaunchKernelGGL(k_sweep_general<SortedRec>, dim3(n_wg), dim3(64), lds, st, boff, eoff,
                            SortedRec{(const Rec*)sorted}, d_poff, span_bits, max_span, M, selend,
-                           ring_size);
+                           ring_size, seg);
     }
 }
 
@@ -204,20 +205,22 @@ void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t 
 void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff,
                                  const uint32_t* eoff, const void* sorted, const uint32_t* next_head,
                                  const uint64_t* d_poff, uint32_t n_contigs, uint32_t span_bits,
-                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring) {
+                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring,
+                                 const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const size_t lds = (size_t)GenSlots::kWords * ring * sizeof(uint32_t);
     if (wide) {
         (void)hipFuncSetAttribute((const void*)k_sweep_general_cached<SortedK64>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general_cached<SortedK64>, dim3(n_contigs), dim3(64), lds, st, boff,
+        hipLaunchKernelGGL(k_sweep_general_cached<SortedK64>, dim3(n_wg), dim3(64), lds, st, boff,
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,
-                           max_span, M, selend, ring);
+                           max_span, M, selend, ring, seg);
     } else {
         (void)hipFuncSetAttribute((const void*)k_sweep_general_cached<SortedRec>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general_cached<SortedRec>, dim3(n_contigs), dim3(64), lds, st, boff,
+        hipLaunchKernelGGL(k_sweep_general_cached<SortedRec>, dim3(n_wg), dim3(64), lds, st, boff,
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span,
-                           M, selend, ring);
+                           M, selend, ring, seg);
     }
 }
 
@@ -225,7 +228,8 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
 bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
-                              uint32_t* selend) {
+                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max) {
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t b = (max_span + 64 + 63) / 64;
 #ifdef QMCP_GEN_STAMP
 #define QMCP_GEN_STAMP_ARG , (unsigned long long*)nullptr
@@ -234,13 +238,13 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
 #endif
 #define QMCP_GEN_REG(BB)                                                                              \
     if (wide)                                                                                          \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_wg), dim3(64), 0, st, boff,       \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
-                           max_span, M, selend QMCP_GEN_STAMP_ARG);                                    \
+                           max_span, M, selend, seg QMCP_GEN_STAMP_ARG);                               \
     else                                                                                               \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_contigs), dim3(64), 0, st, boff,  \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_wg), dim3(64), 0, st, boff,       \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
-                           M, selend QMCP_GEN_STAMP_ARG);
+                           M, selend, seg QMCP_GEN_STAMP_ARG);
     if (b <= 2) { QMCP_GEN_REG(2) }
     else if (b == 3) { QMCP_GEN_REG(3) }
     else if (b == 4) { QMCP_GEN_REG(4) }

@@ -11,6 +11,30 @@
 struct SortedRec { const Rec* r; __device__ uint64_t key(uint32_t j) const { return r[j].key; } };
 struct SortedK64 { const uint64_t* k; __device__ uint64_t key(uint32_t j) const { return k[j]; } };
 
+// A stretch that starts behind a cut point (sweep_segments): every read that covers the position
+// before its first one is kept, whatever came earlier, and none of them is a candidate any more.
+// What the stretch inherits is therefore only their coverage: this returns how many of them reach
+// into the stretch and adds them to the expiry ring by end position (ring index = end - a, modulo;
+// the ring holds at least max_span entries).  One wave; reads starting in the max_span - 1 positions
+// before `a` are looked at (global prefix counts: a previous contig's reads end before `a`).
+template <typename Sorted>
+__device__ __forceinline__ uint32_t seed_stretch_expiry(Sorted skeys, const uint32_t* __restrict__ boff,
+                                                        uint32_t a, uint32_t span_bits, uint32_t max_span,
+                                                        uint32_t* s_exp, uint32_t ring, uint32_t lane) {
+    const uint64_t code_mask = (1ull << span_bits) - 1;
+    const uint32_t lo = a >= max_span ? a - (max_span - 1) : 0u;
+    uint32_t count = 0;
+    for (uint32_t j = boff[lo] + lane; j < boff[a]; j += 64) {
+        const uint64_t kk = skeys.key(j);
+        const uint32_t end = (uint32_t)(kk >> span_bits) + (max_span - (uint32_t)(kk & code_mask)) - 1;
+        if (end >= a) {
+            atomicAdd(&s_exp[(end - a) % ring], 1u);
+            ++count;
+        }
+    }
+    return wave_sum_u32(count);
+}
+
 template <typename Sorted>
 __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict__ boff,
                                                       const uint32_t* __restrict__ eoff,
@@ -18,19 +42,24 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
                                                       const uint64_t* __restrict__ contig_pos_off,
                                                       uint32_t span_bits, uint32_t max_span,
                                                       uint32_t M, uint32_t* __restrict__ selend,
-                                                      uint32_t ring_size) {
+                                                      uint32_t ring_size, const uint32_t* __restrict__ seg) {
     extern __shared__ uint32_t s_ring[];
     uint32_t* s_ptr = s_ring;              // [ring_size] bucket prefix pointers
     uint32_t* s_exp = s_ring + ring_size;  // [ring_size] selected reads by end position
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
+    const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint32_t rmask = ring_size - 1;
     const uint64_t code_mask = (1ull << span_bits) - 1;
     for (uint32_t i = lane; i < 2 * ring_size; i += 64) s_ring[i] = 0;
     __syncthreads();
     uint32_t cur = 0;
+    if (seg != nullptr) {
+        cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, ring_size, lane);
+        __syncthreads();
+    }
     for (uint32_t p = 0; p < L; ++p) {
         const uint32_t gp = base + p;
         if (lane == 0) {
@@ -138,7 +167,8 @@ template <typename Sorted>
 __global__ __launch_bounds__(64) void k_sweep_general_cached(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
-    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend, uint32_t ring) {
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend, uint32_t ring,
+    const uint32_t* __restrict__ seg) {
     extern __shared__ uint32_t s_gen[];
     uint2* s_g0 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG0 * ring);
     uint2* s_g1 = reinterpret_cast<uint2*>(s_gen + GenSlots::kG1 * ring);
@@ -148,8 +178,9 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
     uint32_t* s_exp = s_gen + GenSlots::kExp * ring;
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
+    const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint32_t rmask = ring - 1;
     const uint64_t code_mask = (1ull << span_bits) - 1;
     for (uint32_t i = lane; i < GenSlots::kWords * ring; i += 64) s_gen[i] = 0;
@@ -158,6 +189,7 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
     const uint32_t* __restrict__ ce = eoff + base;
     uint32_t* __restrict__ csel = selend + base;
     uint32_t cur = 0;
+    if (seg != nullptr) cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, ring, lane);
     // One wave per workgroup: its LDS operations execute in program order, so lane-0 updates
     // are visible to every lane's next read without barriers.
     for (uint32_t p0 = 0; p0 < L; p0 += 64) {
@@ -294,7 +326,8 @@ template <typename Sorted, int B>
 __global__ __launch_bounds__(64) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
-    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend
+    uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend,
+    const uint32_t* __restrict__ seg
 #ifdef QMCP_GEN_STAMP
     , unsigned long long* __restrict__ stamps  // lab builds: [0] entry cycles [1] events [2] event cycles [3] fetches [4] fetch cycles [5] walk cycles
 #endif
@@ -305,9 +338,9 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
     __shared__ uint32_t s_exp[kRing];
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
-    const uint32_t base = (uint32_t)contig_pos_off[c_id];
-    const uint32_t L = (uint32_t)(contig_pos_off[c_id + 1] - contig_pos_off[c_id]);
-    if (L == 0) return;
+    SweepSeg sg;
+    if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
+    const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint64_t code_mask = (1ull << span_bits) - 1;
     for (uint32_t i = lane; i < kRing; i += 64) s_exp[i] = 0;
     __syncthreads();
@@ -320,6 +353,10 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
 #pragma unroll
     for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
     uint32_t cur = 0;  // selected reads covering the chunk's first position, before its own selections
+    if (seg != nullptr) {
+        cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, kRing, lane);
+        __syncthreads();
+    }
     const uint32_t n_chunks = (L + 63) / 64;
 
     auto load_group = [&](uint32_t j, uint32_t b1, uint32_t q, uint32_t& gx, uint32_t& gy) {

@@ -16,6 +16,7 @@ static constexpr uint32_t kNoCut = 0xFFFFFFFFu;
 static constexpr int kSegMaxCandidates = 1024;  // contigs + windows
 
 __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ boff,
+                                                   const uint32_t* __restrict__ eoff,  // null: one span, ell
                                                    const uint64_t* __restrict__ contig_pos_off,
                                                    uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
                                                    uint32_t win, uint32_t* __restrict__ cut) {
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t q = q0 + k * 256 + threadIdx.x;
             if (q < hi) {
-                const uint32_t cov = boff[q] - boff[q >= ell ? q - ell : 0u];  // coverage of position q - 1
+                // coverage of position q - 1: starts up to it minus ends before it
+                const uint32_t cov = boff[q] - (eoff != nullptr ? eoff[q - 1] : boff[q >= ell ? q - ell : 0u]);
                 if (cov <= M) {
                     bool contig_start = false;
                     for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= (uint32_t)contig_pos_off[c] == q;

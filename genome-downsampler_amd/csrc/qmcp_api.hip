@@ -306,7 +306,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     const uint32_t windows = sweep_cut_windows(ltot, span, n_contigs, gen);
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);
-        seg = qmcp::launch_sweep_segments(st, boff, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
+        seg = qmcp::launch_sweep_segments(st, boff, nullptr, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
         n_seg_max = n_contigs + windows;
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
@@ -519,6 +519,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // the radix sort instead (the counts and the sweep done here stay valid).
     bool sweep_done = false, ranked = false;
     uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
+    bool mixed_whole_contigs = false;
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     if (uniform && may_rank) {
         hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
@@ -647,6 +648,22 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     } else {
         uint32_t ring = 64;
         while (ring <= max_span) ring <<= 1;
+        // shallow or gapped data: stretches between cut points, one wave each (depth judged with the
+        // longest span: an upper bound)
+        const uint32_t* seg = nullptr;
+        uint32_t n_seg_max = 0;
+        const double depth = (double)n * (double)max_span / ((double)ltot * (double)(M ? M : 1));
+        const uint32_t windows = sweep_cut_windows(ltot, max_span, n_contigs, depth < kGenDepth);
+        if (windows != 0) {
+            KernelSpan sp(c, "k_find_cuts");
+            seg = qmcp::launch_sweep_segments(c->stream, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
+                                              (const uint64_t*)c->poff.p, n_contigs, ltot, max_span, M, windows,
+                                              (uint32_t*)c->segs.p);
+            n_seg_max = n_contigs + windows;
+            // stats.sweep_stretches: the table's count (the uniform kernels count themselves)
+            HIP_TRY(hipMemcpyAsync(d_iters + 2, seg, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        }
+        mixed_whole_contigs = seg == nullptr;
         if (max_span <= qmcp::kMaxCachedSpan) {
             ring = 64;
             while (ring < max_span + 64) ring <<= 1;  // 64 buckets enter per chunk
@@ -669,18 +686,19 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                 !qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p,
                                                 (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                                 (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
-                                                n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p))
+                                                n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p, seg,
+                                                n_seg_max))
             qmcp::launch_sweep_general_cached(c->stream, wide, (const uint32_t*)c->boff.p,
                                               (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                               (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
                                               n_contigs, span_bits, max_span, M,
-                                              (uint32_t*)c->selend.p, ring);
+                                              (uint32_t*)c->selend.p, ring, seg, n_seg_max);
         } else {
             KernelSpan sp(c, "k_sweep_general");
             qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
                                        (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                        (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
-                                       (uint32_t*)c->selend.p, ring);
+                                       (uint32_t*)c->selend.p, ring, seg, n_seg_max);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -714,6 +732,8 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
     local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu);
+    if (mixed_whole_contigs)  // one wave per non-empty contig
+        for (uint32_t k = 0; k < n_contigs; ++k) local.sweep_stretches += lengths[k] != 0 ? 1u : 0u;
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);

@@ -38,9 +38,10 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
 // together with n_seg_max = n_contigs + n_windows workgroups (null: one workgroup per contig).
 uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs);
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows);
-const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
-                                      uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
-                                      uint32_t n_windows, uint32_t* seg_words);
+// eoff: prefix counts of read ends for mixed spans (coverage = starts - ends); null for one span ell
+const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
+                                      const uint64_t* d_poff, uint32_t n_contigs, uint32_t ltot, uint32_t ell,
+                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words);
 // seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
@@ -59,18 +60,19 @@ bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* 
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
-                          uint32_t ring_size);
+                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max);
 void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t n,
                         uint32_t* next_head /* n + 1 entries; reverse-min-scan it afterwards */);
 void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff,
                                  const uint32_t* eoff, const void* sorted, const uint32_t* next_head,
                                  const uint64_t* d_poff, uint32_t n_contigs, uint32_t span_bits,
-                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring);
+                                 uint32_t max_span, uint32_t M, uint32_t* selend, uint32_t ring,
+                                 const uint32_t* seg, uint32_t n_seg_max);
 // `sorted` is a Rec{key,val} array (wide == false) or u64 keys with `svals` beside them
 bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
-                              uint32_t* selend);
+                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
                  unsigned long long* n_kept);

@@ -78,8 +78,8 @@ typedef struct qmcp_hip_stats {
     uint32_t max_span;
     uint32_t sort_passes;     /* radix passes of the bucketing stage (1 = one range partition,    */
                               /* the large uniform-span route; >= 2 = LSD radix sort)             */
-    uint32_t sweep_stretches; /* uniform-span sweeps: chains run side by side (the non-empty contigs, */
-                              /* or more where cut points -- coverage <= M -- split them); else 0 */
+    uint32_t sweep_stretches; /* chains the sweep ran side by side: the non-empty contigs, or more    */
+                              /* where cut points (coverage <= M) split them                       */
     float ms_total;           /* device time of the whole solve (HIP events on the solver stream) */
     float ms_prepare;         /* validate + span reduction + per-position start/end counts        */
     float ms_scan;            /* prefix scans -> bucket offsets / coverage                        */

@@ -127,3 +127,80 @@ def test_default_is_on_for_shallow_data_and_off_for_deep(pkg, oracle, solver):
         s, e = _reads(rng, 1_000_000, L, span)           # coverage 250 = 25 M
         solver.solve(s, e, L, 10)
         assert solver.last_stats.sweep_stretches == 1
+
+
+# ---------------------------------------------------------------- mixed spans: the event sweeps
+
+
+def _mixed_reads(rng, n, L, lo_span, hi_span, lo=0, hi=None):
+    hi = L if hi is None else hi
+    span = rng.integers(lo_span, hi_span + 1, size=n).astype(np.int64)
+    s = (lo + rng.random(n) * np.maximum(hi - lo - span + 1, 1)).astype(np.int64)
+    s = np.minimum(s, L - span)
+    return s.astype(np.uint32), (s + span - 1).astype(np.uint32)
+
+
+def _check_mixed(pkg, oracle, solver, s, e, lengths, M, offs=None, lds=False, expect_split=True):
+    with _env(QMCP_HIP_CUTS="0", QMCP_HIP_GENERAL_LDS="1" if lds else None):
+        whole = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        assert solver.last_stats.path == pkg.PATH_GENERAL
+        chains_whole = solver.last_stats.sweep_stretches
+    with _env(QMCP_HIP_CUTS="1", QMCP_HIP_GENERAL_LDS="1" if lds else None):
+        split = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        chains_split = solver.last_stats.sweep_stretches
+    assert np.array_equal(split, whole)
+    assert np.array_equal(split, oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
+    if expect_split:
+        assert chains_split > chains_whole, (chains_split, chains_whole)
+    return chains_whole, chains_split
+
+
+@pytest.mark.parametrize("spans,lds", [((80, 150), False), ((20, 60), False), ((100, 400), False),
+                                       ((80, 150), True), ((300, 1500), False), ((5000, 9000), False)])
+def test_mixed_spans_shallow_coverage(pkg, oracle, solver, spans, lds):
+    """register-resident, LDS-cached and plain event sweeps, each started behind cut points with the
+    coverage (and expiry) of the reads that reach over from before"""
+    rng = np.random.default_rng(spans[0])
+    lo, hi = spans
+    L, M = 64 * hi * 12, 9
+    n = int(L * M * 1.1 / ((lo + hi) / 2))
+    s, e = _mixed_reads(rng, n, L, lo, hi)
+    whole, split = _check_mixed(pkg, oracle, solver, s, e, L, M, lds=lds)
+    assert whole == 1 and split > 4
+
+
+def test_mixed_spans_islands_and_contigs(pkg, oracle, solver):
+    rng = np.random.default_rng(21)
+    M = 6
+    lengths = np.array([200_000, 0, 140, 350_000], dtype=np.uint32)
+    parts, offs = [], [0]
+    for L in lengths:
+        L = int(L)
+        if L == 0:
+            ps = []
+        elif L < 1000:
+            ps = [_mixed_reads(rng, 30, L, 60, 140)]
+        else:
+            ps = [_mixed_reads(rng, 900, L, 60, 140, lo, lo + 2500) for lo in range(0, L - 3000, 9000)]
+        cnt = sum(p[0].size for p in ps)
+        parts += ps
+        offs.append(offs[-1] + cnt)
+    s = np.concatenate([p[0] for p in parts])
+    e = np.concatenate([p[1] for p in parts])
+    # shuffle inside each contig
+    for a, b in zip(offs[:-1], offs[1:]):
+        perm = rng.permutation(b - a) + a
+        s[a:b], e[a:b] = s[perm], e[perm]
+    whole, split = _check_mixed(pkg, oracle, solver, s, e, lengths, M, offs=np.array(offs, dtype=np.uint64))
+    assert whole == 3
+
+
+def test_mixed_spans_long_reads_reach_over_several_cuts(pkg, oracle, solver):
+    """a few reads far longer than the rest keep covering across many cut points"""
+    rng = np.random.default_rng(4)
+    L, M = 64 * 400 * 20, 3
+    s1, e1 = _mixed_reads(rng, 40_000, L, 30, 60)
+    s2, e2 = _mixed_reads(rng, 300, L, 380, 400)
+    s, e = np.concatenate([s1, s2]), np.concatenate([e1, e2])
+    perm = rng.permutation(s.size)
+    _check_mixed(pkg, oracle, solver, s[perm], e[perm], L, M)

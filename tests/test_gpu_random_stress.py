@@ -81,3 +81,20 @@ def test_random_shallow_case_split_at_cut_points(pkg, oracle, solver, seed, monk
     got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shallow_mixed_span_case_split_at_cut_points(pkg, oracle, solver, seed, monkeypatch):
+    """the same shallow cases with every read's span drawn at random: the event sweeps, segmented"""
+    rng = np.random.default_rng(50_000 + seed)
+    s, e, lengths, offs, M = _shallow_case(rng)
+    span = int(e[0] - s[0]) + 1
+    cut = rng.integers(0, max(span // 2, 1), size=s.size).astype(np.uint32)   # shorten: ends stay inside the contig
+    e = (e - cut).astype(np.uint32)
+    monkeypatch.setenv("QMCP_HIP_CUTS", "1")
+    if seed % 4 == 0:
+        monkeypatch.setenv("QMCP_HIP_GENERAL_LDS", "1")
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert solver.last_stats.path == pkg.PATH_GENERAL
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
