@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  uint32_t* __restrict__ stats,
                                                  uint32_t n_tiles, uint32_t tiles_per_block,
                                                  uint32_t part_shift,
-                                                 uint32_t* __restrict__ part_hist,
+                                                 uint32_t* __restrict__ part_hist, uint32_t part_pitch,
                                                  uint32_t* __restrict__ digit0_hist,
                                                  uint32_t* __restrict__ global_digit_hist,
                                                  unsigned long long* __restrict__ zero_mask) {
@@ -27,8 +27,14 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     __shared__ uint64_t s_roff[65];
     __shared__ uint64_t s_poff[65];
-    __shared__ uint32_t s_h[256];
+    // partition histograms of the workgroup's (up to 8) consecutive tiles, written together at the
+    // end: the table is laid out [digit][tile] (row pitch part_pitch, a multiple of 8), so a thread's
+    // eight tile counts are one aligned 32-byte run of its digit's row instead of eight lone words
+    // in eight rows' worth of evicted lines (that cost 8x the table's size in HBM writes)
+    __shared__ uint32_t s_ph[8][256];
     __shared__ uint32_t s_h0[256];
+    if (part_hist)
+        for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) (&s_ph[0][0])[i] = 0;
     const uint32_t nc = min(n_contigs, 64u);
     for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
         s_roff[i] = contig_read_off[i];
@@ -42,8 +48,8 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     const uint32_t t0 = blockIdx.x * tiles_per_block;
     for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
         const uint32_t tile = t0 + g;
+        uint32_t* s_h = s_ph[g];
         if (part_hist) {
-            s_h[threadIdx.x] = 0;
             s_h0[threadIdx.x] = 0;
             __syncthreads();
         }
@@ -122,12 +128,24 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
         }
         if (part_hist) {
             __syncthreads();
-            part_hist[threadIdx.x * n_tiles + tile] = s_h[threadIdx.x];
             if (digit0_hist) {
                 digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
                 if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
             }
             __syncthreads();
+        }
+    }
+    if (part_hist) {
+        __syncthreads();
+        uint32_t* row = part_hist + (size_t)threadIdx.x * part_pitch + t0;
+        if (tiles_per_block == 8) {  // t0 and the pitch are multiples of 8: two aligned 16-byte stores
+            uint4 a, b;
+            a.x = s_ph[0][threadIdx.x]; a.y = s_ph[1][threadIdx.x]; a.z = s_ph[2][threadIdx.x]; a.w = s_ph[3][threadIdx.x];
+            b.x = s_ph[4][threadIdx.x]; b.y = s_ph[5][threadIdx.x]; b.z = s_ph[6][threadIdx.x]; b.w = s_ph[7][threadIdx.x];
+            reinterpret_cast<uint4*>(row)[0] = a;
+            reinterpret_cast<uint4*>(row)[1] = b;
+        } else {
+            for (uint32_t g = 0; g < tiles_per_block && t0 + g < part_pitch; ++g) row[g] = s_ph[g][threadIdx.x];
         }
     }
     if (global_digit_hist) {

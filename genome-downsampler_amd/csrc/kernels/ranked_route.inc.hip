@@ -48,7 +48,8 @@ template <int MODE, bool OUT_REC>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, SegTables seg,
     const uint64_t* __restrict__ contig_read_off, const uint64_t* __restrict__ contig_pos_off,
-    uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles, const uint32_t* __restrict__ offs,
+    uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles /* row pitch of offs, in tiles */,
+    const uint32_t* __restrict__ offs,
     uint16_t* __restrict__ out_key, uint32_t* __restrict__ out_idx, Rec* __restrict__ out_rec,
     uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
     extern __shared__ uint32_t s_part[];
