@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     const uint32_t t0 = blockIdx.x * tiles_per_block;
     for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
         const uint32_t tile = t0 + g;
-        uint32_t* s_h = s_ph[g];
-        if (part_hist) {
+        uint32_t* s_h = s_ph[g];  // this tile's own row: no barrier between tiles on its account
+        if (part_hist && digit0_hist) {
             s_h0[threadIdx.x] = 0;
             __syncthreads();
         }
@@ -126,12 +126,10 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 if (on) atomicAdd(&cstart[gs], 1u);
             }
         }
-        if (part_hist) {
+        if (part_hist && digit0_hist) {
             __syncthreads();
-            if (digit0_hist) {
-                digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
-                if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
-            }
+            digit0_hist[threadIdx.x * n_tiles + tile] = s_h0[threadIdx.x];
+            if (global_digit_hist) s_gh[0][threadIdx.x] += s_h0[threadIdx.x];
             __syncthreads();
         }
     }
