@@ -344,7 +344,6 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     // size the whole arena before anything is enqueued (growing a buffer frees it, and
     // hipFree would stall on the work in flight)
     {
-        const uint32_t tiles = qmcp::sort_tiles(n);
         const uint32_t tiles_seg = qmcp::seg_tile_bound(n);  // second partition level: tiles aligned to super-ranges
         const uint32_t spine_a = qmcp::scan_spine_entries(256u * tiles_seg);
         const uint32_t spine_b = qmcp::scan_spine_entries(ltot + 1) + 1;
