@@ -204,3 +204,54 @@ def test_mixed_spans_long_reads_reach_over_several_cuts(pkg, oracle, solver):
     s, e = np.concatenate([s1, s2]), np.concatenate([e1, e2])
     perm = rng.permutation(s.size)
     _check_mixed(pkg, oracle, solver, s[perm], e[perm], L, M)
+
+
+# ---------------------------------------------------------------- odd shapes
+
+
+@pytest.mark.parametrize("span", [1, 2, 64, 65])
+def test_many_contigs_tiny_spans_and_m_one(pkg, oracle, solver, span):
+    """200 contigs (stretch table: 200 contig starts + window cuts), spans of one and two bases, M = 1"""
+    rng = np.random.default_rng(1000 + span)
+    lengths = rng.integers(max(span, 50), 6000, size=200).astype(np.uint32)
+    lengths[rng.integers(0, 200, size=20)] = 0
+    parts, offs = [], [0]
+    for L in lengths:
+        L = int(L)
+        n = 0 if L < span or rng.random() < 0.2 else int(rng.integers(1, max(2, 3 * L // max(span, 8))))
+        s = rng.integers(0, L - span + 1, size=n, dtype=np.uint32) if n else np.zeros(0, np.uint32)
+        parts.append(s)
+        offs.append(offs[-1] + n)
+    s = np.concatenate(parts)
+    e = (s + np.uint32(span - 1)).astype(np.uint32)
+    offs = np.array(offs, dtype=np.uint64)
+    for M in (1, 3):
+        _check(pkg, oracle, solver, s, e, lengths, M, offs=offs, expect_split=False)
+    assert solver.last_stats.sweep_stretches >= int((lengths > 0).sum())
+
+
+def test_more_contigs_than_the_stretch_table_takes(pkg, oracle, solver):
+    """300 contigs: no split is attempted (one workgroup per contig already fills the chip)"""
+    rng = np.random.default_rng(9)
+    span, M = 40, 2
+    lengths = np.full(300, 5000, dtype=np.uint32)
+    counts = rng.integers(0, 400, size=300)
+    s = np.concatenate([rng.integers(0, 5000 - span + 1, size=int(c), dtype=np.uint32) for c in counts])
+    e = (s + np.uint32(span - 1)).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    whole, split = _check(pkg, oracle, solver, s, e, lengths, M, offs=offs, expect_split=False)
+    assert whole == split == 300
+
+
+def test_single_read_and_cap_above_every_coverage(pkg, oracle, solver):
+    """M above the deepest coverage: every position is a cut point and every read is kept"""
+    rng = np.random.default_rng(2)
+    L, span = 500_000, 100
+    s, e = _reads(rng, 40_000, L, span)
+    with _env(QMCP_HIP_CUTS="1"):
+        got = solver.solve(s, e, L, 1_000_000)
+        assert solver.last_stats.n_kept == s.size and solver.last_stats.sweep_stretches > 50
+        assert np.array_equal(got, oracle.solve(s, e, L, 1_000_000))
+        one = solver.solve(s[:1], e[:1], L, 5)
+        assert solver.last_stats.n_kept == 1
+        assert np.array_equal(one, oracle.solve(s[:1], e[:1], L, 5))
