@@ -243,11 +243,11 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
 #endif
 #define QMCP_GEN_REG(BB)                                                                              \
     if (wide)                                                                                          \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_wg), dim3(64), 0, st, boff,       \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_wg), dim3(128), 0, st, boff,       \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
                            max_span, M, selend, seg QMCP_GEN_STAMP_ARG);                               \
     else                                                                                               \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_wg), dim3(64), 0, st, boff,       \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_wg), dim3(128), 0, st, boff,       \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
                            M, selend, seg QMCP_GEN_STAMP_ARG);
     if (b <= 2) { QMCP_GEN_REG(2) }

@@ -318,12 +318,17 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
 // serial path.  Only the expiry counts of reads that end beyond the chunk go through an LDS ring
 // (fire-and-forget adds, read back when their chunk enters).  The chunk loop is unrolled B times so
 // that the slot a chunk's buckets enter is a compile-time index.
+// Two waves: the walker above, and a loader that stays one chunk ahead -- bucket bounds, coverage
+// and the first two groups of every entering bucket are three dependent trips to memory (~1.5 us),
+// which the walker would otherwise sit out at every chunk's entry (most of its time on shallow
+// data); the loader hands them over through LDS at one barrier per chunk and also stores the
+// selected counts of the buckets whose slot the chunk recycles.
 __device__ __forceinline__ uint32_t reg_sweep_key(uint32_t gx, uint32_t gy, uint32_t qrel, uint32_t pbase) {
     return gy != 0 ? (((gx - pbase) << 16) | (qrel << 7) | min(gy, 127u)) : 0u;
 }
 
 template <typename Sorted, int B>
-__global__ __launch_bounds__(64) void k_sweep_general_reg(
+__global__ __launch_bounds__(128) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
     uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend,
@@ -336,13 +341,20 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
     constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
     constexpr uint32_t kBack = 64u * (uint32_t)(B - 1);  // p0 - pbase
     __shared__ uint32_t s_exp[kRing];
-    const uint32_t lane = threadIdx.x;
+    // what the loader hands the walker for a chunk: need, bucket end, head group, second group, next
+    // unread group (double-buffered), and what the walker hands back: selected counts of the slot
+    // the chunk recycles
+    enum { kInNeed, kInB1, kInG0x, kInG0y, kInG1x, kInG1y, kInNext, kInWords };
+    __shared__ uint32_t s_in[2][kInWords][64];
+    __shared__ uint32_t s_tk[2][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 walker, 1 loader
     const uint32_t c_id = blockIdx.x;
     SweepSeg sg;
     if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
     const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint64_t code_mask = (1ull << span_bits) - 1;
-    for (uint32_t i = lane; i < kRing; i += 64) s_exp[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kRing; i += 128) s_exp[i] = 0;
     __syncthreads();
     const uint32_t* __restrict__ cb = boff + base;
     const uint32_t* __restrict__ ce = eoff + base;
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
     for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
     uint32_t cur = 0;  // selected reads covering the chunk's first position, before its own selections
     if (seg != nullptr) {
-        cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, kRing, lane);
+        if (role == 0) cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, kRing, lane);
         __syncthreads();
     }
     const uint32_t n_chunks = (L + 63) / 64;
@@ -369,6 +381,39 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
         }
     };
 
+    if (role == 1) {
+        // ---- loader: chunk c + 1 while the walker walks chunk c
+        auto enter = [&](uint32_t c) {
+            const uint32_t q = c * 64 + lane, buf = c & 1u;
+            uint32_t need = 0, b1 = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, nj = 0;
+            if (q < L) {
+                const uint32_t b0 = cb[q];
+                b1 = cb[q + 1];
+                need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
+                load_group(b0, b1, q, x0, y0);
+                load_group(b0 + y0, b1, q, x1, y1);
+                nj = b0 + y0 + y1;
+            }
+            s_in[buf][kInNeed][lane] = need; s_in[buf][kInB1][lane] = b1;
+            s_in[buf][kInG0x][lane] = x0; s_in[buf][kInG0y][lane] = y0;
+            s_in[buf][kInG1x][lane] = x1; s_in[buf][kInG1y][lane] = y1;
+            s_in[buf][kInNext][lane] = nj;
+        };
+        enter(0);
+        __syncthreads();  // chunk 0 handed over
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            // the slot chunk c recycles held the buckets of chunk c - B: their selected counts came in
+            // s_tk before the barrier that handed chunk c over
+            const uint32_t qq = c * 64 + lane - kRing;
+            if (c >= (uint32_t)B && qq < L) csel[qq] = cb[qq] + s_tk[c & 1u][lane];
+            if (c + 1 < n_chunks) {
+                enter(c + 1);
+                __syncthreads();  // chunk c + 1 handed over (the walker arrives when it has walked chunk c)
+            }
+        }
+        return;
+    }
+
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += B) {
 #pragma unroll
         for (int e = 0; e < B; ++e) {
@@ -378,20 +423,24 @@ __global__ __launch_bounds__(64) void k_sweep_general_reg(
 #ifdef QMCP_GEN_STAMP
             const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
-            // ---- the chunk's 64 buckets enter slot e (lane = position p0 + lane)
+            // ---- the chunk's 64 buckets enter slot e (lane = position p0 + lane): the slot's previous
+            // buckets hand their selected counts to the loader, which hands this chunk's buckets over
             const uint32_t q = p0 + lane;
             uint32_t need = 0, exp_c = 0;
-            if (c >= (uint32_t)B && q - kRing < L) csel[q - kRing] = cb[q - kRing] + taken[e];  // recycled slot
-            g0x[e] = g0y[e] = g1x[e] = g1y[e] = 0; nextj[e] = bend1[e] = taken[e] = 0;
+            if (c >= (uint32_t)B) s_tk[c & 1u][lane] = taken[e];
+            __syncthreads();
+            {
+                const uint32_t buf = c & 1u;
+                need = s_in[buf][kInNeed][lane];
+                bend1[e] = s_in[buf][kInB1][lane];
+                g0x[e] = s_in[buf][kInG0x][lane]; g0y[e] = s_in[buf][kInG0y][lane];
+                g1x[e] = s_in[buf][kInG1x][lane]; g1y[e] = s_in[buf][kInG1y][lane];
+                nextj[e] = s_in[buf][kInNext][lane];
+                taken[e] = 0;
+            }
             if (q < L) {
                 exp_c = s_exp[q % kRing];
                 s_exp[q % kRing] = 0;
-                const uint32_t b0 = cb[q], b1 = cb[q + 1];
-                need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
-                bend1[e] = b1;
-                load_group(b0, b1, q, g0x[e], g0y[e]);
-                load_group(b0 + g0y[e], b1, q, g1x[e], g1y[e]);
-                nextj[e] = b0 + g0y[e] + g1y[e];
             }
 #ifdef QMCP_GEN_STAMP
             __builtin_amdgcn_s_waitcnt(0);
