@@ -179,22 +179,26 @@ bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* 
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* sorted, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
-                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max) {
+                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max, uint32_t* g_rings) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
-    const size_t lds = 2 * (size_t)ring_size * sizeof(uint32_t);
-    if (wide) {
-        (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedK64>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<SortedK64>, dim3(n_wg), dim3(64), lds, st, boff, eoff,
-                           SortedK64{(const uint64_t*)sorted}, d_poff, span_bits, max_span, M, selend,
-                           ring_size, seg);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_sweep_general<SortedRec>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sweep_general<SortedRec>, dim3(n_wg), dim3(64), lds, st, boff, eoff,
-                           SortedRec{(const Rec*)sorted}, d_poff, span_bits, max_span, M, selend,
-                           ring_size, seg);
+    // rings in LDS while they fit (two of ring_size words); beyond that in g_rings (2 * ring_size words
+    // per workgroup)
+    const size_t lds = g_rings ? 0 : 2 * (size_t)ring_size * sizeof(uint32_t);
+#define QMCP_SWEEP_GENERAL(SORTED, ARG, GRING)                                                          \
+    {                                                                                                   \
+        (void)hipFuncSetAttribute((const void*)k_sweep_general<SORTED, GRING>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((k_sweep_general<SORTED, GRING>), dim3(n_wg), dim3(64), lds, st, boff, eoff, \
+                           ARG, d_poff, span_bits, max_span, M, selend, ring_size, seg, g_rings);       \
     }
+    if (wide) {
+        if (g_rings) QMCP_SWEEP_GENERAL(SortedK64, SortedK64{(const uint64_t*)sorted}, true)
+        else QMCP_SWEEP_GENERAL(SortedK64, SortedK64{(const uint64_t*)sorted}, false)
+    } else {
+        if (g_rings) QMCP_SWEEP_GENERAL(SortedRec, SortedRec{(const Rec*)sorted}, true)
+        else QMCP_SWEEP_GENERAL(SortedRec, SortedRec{(const Rec*)sorted}, false)
+    }
+#undef QMCP_SWEEP_GENERAL
 }
 
 void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t n,

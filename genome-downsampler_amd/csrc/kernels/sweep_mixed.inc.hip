@@ -35,17 +35,30 @@ __device__ __forceinline__ uint32_t seed_stretch_expiry(Sorted skeys, const uint
     return wave_sum_u32(count);
 }
 
-template <typename Sorted>
+// GRING: the two rings live in global memory (`g_rings`, 2 * ring_size words per workgroup) instead
+// of LDS -- spans beyond 16 383 (long reads); every ring access is then a write-through / L1-bypassing
+// access, ordered by the wave's program order and the workgroup barriers as the LDS ones are.
+template <typename Sorted, bool GRING>
 __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict__ boff,
                                                       const uint32_t* __restrict__ eoff,
                                                       Sorted skeys,
                                                       const uint64_t* __restrict__ contig_pos_off,
                                                       uint32_t span_bits, uint32_t max_span,
                                                       uint32_t M, uint32_t* __restrict__ selend,
-                                                      uint32_t ring_size, const uint32_t* __restrict__ seg) {
+                                                      uint32_t ring_size, const uint32_t* __restrict__ seg,
+                                                      uint32_t* g_rings) {
     extern __shared__ uint32_t s_ring[];
-    uint32_t* s_ptr = s_ring;              // [ring_size] bucket prefix pointers
-    uint32_t* s_exp = s_ring + ring_size;  // [ring_size] selected reads by end position
+    uint32_t* const ring = GRING ? g_rings + (size_t)blockIdx.x * 2u * ring_size : s_ring;
+    uint32_t* s_ptr = ring;              // [ring_size] bucket prefix pointers
+    uint32_t* s_exp = ring + ring_size;  // [ring_size] selected reads by end position
+    auto rd = [&](const uint32_t* a, uint32_t i) -> uint32_t {
+        if constexpr (GRING) return __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return a[i];
+    };
+    auto wr = [&](uint32_t* a, uint32_t i, uint32_t v) {
+        if constexpr (GRING) __hip_atomic_store(a + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a[i] = v;
+    };
     const uint32_t lane = threadIdx.x;
     const uint32_t c_id = blockIdx.x;
     SweepSeg sg;
@@ -53,7 +66,7 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
     const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint32_t rmask = ring_size - 1;
     const uint64_t code_mask = (1ull << span_bits) - 1;
-    for (uint32_t i = lane; i < 2 * ring_size; i += 64) s_ring[i] = 0;
+    for (uint32_t i = lane; i < 2 * ring_size; i += 64) wr(ring, i, 0u);
     __syncthreads();
     uint32_t cur = 0;
     if (seg != nullptr) {
@@ -65,9 +78,9 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
         if (lane == 0) {
             if (p >= ring_size) {
                 const uint32_t q = p - ring_size;  // long dead: ring_size > max_span
-                selend[base + q] = boff[base + q] + s_ptr[p & rmask];
+                selend[base + q] = boff[base + q] + rd(s_ptr, p & rmask);
             }
-            s_ptr[p & rmask] = 0;
+            wr(s_ptr, p & rmask, 0u);
         }
         __syncthreads();
         const uint32_t cov = boff[gp + 1] - eoff[gp];
@@ -80,7 +93,8 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
                 const uint32_t q = p - t;
                 const uint32_t gq = base + q;
                 const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
-                const uint32_t ptr = s_ptr[q & rmask];
+                if (b0 == b1) continue;  // nothing starts here (most positions, when reads are long)
+                const uint32_t ptr = rd(s_ptr, q & rmask);
                 if (b0 + ptr < b1) {
                     const uint64_t key = skeys.key(b0 + ptr);
                     const uint32_t span = max_span - (uint32_t)(key & code_mask);
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
             const uint32_t bq = (uint32_t)(best & 0xFFFFFFFFu) - 1;
             const uint32_t gq = base + bq;
             const uint32_t b0 = boff[gq], b1 = boff[gq + 1];
-            const uint32_t ptr = s_ptr[bq & rmask];
+            const uint32_t ptr = rd(s_ptr, bq & rmask);
             // length of the run of equal-end reads at the head of the winning bucket (<= 64)
             bool same = false;
             const uint32_t j = b0 + ptr + lane;
@@ -112,23 +126,23 @@ __global__ __launch_bounds__(64) void k_sweep_general(const uint32_t* __restrict
             const uint32_t take = min(k, run);
             __syncthreads();
             if (lane == 0) {
-                s_ptr[bq & rmask] = ptr + take;
-                s_exp[bend & rmask] += take;
+                wr(s_ptr, bq & rmask, ptr + take);
+                wr(s_exp, bend & rmask, rd(s_exp, bend & rmask) + take);
             }
             __syncthreads();
             cur += take;
             k -= take;
         }
         // reads ending at p stop covering p+1
-        const uint32_t ex = s_exp[p & rmask];
+        const uint32_t ex = rd(s_exp, p & rmask);
         cur -= ex;
         __syncthreads();
-        if (lane == 0) s_exp[p & rmask] = 0;
+        if (lane == 0) wr(s_exp, p & rmask, 0u);
     }
     __syncthreads();
     // flush the buckets still in the ring
     const uint32_t first = L > ring_size ? L - ring_size : 0u;
-    for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + s_ptr[q & rmask];
+    for (uint32_t q = first + lane; q < L; q += 64) selend[base + q] = boff[base + q] + rd(s_ptr, q & rmask);
 }
 // ------------------------------------------------------------------ mixed-span sweep, LDS-cached
 // Same rule as k_sweep_general, organised so that the serial loop touches LDS only:

@@ -73,6 +73,7 @@ struct qmcp_hip_ctx {
     uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
+    DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
     int profiling = 0;  // 0 off, 1 every kernel, 2 the selection sweep only
@@ -693,11 +694,18 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
                                               n_contigs, span_bits, max_span, M,
                                               (uint32_t*)c->selend.p, ring, seg, n_seg_max);
         } else {
+            uint32_t* g_rings = nullptr;
+            if (max_span > qmcp::kMaxLdsRingSpan) {
+                // long reads: the two rings of a workgroup no longer fit LDS
+                const size_t n_wg = seg ? n_seg_max : n_contigs;
+                TRY(ensure(c, c->rings, n_wg * 2 * (size_t)ring * sizeof(uint32_t)));
+                g_rings = (uint32_t*)c->rings.p;
+            }
             KernelSpan sp(c, "k_sweep_general");
             qmcp::launch_sweep_general(c->stream, wide, (const uint32_t*)c->boff.p,
                                        (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                        (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
-                                       (uint32_t*)c->selend.p, ring, seg, n_seg_max);
+                                       (uint32_t*)c->selend.p, ring, seg, n_seg_max, g_rings);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -857,7 +865,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

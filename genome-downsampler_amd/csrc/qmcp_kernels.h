@@ -7,7 +7,8 @@
 
 namespace qmcp {
 
-static constexpr uint32_t kMaxGeneralSpan = 16383;  // two LDS rings of 16384 u32 = 128 KiB
+static constexpr uint32_t kMaxLdsRingSpan = 16383;   // two LDS rings of 16384 u32 = 128 KiB
+static constexpr uint32_t kMaxGeneralSpan = (1u << 24) - 1;  // beyond kMaxLdsRingSpan the rings live in global memory
 static constexpr uint32_t kMaxUniformSpan = 512;    // 8 positions per lane in the block sweep
 static constexpr uint32_t kMaxCachedSpan = 4032;    // LDS-cached mixed-span sweep: 8 words x 4096 slots,
                                                     // ring >= max_span + 64 (a chunk enters 64 buckets at once)
@@ -63,7 +64,8 @@ bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* 
 void launch_sweep_general(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                           const void* skeys, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* selend,
-                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max);
+                          uint32_t ring_size, const uint32_t* seg, uint32_t n_seg_max,
+                          uint32_t* g_rings /* 2 * ring_size words per workgroup when the rings do not fit LDS, else null */);
 void launch_group_heads(hipStream_t st, bool wide, const void* sorted, uint32_t n,
                         uint32_t* next_head /* n + 1 entries; reverse-min-scan it afterwards */);
 void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff,

@@ -179,3 +179,25 @@ def test_many_small_contigs(pkg, oracle, solver):
         ss.append(a); ee.append(b)
     s, e = np.concatenate(ss), np.concatenate(ee)
     _check(pkg, oracle, solver, s, e, np.array(lens, np.uint32), 10, offs=offs, expect_path=pkg.PATH_GENERAL)
+
+
+@pytest.mark.parametrize("max_span,contigs", [(16_384, 1), (40_000, 1), (131_000, 2)])
+def test_long_reads_rings_in_global_memory(pkg, oracle, solver, max_span, contigs):
+    """spans beyond 16 383 (long reads, up to whole-genome length): the plain event sweep keeps its two
+    rings in global memory instead of LDS"""
+    rng = np.random.default_rng(max_span)
+    L = max_span + 9_000
+    ss, ee, offs = [], [], [0]
+    for c in range(contigs):
+        n = 3_000
+        span = np.where(rng.random(n) < 0.3, rng.integers(max_span // 2, max_span + 1, size=n), rng.integers(200, 3_000, size=n))
+        st = (rng.random(n) * (L - span + 1)).astype(np.int64)
+        if c == 0:
+            st[0], span[0] = 5, max_span  # the longest span occurs
+        ss.append(st.astype(np.uint32)); ee.append((st + span - 1).astype(np.uint32))
+        offs.append(offs[-1] + n)
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    lengths = np.full(contigs, L, dtype=np.uint32)
+    offs = np.array(offs, dtype=np.uint64)
+    for M in (2, 25):
+        _check(pkg, oracle, solver, s, e, lengths, M, offs=offs, expect_path=pkg.PATH_GENERAL)
