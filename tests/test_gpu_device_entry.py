@@ -40,7 +40,9 @@ def test_error_paths_leave_context_usable(pkg, solver):
     with pytest.raises(pkg.QmcpError) as ei:  # offsets do not end at n_reads
         solver.solve(z, z, np.array([10, 10], np.uint32), 1, contig_read_offsets=np.array([0, 2, 3], np.uint64))
     assert ei.value.code == -1
-    with pytest.raises(pkg.QmcpError) as ei:  # mixed spans beyond the LDS ring of the event sweep
-        solver.solve([0, 5], [20000, 6], 30000, 1)
+    with pytest.raises(pkg.QmcpError) as ei:  # mixed spans beyond what the event sweep's rings are sized for
+        solver.solve([0, 5], [1 << 24, 6], (1 << 24) + 10, 1)
     assert ei.value.code == -3
+    # (spans beyond the LDS rings are fine: rings in global memory)
+    assert pkg.mask_to_indices(solver.solve([0, 5], [20000, 6], 30000, 1), 2).tolist() == [0]
     assert solver.solve([0, 5], [9, 6], 10, 1).size == 1
