@@ -385,8 +385,21 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
     // list slots: one per position of the range, or (when the call has fewer reads than positions)
     // one per record of the range -- a listed position has at least one record
     uint2* const amb = amb_lists + (lists_by_records ? (size_t)range_start[range] : (size_t)range * width);
-    for (uint32_t i = tid; i < live; i += nthreads)
-        s_q[i] = (int32_t)(selend[pos0 + i] - boff[pos0 + i]);
+    // quotas: eight positions' two loads in flight per thread (a range of 32 Ki positions is 32 trips to
+    // memory per thread if taken one by one -- on sparse data, thousands of ranges of few reads, that
+    // was most of this kernel's time)
+    for (uint32_t i0 = tid; i0 < live; i0 += 8 * nthreads) {
+        uint32_t a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = min(i0 + u * nthreads, live - 1);  // clamped: every load is issued
+            a[u] = selend[pos0 + i];
+            b[u] = boff[pos0 + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * nthreads < live) s_q[i0 + u * nthreads] = (int32_t)(a[u] - b[u]);
+    }
     if (tid == 0) s_namb = 0;
     const uint32_t lo = range_start[range], hi = range_start[range + 1];
     if (lo >= hi) return;  // uniform
