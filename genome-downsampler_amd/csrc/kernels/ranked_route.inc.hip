@@ -497,5 +497,12 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
             skip = skip > in_step ? skip - in_step : 0u;
         }
     }
-    if (lane == 0 && kept) atomicAdd(kept_total, (unsigned long long)kept);
+    // one global add per workgroup (thousands of ranges on a long genome would otherwise queue sixteen
+    // same-address atomics each)
+    __syncthreads();
+    if (tid == 0) s_namb = 0;
+    __syncthreads();
+    if (lane == 0 && kept) atomicAdd(&s_namb, kept);
+    __syncthreads();
+    if (tid == 0 && s_namb) atomicAdd(kept_total, (unsigned long long)s_namb);
 }
