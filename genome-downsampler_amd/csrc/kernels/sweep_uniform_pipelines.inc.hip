@@ -526,6 +526,14 @@ struct MgLayout {
     static constexpr size_t kBytes = ((size_t)kSlots * kG * kWords + kSlots) * 64 * sizeof(uint32_t);
 };
 
+// wave-scan step s (row_shr 1, 2, 4, 8, row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3):
+// does this lane take nothing from another lane at it?
+__device__ __forceinline__ bool mg_no_source(int s, uint32_t lane) {
+    if (s < 4) return (lane & 15u) < (1u << s);
+    if (s == 4) return ((lane >> 4) & 1u) == 0;  // rows 0 and 2
+    return lane < 32;                            // rows 0 and 1
+}
+
 template <int E>
 __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __restrict__ boff,
                                                            const uint64_t* __restrict__ contig_pos_off,
@@ -602,8 +610,12 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                     // the (a, b) half of the wave scan, recording what each lane holds before every step
 #define MG_AB_STEP(s, ctrl, rmask)                                                         \
                     {                                                                      \
-                        MG_AT(slot, 0, Ly::kA + (s)) = a;                                  \
-                        MG_AT(slot, 0, Ly::kB + (s)) = b;                                  \
+                        /* lanes that take nothing at this step (no lane to their left in the row; the rows \
+                           the two cross-row steps skip): what they hold is never used there, and +inf in  \
+                           its place lets the chain wave fold its shifted read of u into the add (a DPP    \
+                           operand that reads 0 where there is no source lane) */          \
+                        MG_AT(slot, 0, Ly::kA + (s)) = mg_no_source(s, lane) ? kInf : a;  \
+                        MG_AT(slot, 0, Ly::kB + (s)) = mg_no_source(s, lane) ? kInf : b;  \
                         const uint32_t aL = QMCP_DPP(0u, a, ctrl, rmask);                  \
                         const uint32_t bL = QMCP_DPP(kInf, b, ctrl, rmask);                \
                         const uint32_t na = min(aL + a, bL), nb = min(aL + b, bL);         \
@@ -678,9 +690,10 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                             const uint32_t off2 = row < 2 ? 0u : 0xFFFFFFFFu;
                             const uint32_t off3 = row < 3 ? 0u : 0xFFFFFFFFu;
                             ws = min(min(ws, r1 | off1), min(r2 | off2, r3 | off3));
-                            const uint32_t after = min(QMCP_DPP(0xFFFFFFFFu, ws, 0x130, 0xF), kInf);
+                            // everything in the lanes above: the shifted read folds into each min (the last
+                            // lane has no lane above and keeps its own)
 #pragma unroll
-                            for (int r = 0; r < E; ++r) A[r] = min(A[r], after);
+                            for (int r = 0; r < E; ++r) A[r] = min(QMCP_DPP_UMIN(ws, 0x130, 0xF), A[r]);
                         }
                         // the lane's own (u, v)
                         uint32_t u = A[0], v = A[0] + exj[0];
@@ -699,18 +712,28 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                             const uint32_t nv = min(min(uL + bs[s], vL), v);           \
                             u = nu; v = nv;                                            \
                         }
-                        MG_UV_STEP(0, 0x111, 0xF)
-                        MG_UV_STEP(1, 0x112, 0xF)
-                        MG_UV_STEP(2, 0x114, 0xF)
-                        MG_UV_STEP(3, 0x118, 0xF)
-                        MG_UV_STEP(4, 0x142, 0xA)
-                        MG_UV_STEP(5, 0x143, 0xC)
+                        // lanes that take nothing at a step read u as 0 (or some other row's) and find +inf in
+                        // as / bs (PREP put it there), so the shifted read of u folds into the add
+#define MG_UV_STEP_ROW(s, ctrl, vmask)                                                 \
+                        {                                                              \
+                            const uint32_t uL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, ctrl, 0xF, 0xF, true); \
+                            const uint32_t vL = QMCP_DPP(kInf, v, ctrl, vmask);        \
+                            const uint32_t nu = min(min(uL + as[s], vL), u);           \
+                            const uint32_t nv = min(min(uL + bs[s], vL), v);           \
+                            u = nu; v = nv;                                            \
+                        }
+                        MG_UV_STEP_ROW(0, 0x111, 0xF)
+                        MG_UV_STEP_ROW(1, 0x112, 0xF)
+                        MG_UV_STEP_ROW(2, 0x114, 0xF)
+                        MG_UV_STEP_ROW(3, 0x118, 0xF)
+                        MG_UV_STEP_ROW(4, 0x142, 0xA)
+                        MG_UV_STEP_ROW(5, 0x143, 0xC)
+#undef MG_UV_STEP_ROW
 #undef MG_UV_STEP
-                        const uint32_t pu = QMCP_DPP(kInf, u, 0x138, 0xF);
-                        const uint32_t pv = QMCP_DPP(kInf, v, 0x138, 0xF);
-                        // state entering this lane: the map of all lower lanes applied to (d_last, +inf)
-                        uint32_t dd = min(d_last + pa, pu);
-                        uint32_t m = min(d_last + pb, pv);
+                        // state entering this lane: the map of all lower lanes applied to (d_last, +inf); the
+                        // shifted reads of u and v fold into the mins (lane 0 has no lower lane: identity)
+                        uint32_t dd = min(QMCP_DPP_UMIN(u, 0x138, 0xF), d_last + pa);
+                        uint32_t m = min(QMCP_DPP_UMIN(v, 0x138, 0xF), d_last + pb);
 #pragma unroll
                         for (int r = 0; r < E; ++r) {
                             dd = min(min(dd + cnt[r], m), A[r]);
