@@ -263,7 +263,7 @@ int scan_counts(qmcp_hip_ctx* c, DevBuf& counts, DevBuf& out, uint32_t ltot) {
 // the radix sort it replaces
 constexpr uint64_t kRankBalance = 24;
 // mean coverage / M below which the sweep runs every block in the general form (lab/sweep_lab.hip)
-constexpr double kGenDepth = 9.0;  // lab: fast 668 vs general 653 cycles per block at 9 x M, 500 vs 652 at 12 x M
+constexpr double kGenDepth = 11.0;  // lab, cycles per block fast / general: 674 / 542 at 9 x M, 595 / 545 at 10.5, 500 / 543 at 12
 // ... and when the call is large enough for a per-range workgroup to have work (QMCP_HIP_RANK_MIN
 // overrides, for experiments)
 static uint32_t rank_min_reads() {

@@ -116,6 +116,9 @@ int main() {
     run_case("depth 4.5 x M", 1.5, 400000, 150, 50, 1);
     run_case("depth 6 x M", 2.0, 400000, 150, 50, 1);
     run_case("depth 9 x M", 3.0, 400000, 150, 50, 1);
+    run_case("depth 10.5 x M", 3.5, 400000, 150, 50, 1);
     run_case("depth 12 x M", 4.0, 400000, 150, 50, 1);
+    run_case("depth 13.5 x M", 4.5, 400000, 150, 50, 1);
+    run_case("depth 15 x M", 5.0, 400000, 150, 50, 1);
     return 0;
 }
