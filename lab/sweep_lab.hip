@@ -32,7 +32,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
     const uint32_t nb = (L + ell - 1) / ell;
     printf("%-34s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form blocks %u of %u)\n", name, best,
            best * 1e6 / nb, best * 1e6 / nb * 2.4, it2[0] / reps, it2[1] / reps);
-    // three-wave kernel on the same data: must produce identical selend
+    // seven-wave fast pipeline on the same data: must produce identical selend
     {
         std::vector<uint32_t> ref(Lt + 1), got(Lt + 1);
         hipMemcpy(ref.data(), d_sel, (Lt + 1) * 4, hipMemcpyDeviceToHost);
@@ -76,7 +76,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         size_t diff = 0, first = 0;
         for (uint64_t i = 0; i < Lt; ++i) if (ref[i] != got[i]) { if (!diff) first = i; ++diff; }
         printf("   cold (caches flushed): %.3f ms\n", cold);
-        printf("   three-wave: %s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form %u) mismatches %zu (first at %zu) %s\n",
+        printf("   seven-wave: %s %.3f ms  %.1f ns/block ~%.0f cyc/block (general-form %u) mismatches %zu (first at %zu) %s\n",
                ok ? "" : "(unsupported span)", best2, best2 * 1e6 / nb, best2 * 1e6 / nb * 2.4, it2[0] / reps, diff, first,
                hipGetErrorString(e));
     }
