@@ -239,75 +239,77 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
             s_b1[slot] = b1;
             s_taken[slot] = 0;
         }
-        // ---- walk the chunk's positions; per-position need / expiry come from lane registers
-        const uint32_t chunk = min(64u, L - p0);
-        for (uint32_t j = 0; j < chunk; ++j) {
+        // ---- walk the chunk, event by event: lane j holds need(p0 + j) and the selected coverage at
+        // p0 + j given the selections so far (exclusive prefix sum of the chunk's expiry counts, then
+        // += take on the lanes a selected group covers), so the next position with a deficit is one
+        // ballot away and positions without one cost nothing
+        uint32_t curv = cur - (wave_incl_scan_add(exp_c) - exp_c);
+        for (;;) {
+            const unsigned long long pend = __ballot(need > curv);
+            if (pend == 0) break;
+            const uint32_t j = (uint32_t)__ffsll((long long)pend) - 1;  // first position with a deficit
             const uint32_t p = p0 + j;
-            const uint32_t need_p = __builtin_amdgcn_readlane(need, j);
-            uint32_t k = need_p > cur ? need_p - cur : 0u;
-            while (k > 0) {
-                // best live head among buckets q' in (p - max_span, p]:
-                // key = (end + 1 - p) << 16 | (0xFFFF - (p - q')): largest end, then largest start
-                uint32_t best = 0, my_run = 0;
-                for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
-                    const uint2 g = s_g0[(p - t) & rmask];
-                    if (g.x > p) {
-                        const uint32_t key = ((g.x - p) << 16) | (0xFFFFu - t);
-                        if (key > best) { best = key; my_run = g.y; }
-                    }
+            const uint32_t k = __builtin_amdgcn_readlane(need - curv, j);
+            // best live head among buckets q' in (p - max_span, p]:
+            // key = (end + 1 - p) << 16 | (0xFFFF - (p - q')): largest end, then largest start
+            uint32_t best = 0, my_run = 0;
+            for (uint32_t t = lane; t < max_span && t <= p; t += 64) {
+                const uint2 g = s_g0[(p - t) & rmask];
+                if (g.x > p) {
+                    const uint32_t key = ((g.x - p) << 16) | (0xFFFFu - t);
+                    if (key > best) { best = key; my_run = g.y; }
                 }
-                uint32_t top = best;
-                top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
-                top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
-                top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
-                top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
-                top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
-                top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
-                top = __builtin_amdgcn_readlane(top, 63);
-                if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
-                const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
-                const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
-                const uint32_t bq = p - (0xFFFFu - (top & 0xFFFFu));
-                const uint32_t bslot = bq & rmask;
-                const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group
-                const uint32_t take = min(k, run);
-                // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
-                if (bend < p0 + 64) {
-                    exp_c += (lane == bend - p0) ? take : 0u;
-                } else if (lane == 0) {
-                    atomicAdd(&s_exp[bend & rmask], take);
-                }
-                if (lane == 0) {
-                    atomicAdd(&s_taken[bslot], take);
-                    if (take < run) {
-                        s_g0[bslot].y = run - take;
-                    } else {
-                        const uint2 g1 = s_g1[bslot];
-                        if (g1.y != 0) {
-                            // group used up: promote the cached second group (refilled lazily)
-                            s_g0[bslot] = g1;
-                            s_g1[bslot].y = 0;
-                        } else {
-                            // both cached groups used: fetch the bucket's next group, if any
-                            const uint32_t nj = s_nextj[bslot];
-                            const uint32_t b1 = s_b1[bslot];
-                            uint2 g0 = make_uint2(0, 0);
-                            if (nj < b1) {
-                                const uint64_t kk = skeys.key(nj);
-                                g0.y = min(next_head[nj + 1], b1) - nj;
-                                g0.x = bq + (max_span - (uint32_t)(kk & code_mask));
-                                s_nextj[bslot] = nj + g0.y;
-                            }
-                            s_g0[bslot] = g0;
-                        }
-                    }
-                }
-                cur += take;
-                k -= take;
             }
-            // reads ending at p stop covering p + 1
-            cur -= __builtin_amdgcn_readlane(exp_c, j);
+            uint32_t top = best;
+            top = max(top, QMCP_DPP(0u, top, 0x111, 0xF));
+            top = max(top, QMCP_DPP(0u, top, 0x112, 0xF));
+            top = max(top, QMCP_DPP(0u, top, 0x114, 0xF));
+            top = max(top, QMCP_DPP(0u, top, 0x118, 0xF));
+            top = max(top, QMCP_DPP(0u, top, 0x142, 0xA));
+            top = max(top, QMCP_DPP(0u, top, 0x143, 0xC));
+            top = __builtin_amdgcn_readlane(top, 63);
+            if (top == 0) break;  // cannot happen (need <= cov); keeps the loop finite
+            const uint32_t src = (uint32_t)__ffsll((long long)__ballot(best == top)) - 1;
+            const uint32_t run = __builtin_amdgcn_readlane(my_run, src);
+            const uint32_t bq = p - (0xFFFFu - (top & 0xFFFFu));
+            const uint32_t bslot = bq & rmask;
+            const uint32_t bend = p + (top >> 16) - 1;  // end of the winning group (>= p: it is live)
+            const uint32_t take = min(k, run);
+            // expiry bookkeeping: inside the chunk in the lane register, beyond it in the ring
+            if (bend < p0 + 64) {
+                exp_c += (lane == bend - p0) ? take : 0u;
+            } else if (lane == 0) {
+                atomicAdd(&s_exp[bend & rmask], take);
+            }
+            curv += (lane >= j && lane <= bend - p0) ? take : 0u;
+            if (lane == 0) {
+                atomicAdd(&s_taken[bslot], take);
+                if (take < run) {
+                    s_g0[bslot].y = run - take;
+                } else {
+                    const uint2 g1 = s_g1[bslot];
+                    if (g1.y != 0) {
+                        // group used up: promote the cached second group (refilled lazily)
+                        s_g0[bslot] = g1;
+                        s_g1[bslot].y = 0;
+                    } else {
+                        // both cached groups used: fetch the bucket's next group, if any
+                        const uint32_t nj = s_nextj[bslot];
+                        const uint32_t b1 = s_b1[bslot];
+                        uint2 g0 = make_uint2(0, 0);
+                        if (nj < b1) {
+                            const uint64_t kk = skeys.key(nj);
+                            g0.y = min(next_head[nj + 1], b1) - nj;
+                            g0.x = bq + (max_span - (uint32_t)(kk & code_mask));
+                            s_nextj[bslot] = nj + g0.y;
+                        }
+                        s_g0[bslot] = g0;
+                    }
+                }
+            }
         }
+        // reads ending at the chunk's last position stop covering the next chunk
+        cur = __builtin_amdgcn_readlane(curv - exp_c, 63);
     }
     // flush the buckets still in the ring
     const uint32_t first = L > ring ? L - ring : 0u;
