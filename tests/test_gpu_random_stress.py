@@ -98,3 +98,30 @@ def test_random_shallow_mixed_span_case_split_at_cut_points(pkg, oracle, solver,
     assert solver.last_stats.path == pkg.PATH_GENERAL
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_wide_mixed_spans(pkg, oracle, solver, seed, monkeypatch):
+    """spans from tens to thousands of bases (the LDS-cached event sweep, beyond 4 032 the plain one), deep
+    and shallow, with and without the cut-point split"""
+    rng = np.random.default_rng(30_000 + seed)
+    hi = int(rng.choice([500, 1200, 2500, 4032, 5000]))
+    lo = int(rng.integers(1, hi // 2))
+    n_contigs = int(rng.integers(1, 4))
+    lengths, counts, ss, ee = [], [], [], []
+    for _ in range(n_contigs):
+        L = int(rng.integers(hi + 10, 60_000))
+        c = int(rng.integers(0, 30_000))
+        span = rng.integers(lo, hi + 1, size=c)
+        st = (rng.random(c) * (L - span + 1)).astype(np.int64)
+        lengths.append(L); counts.append(c)
+        ss.append(st.astype(np.uint32)); ee.append((st + span - 1).astype(np.uint32))
+    if sum(counts) == 0:
+        return
+    s, e = np.concatenate(ss), np.concatenate(ee)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    M = int(rng.choice([1, 3, 20, 150]))
+    monkeypatch.setenv("QMCP_HIP_CUTS", "1" if seed % 2 else "0")
+    got = solver.solve(s, e, np.array(lengths, np.uint32), M, contig_read_offsets=offs)
+    want = oracle.solve(s, e, np.array(lengths, np.uint32), M, contig_read_offsets=offs)
+    assert np.array_equal(got, want), (seed, lo, hi, lengths, counts, M)
