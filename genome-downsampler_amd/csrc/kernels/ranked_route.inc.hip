@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
             rec[k].val = i;
         }
     }
+    uint32_t match_bits = 8;  // digit bits that can differ inside this pass
     if (MODE == 1) {
         // `keys` holds contig-relative starts: add the contig's position offset.  Almost every pass
         // lies inside one contig (reads are grouped by contig); otherwise search per read.
@@ -132,6 +133,14 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
             return lo;
         };
         const uint32_t c_first = contig_of(base), c_last = contig_of(base + count - 1);
+        // the pass's digits lie in the range the contigs it touches span: their low bit_width(hi - lo)
+        // bits tell them apart, so the in-wave match below needs that many ballots, not eight
+        {
+            const uint32_t d_lo = ((uint32_t)contig_pos_off[c_first] >> shift) & 255u;
+            const uint32_t d_hi = (((uint32_t)contig_pos_off[c_last + 1] - 1u) >> shift) & 255u;
+            match_bits = d_hi >= d_lo ? 32u - (uint32_t)__builtin_clz((d_hi - d_lo) | 1u) : 8u;
+            if (d_hi == d_lo) match_bits = 0;
+        }
         if (c_first == c_last) {
             const uint32_t p0 = (uint32_t)contig_pos_off[c_first];
 #pragma unroll
@@ -153,8 +162,10 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         if (!valid) peers = ~peers;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+            if ((uint32_t)b < match_bits) {  // uniform
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
         }
         const uint32_t in_group = __popcll(peers & lt_mask);
         const int leader = __ffsll((long long)peers) - 1;
