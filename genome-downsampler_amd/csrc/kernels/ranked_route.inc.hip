@@ -169,12 +169,11 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         }
         const uint32_t in_group = __popcll(peers & lt_mask);
         const int leader = __ffsll((long long)peers) - 1;
-        uint32_t old = 0;
-        if (valid && lane == leader) {
-            old = s_cnt[w * 256 + d];
-            s_cnt[w * 256 + d] = old + __popcll(peers);
-        }
-        old = (uint32_t)__shfl((int)old, leader, kWave);
+        // every lane of the group reads the wave's running count of its digit (a broadcast read), then
+        // the group's first lane moves it on: a wave's LDS operations execute in order, so the read is
+        // the value before this round and the next round's read sees the write
+        const uint32_t old = s_cnt[w * 256 + d];
+        if (valid && lane == leader) s_cnt[w * 256 + d] = old + __popcll(peers);
         rank[k] = old + in_group;
     }
     __syncthreads();
