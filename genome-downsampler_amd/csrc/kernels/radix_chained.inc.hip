@@ -66,12 +66,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(
         }
         const uint32_t in_group = __popcll(peers & lt_mask);
         const int leader = __ffsll((long long)peers) - 1;
-        uint32_t old = 0;
-        if (valid && lane == leader) {
-            old = s_cnt[w][d];
-            s_cnt[w][d] = old + __popcll(peers);
-        }
-        old = (uint32_t)__shfl((int)old, leader, kWave);
+        // broadcast read of the wave's running count, then the group's first lane moves it on (a wave's
+        // LDS operations execute in order)
+        const uint32_t old = s_cnt[w][d];
+        if (valid && lane == leader) s_cnt[w][d] = old + __popcll(peers);
         rank[k] = old + in_group;
     }
     __syncthreads();
