@@ -85,18 +85,32 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
         };
         const uint32_t c_first = n_contigs > 1 ? contig_of(tbase) : 0u;
         const uint32_t c_last = n_contigs > 1 ? contig_of(tbase + tcount - 1) : 0u;
+        // the usual tile lies inside one contig: its offset and length once per tile (uniform)
+        const bool one_contig = c_first == c_last;
+        uint32_t tile_p0 = 0, tile_len = 0;
+        {
+            uint64_t p0, p1;
+            if (n_contigs <= 64) { p0 = s_poff[c_first]; p1 = s_poff[c_first + 1]; }
+            else { p0 = contig_pos_off[c_first]; p1 = contig_pos_off[c_first + 1]; }
+            tile_p0 = (uint32_t)p0;
+            tile_len = (uint32_t)(p1 - p0);
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t j = k * 256u + threadIdx.x;
             if (j >= tcount) break;
             const uint32_t i = tbase + j;
             const uint32_t s = sv[k], e = ev[k];
-            const uint32_t c = c_first == c_last ? c_first : contig_of(i);
-            uint64_t p0, p1;
-            if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
-            else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
-            const uint32_t len_c = (uint32_t)(p1 - p0);
-            const uint32_t gs = (uint32_t)p0 + s;
+            uint32_t len_c = tile_len, pos0 = tile_p0;
+            if (!one_contig) {
+                const uint32_t c = contig_of(i);
+                uint64_t p0, p1;
+                if (n_contigs <= 64) { p0 = s_poff[c]; p1 = s_poff[c + 1]; }
+                else { p0 = contig_pos_off[c]; p1 = contig_pos_off[c + 1]; }
+                len_c = (uint32_t)(p1 - p0);
+                pos0 = (uint32_t)p0;
+            }
+            const uint32_t gs = pos0 + s;
             if (s > e || e >= len_c) {
                 // the call will fail, but kernels queued behind this one before the host knows must
                 // stay in bounds: the read is counted under the digit the partition will compute
