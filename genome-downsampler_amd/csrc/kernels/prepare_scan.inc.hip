@@ -95,6 +95,22 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             tile_p0 = (uint32_t)p0;
             tile_len = (uint32_t)(p1 - p0);
         }
+        // the ranked route's whole tiles inside one contig (all but a handful): validate, span range and
+        // the partition digit, nothing else and no branch per read (an invalid read makes the call fail;
+        // what its span adds to the statistics is then never looked at)
+        const bool lean = part_hist != nullptr && gstart_out == nullptr && digit0_hist == nullptr &&
+                          global_digit_hist == nullptr && cstart == nullptr && one_contig && tcount == 4096u;
+        if (lean) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t s = sv[k], e = ev[k];
+                bad |= (s > e || e >= tile_len) ? 1u : 0u;
+                const uint32_t span = e - s + 1;
+                mn = min(mn, span);
+                mx = max(mx, span);
+                atomicAdd(&s_h[((tile_p0 + s) >> part_shift) & 255u], 1u);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t j = k * 256u + threadIdx.x;
