@@ -82,6 +82,9 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         off_stride = n_tiles;
     }
     const uint32_t count = min((uint32_t)kPartRecs, bound - base);
+    // where this pass's run of every range begins: a lone word per range from the offset table, asked
+    // for now so that its trip to memory is over when the counts are in
+    const uint32_t run_begin = threadIdx.x < 256 ? offs[off0 + threadIdx.x * off_stride] : 0u;
     for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
     if (MODE != 2 && blockIdx.x == 0) {
         // the first workgroup also publishes where every range's records begin (257 entries) and the
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         uint32_t run = tile_off;
 #pragma unroll
         for (int x = 0; x < kPartWaves; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
-        s_gbase[d] = offs[off0 + d * off_stride] - tile_off;
+        s_gbase[d] = run_begin - tile_off;
     }
     __syncthreads();
 #pragma unroll
