@@ -85,6 +85,22 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     // where this pass's run of every range begins: a lone word per range from the offset table, asked
     // for now so that its trip to memory is over when the counts are in
     const uint32_t run_begin = threadIdx.x < 256 ? offs[off0 + threadIdx.x * off_stride] : 0u;
+    // (loads first: they travel while the counters are cleared)
+    // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
+    // range = (wave, round, lane) = input order
+    const uint32_t wbase = base + w * (kSortItems * 64);
+    Rec rec[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        if (MODE == 2) {
+            rec[k] = i < bound ? recs_in[i] : Rec{0u, 0u};
+        } else {
+            rec[k].key = i < bound ? keys[i] : 0u;
+            rec[k].val = i;
+        }
+    }
     for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
     if (MODE != 2 && blockIdx.x == 0) {
         // the first workgroup also publishes where every range's records begin (257 entries) and the
@@ -108,21 +124,6 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         }
     }
     __syncthreads();
-    // wave w owns records [w * 1024, (w + 1) * 1024) of the pass, in 16 rounds of 64: order inside a
-    // range = (wave, round, lane) = input order
-    const uint32_t wbase = base + w * (kSortItems * 64);
-    Rec rec[kSortItems];
-    uint32_t rank[kSortItems];
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t i = wbase + k * 64 + lane;
-        if (MODE == 2) {
-            rec[k] = i < bound ? recs_in[i] : Rec{0u, 0u};
-        } else {
-            rec[k].key = i < bound ? keys[i] : 0u;
-            rec[k].val = i;
-        }
-    }
     uint32_t match_bits = 8;  // digit bits that can differ inside this pass
     if (MODE == 1) {
         // `keys` holds contig-relative starts: add the contig's position offset.  Almost every pass
