@@ -306,9 +306,9 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
 #define PADDED(i) ((i) + ((i) >> 5))
     __shared__ uint32_t s_wsum[16];
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
+    const uint32_t lo = range_start[range], hi = range_start[range + 1];  // (asked for before the clearing)
     for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[PADDED(i)] = 0;
     __syncthreads();
-    const uint32_t lo = range_start[range], hi = range_start[range + 1];
     // The range's 16-bit records are read four at a time (8-byte loads from the first 8-byte-aligned
     // record on), eight loads in flight per thread: 64 KiB in flight per workgroup -- what it takes
     // to keep a CU's share of HBM busy at ~2 us latency (2-byte loads, 16 KiB in flight: 2.9 TB/s).
@@ -398,7 +398,9 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
     const uint32_t lane = tid & 63u, w = tid >> 6;
     // list slots: one per position of the range, or (when the call has fewer reads than positions)
     // one per record of the range -- a listed position has at least one record
-    uint2* const amb = amb_lists + (lists_by_records ? (size_t)range_start[range] : (size_t)range * width);
+    const uint32_t lo = range_start[range], hi = range_start[range + 1];
+    if (lo >= hi) return;  // uniform: a range without reads needs no quotas either
+    uint2* const amb = amb_lists + (lists_by_records ? (size_t)lo : (size_t)range * width);
     // quotas: eight positions' two loads in flight per thread (a range of 32 Ki positions is 32 trips to
     // memory per thread if taken one by one -- on sparse data, thousands of ranges of few reads, that
     // was most of this kernel's time)
@@ -415,8 +417,6 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
             if (i0 + u * nthreads < live) s_q[i0 + u * nthreads] = (int32_t)(a[u] - b[u]);
     }
     if (tid == 0) s_namb = 0;
-    const uint32_t lo = range_start[range], hi = range_start[range + 1];
-    if (lo >= hi) return;  // uniform
     __syncthreads();
     const uint32_t chunk_recs = kRankU * nthreads;
     const uint32_t n_chunks = (hi - lo + chunk_recs - 1) / chunk_recs;
