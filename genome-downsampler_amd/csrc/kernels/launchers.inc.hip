@@ -8,8 +8,9 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 *
 }
 
 static inline uint32_t tiles_per_block_for(uint32_t n_tiles);
-// row pitch, in tiles, of the range partition's [digit][tile] count / offset table
-uint32_t part_tile_pitch(uint32_t n) { return (sort_tiles(n) + 7u) & ~7u; }
+// row pitch, in partition passes (pairs of tiles), of the range partition's [digit][pass] count /
+// offset table
+uint32_t part_pass_pitch(uint32_t n) { return (((sort_tiles(n) + 1u) >> 1) + 3u) & ~3u; }
 
 void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
@@ -18,13 +19,14 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     uint32_t* digit0_hist, uint32_t* global_digit_hist, unsigned long long* zero_mask) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
-    const uint32_t g = tiles_per_block_for(n_tiles);
-    // the partition table's rows are padded to part_tile_pitch(n) tiles; the workgroups cover the
-    // padding too (empty tiles: zero counts)
-    const uint32_t covered = part_hist ? part_tile_pitch(n) : n_tiles;
+    uint32_t g = tiles_per_block_for(n_tiles);
+    // the partition table has one entry per pass (a pair of tiles) and rows padded to part_pass_pitch(n):
+    // a workgroup takes whole passes, and the workgroups cover the padding too (empty tiles: zero counts)
+    if (part_hist) g = (g + 1u) & ~1u;
+    const uint32_t covered = part_hist ? 2u * part_pass_pitch(n) : n_tiles;
     hipLaunchKernelGGL(k_prepare, dim3((covered + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       part_shift, part_hist, part_tile_pitch(n), digit0_hist, global_digit_hist, zero_mask);
+                       part_shift, part_hist, part_pass_pitch(n), digit0_hist, global_digit_hist, zero_mask);
 }
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
@@ -383,10 +385,10 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
     const SegTables none{nullptr, nullptr, nullptr};
     if (gstart_or_null)
         launch_partition_t<0, false>(st, grid, gstart_or_null, nullptr, none, d_roff, d_poff, n_contigs, n, shift,
-                                     part_tile_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
+                                     part_pass_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
     else
         launch_partition_t<1, false>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift,
-                                     part_tile_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
+                                     part_pass_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
 }
 
 // Two-level route.  Level 1: stable partition of the reads into <= 256 super-ranges of 2^(shift+8)
@@ -400,7 +402,7 @@ void launch_partition_level1(hipStream_t st, const uint32_t* starts, const uint6
     const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles);
     const SegTables none{nullptr, nullptr, nullptr};
     launch_partition_t<1, true>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift_hi,
-                                part_tile_pitch(n), offs, nullptr, nullptr, (Rec*)recs_out, super_start,
+                                part_pass_pitch(n), offs, nullptr, nullptr, (Rec*)recs_out, super_start,
                                 max_super_load);
 }
 // Level 2: every super-range is partitioned on its own into its (<= 256) final ranges.

@@ -27,14 +27,15 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     __shared__ uint64_t s_roff[65];
     __shared__ uint64_t s_poff[65];
-    // partition histograms of the workgroup's (up to 8) consecutive tiles, written together at the
-    // end: the table is laid out [digit][tile] (row pitch part_pitch, a multiple of 8), so a thread's
-    // eight tile counts are one aligned 32-byte run of its digit's row instead of eight lone words
-    // in eight rows' worth of evicted lines (that cost 8x the table's size in HBM writes)
-    __shared__ uint32_t s_ph[8][256];
+    // partition histograms of the workgroup's consecutive tiles, one per partition PASS (a pair of
+    // tiles: the partition kernel stages two and only needs the pair's counts), written together at the
+    // end: the table is laid out [digit][pass] (row pitch part_pitch, a multiple of 4), so a thread's
+    // four pass counts are one aligned 16-byte run of its digit's row instead of lone words in rows'
+    // worth of evicted lines (that cost 8x the table's size in HBM writes)
+    __shared__ uint32_t s_ph[4][256];
     __shared__ uint32_t s_h0[256];
     if (part_hist)
-        for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) (&s_ph[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_ph[0][0])[i] = 0;
     const uint32_t nc = min(n_contigs, 64u);
     for (uint32_t i = threadIdx.x; i <= nc; i += blockDim.x) {
         s_roff[i] = contig_read_off[i];
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     const uint32_t t0 = blockIdx.x * tiles_per_block;
     for (uint32_t g = 0; g < tiles_per_block && t0 + g < n_tiles; ++g) {
         const uint32_t tile = t0 + g;
-        uint32_t* s_h = s_ph[g];  // this tile's own row: no barrier between tiles on its account
+        uint32_t* s_h = s_ph[g >> 1];  // the pass's own row (the launcher keeps tiles_per_block even): no barrier between tiles on its account
         if (part_hist && digit0_hist) {
             s_h0[threadIdx.x] = 0;
             __syncthreads();
@@ -165,15 +166,14 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     }
     if (part_hist) {
         __syncthreads();
-        uint32_t* row = part_hist + (size_t)threadIdx.x * part_pitch + t0;
-        if (tiles_per_block == 8) {  // t0 and the pitch are multiples of 8: two aligned 16-byte stores
-            uint4 a, b;
+        const uint32_t pass0 = t0 >> 1, n_pass = tiles_per_block >> 1;
+        uint32_t* row = part_hist + (size_t)threadIdx.x * part_pitch + pass0;
+        if (tiles_per_block == 8) {  // pass0 and the pitch are multiples of 4: one aligned 16-byte store
+            uint4 a;
             a.x = s_ph[0][threadIdx.x]; a.y = s_ph[1][threadIdx.x]; a.z = s_ph[2][threadIdx.x]; a.w = s_ph[3][threadIdx.x];
-            b.x = s_ph[4][threadIdx.x]; b.y = s_ph[5][threadIdx.x]; b.z = s_ph[6][threadIdx.x]; b.w = s_ph[7][threadIdx.x];
             reinterpret_cast<uint4*>(row)[0] = a;
-            reinterpret_cast<uint4*>(row)[1] = b;
         } else {
-            for (uint32_t g = 0; g < tiles_per_block && t0 + g < part_pitch; ++g) row[g] = s_ph[g][threadIdx.x];
+            for (uint32_t h = 0; h < n_pass && pass0 + h < part_pitch; ++h) row[h] = s_ph[h][threadIdx.x];
         }
     }
     if (global_digit_hist) {

@@ -24,6 +24,7 @@ static constexpr uint32_t kMaxRangeShift = 15;  // 32 Ki positions x 4 B = 128 K
 #define QMCP_PART_TILES 2  // measured on cfg4: 1 tile 0.64 ms, 2 tiles 0.34 ms, 4 tiles 0.46 ms
 #endif
 static constexpr int kPartTiles = QMCP_PART_TILES;             // 4096-read tiles per workgroup pass
+static_assert(kPartTiles == 2, "k_prepare writes its partition table per pair of tiles");
 static constexpr int kPartRecs = kPartTiles * kSortTile;      // 16384
 static constexpr int kPartThreads = 256 * kPartTiles;
 static constexpr int kPartWaves = kPartThreads / 64;
@@ -48,7 +49,7 @@ template <int MODE, bool OUT_REC>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, SegTables seg,
     const uint64_t* __restrict__ contig_read_off, const uint64_t* __restrict__ contig_pos_off,
-    uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles /* row pitch of offs, in tiles */,
+    uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles /* row pitch of offs (MODE 0/1: in passes) */,
     const uint32_t* __restrict__ offs,
     uint16_t* __restrict__ out_key, uint32_t* __restrict__ out_idx, Rec* __restrict__ out_rec,
     uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     } else {
         base = blockIdx.x * kPartRecs;
         bound = n;
-        off0 = blockIdx.x * kPartTiles;
+        off0 = blockIdx.x;  // k_prepare's table has one entry per pass
         off_stride = n_tiles;
     }
     const uint32_t count = min((uint32_t)kPartRecs, bound - base);

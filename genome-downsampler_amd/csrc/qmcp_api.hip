@@ -355,7 +355,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
-        TRY(ensure(c, c->hist2, (size_t)256 * qmcp::part_tile_pitch(n) * sizeof(uint32_t)));
+        TRY(ensure(c, c->hist2, (size_t)256 * qmcp::part_pass_pitch(n) * sizeof(uint32_t)));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
@@ -425,7 +425,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
         {
             KernelSpan sp(c, "scan_radix_hist(3 kernels)");
-            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::part_tile_pitch(n),
+            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::part_pass_pitch(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
         if (!two_level) {

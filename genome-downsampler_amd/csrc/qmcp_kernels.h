@@ -37,9 +37,10 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
 // windows to look for cuts in (0: not worth it); launch_sweep_segments fills `seg_words`
 // (sweep_segment_words() uint32) and returns the stretch table the sweep launchers take as `seg`
 // together with n_seg_max = n_contigs + n_windows workgroups (null: one workgroup per contig).
-// row pitch, in tiles, of the range partition's [digit][tile] table (k_prepare writes it, one plain
-// scan over 256 * pitch entries turns it into offsets, the partition reads it)
-uint32_t part_tile_pitch(uint32_t n);
+// row pitch, in partition passes (pairs of 4096-read tiles), of the range partition's [digit][pass]
+// table (k_prepare writes it, one plain scan over 256 * pitch entries turns it into offsets, the
+// partition reads it)
+uint32_t part_pass_pitch(uint32_t n);
 uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs);
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows);
 // eoff: prefix counts of read ends for mixed spans (coverage = starts - ends); null for one span ell
