@@ -111,7 +111,10 @@ int qmcp_hip_kernel_times(qmcp_hip_ctx* ctx, char* buf, size_t cap);
 /* Replaces QuasiMcpCpuMaxFlowSolver::solve / QuasiMcpCudaMaxFlowSolver::solve
  * (libs/qmcp-solver/src/quasi_mcp_cpu_max_flow_solver.cpp:11-28,
  *  libs/qmcp-solver/src/quasi_mcp_cuda_max_flow_solver.cu:319-435) for host-resident reads.
- * keep_mask_out has ceil(n_reads / 64) words and is fully overwritten.  stats may be NULL. */
+ * keep_mask_out has ceil(n_reads / 64) words and is fully overwritten.  stats may be NULL.
+ * Limits (QMCP_ERANGE beyond them): 2^30 reads and 2^31 - 2 bases per call; reads of one length per
+ * call take the block sweep (any length up to 512 bases, longer ones and any mix of lengths the event
+ * sweeps, reads up to 2^24 - 1 bases); 2^28 reads per contig on the block sweep. */
 int qmcp_hip_solve_host(qmcp_hip_ctx* ctx,
                         const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
                         const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
