@@ -1,0 +1,428 @@
+// sweep_uniform_events.inc.hip -- part of qmcp_kernels.hip (one translation unit; included inside namespace qmcp).
+// ------------------------------------------------------------------ uniform sweep, event-driven form
+// The same selection as k_sweep_uniform* (the canonical greedy of oracle/qmcp_oracle.c, which stands
+// in for SimpleMaxFlow::Solve at quasi_mcp_cpu_max_flow_solver.cpp:19-20), stated on the KEPT counts
+// instead of the dropped ones.  With S(p) = reads kept among those starting at p, need(p) =
+// min(cov(p), M) and all spans equal to ell, the greedy's demand at position p is
+//     delta(p) = need(p) - need(p-1) + S(p - ell)          (>= 0; the reads kept at p - ell expire at p)
+// served from bucket p first and, when c(p) < delta(p), pushed back to p-1, p-2, ...: with
+//     ov(p) = max(0, delta(p) + ov(p+1) - c(p))             (what position p hands on to p-1)
+// the kept counts are S(p) = delta(p) + ov(p+1) - ov(p).  Over one block of ell positions the
+// pushed-back amounts are a suffix Lindley recursion: a prefix sum T of t = delta - c and a suffix
+// maximum of T give every ov at once; what leaves the block's first position goes into the block
+// before it (top-down through its free room), whose kept counts feed delta of this block again --
+// repeated until nothing more is handed back (rarely once; exhaustively checked against the oracle
+// on random instances before this kernel was written).
+//
+// Why this form: where coverage stays above M (need(p) == need(p-1) == M, "deep"), delta of a block is
+// just S of the block before it, and the block changes nothing -- S(p) = S(p - ell) for all its
+// positions -- unless some c(p) < S(p - ell).  On deep data that is rare (cfg4: 8.5 % of the blocks,
+// nearly all of them early in a contig), so the chain wave only has to TEST a block:
+//   k_sweep_pack    (whole chip) packs every block's counts into one word per lane, E saturating
+//                   fields of 30/E bits + a flag bit for blocks that need the general step (not deep,
+//                   first or cut by the contig's end), four blocks per lane as one 16-byte piece;
+//   k_sweep_uniform_ev  (one wave per contig or stretch) streams the pieces into an LDS ring by LDS-DMA,
+//                   48 KiB ahead of itself, and tests four blocks with one 16-byte LDS read and
+//                   a field-wise borrow check against the packed profile; only a failing block runs
+//                   the two wave scans above.  It writes S only for the blocks that changed, and for
+//                   every block the index of the last changed block at or before it;
+//   k_sweep_expand  (whole chip) writes selend[p] = boff[p] + S(p) for every position from those.
+// Exact for any input (shallow data merely flags every block); the host picks it for deep calls
+// whose M fits the fields (3 M + 1 <= field maximum: then no kept count, demand or pushed-back amount
+// can reach a saturated field's value, and a saturated count behaves like the true one).
+
+template <int E> struct EvPack {
+    static constexpr uint32_t kW = 30 / E;                  // field width
+    static constexpr uint32_t kSat = (1u << kW) - 1u;       // field maximum: "at least this many"
+    // borrow INTO these bits = borrow out of a field
+    static constexpr uint32_t kBorrow = E == 1 ? 0x40000000u : E == 2 ? 0x40008000u : E == 3 ? 0x40100400u : 0x10204080u;
+};
+static constexpr uint32_t kEvSpecial = 0x80000000u;
+static constexpr uint32_t kEvSlots = 64;    // LDS ring: 64 pieces of 1 KiB
+static constexpr uint32_t kEvDepth = 48;    // pieces in flight ahead of the chain (s_waitcnt vmcnt(48))
+static constexpr int32_t kEvNeg = -(1 << 30);
+
+// A stretch's place in the per-piece / per-block side arrays: pieces hold four blocks, a stretch of
+// Lrun positions has at most Lrun / (4 ell) + 1 of them, so base / (4 ell) + index never overlaps.
+struct EvGeom { uint32_t base, Lrun, L, n_blocks, piece_base; };
+__device__ __forceinline__ uint32_t ev_piece_base(uint32_t base, uint32_t idx, uint32_t ell) { return base / (4u * ell) + idx; }
+__device__ __forceinline__ bool ev_geom(const uint64_t* __restrict__ contig_pos_off, const uint32_t* __restrict__ seg,
+                                        uint32_t idx, uint32_t ell, EvGeom& g) {
+    SweepSeg sg;
+    const bool ok = sweep_segment(contig_pos_off, seg, idx, sg);
+    g.base = sg.base; g.Lrun = ok ? sg.Lrun : 0u; g.L = ok ? sg.L : 0u;
+    g.n_blocks = (g.Lrun + ell - 1) / ell;
+    g.piece_base = ev_piece_base(g.base, idx, ell);
+    return ok;
+}
+// the stretch that owns global piece w (false: none)
+__device__ __forceinline__ bool ev_find(const uint64_t* __restrict__ contig_pos_off, const uint32_t* __restrict__ seg,
+                                        uint32_t n_wg, uint32_t ell, uint32_t w, EvGeom& g, uint32_t& idx) {
+    const uint32_t count = seg ? min(seg[0], n_wg) : n_wg;
+    if (count == 0) return false;
+    auto pb = [&](uint32_t s) {
+        const uint32_t b = seg ? seg[1 + 3 * s] : (uint32_t)contig_pos_off[s];
+        return ev_piece_base(b, s, ell);
+    };
+    uint32_t lo = 0, hi = count;
+    if (pb(0) > w) return false;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pb(mid) <= w) lo = mid; else hi = mid;
+    }
+    idx = lo;
+    if (!ev_geom(contig_pos_off, seg, lo, ell, g)) return false;
+    return w - g.piece_base < (g.n_blocks + 3) / 4;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__ boff,
+                                                    const uint64_t* __restrict__ contig_pos_off, uint32_t n_wg,
+                                                    uint32_t ell, uint32_t M, uint32_t ltot,
+                                                    const uint32_t* __restrict__ seg, uint32_t n_pieces_max,
+                                                    uint32_t* __restrict__ pk) {
+    using P = EvPack<E>;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_pieces_max) return;
+    EvGeom g;
+    uint32_t idx;
+    if (!ev_find(contig_pos_off, seg, n_wg, ell, w, g, idx)) return;
+    const uint32_t q = w - g.piece_base;
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t k = 4 * q + j;
+        const uint32_t p0 = g.base + k * ell + lane * E;   // global position of the lane's first slot
+        uint32_t X[E + 1], Pv[E + 1];
+#pragma unroll
+        for (int r = 0; r <= E; ++r) {
+            const uint32_t p = p0 + r;
+            X[r] = boff[min(p, ltot)];
+            Pv[r] = boff[p >= ell ? min(p - ell, ltot) : 0u];
+        }
+        uint32_t word = 0;
+        bool deep = true;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t i = lane * E + r;
+            const bool valid = i < ell && k * ell + i < g.L;
+            const uint32_t c = valid ? X[r + 1] - X[r] : 0u;
+            word |= min(c, P::kSat) << (r * P::kW);
+            // need(p) == need(p - 1) == M
+            if (i < ell) deep = deep && (X[r + 1] - Pv[r + 1] >= M) && (X[r] - Pv[r] >= M);
+        }
+        const bool inside = (uint64_t)(k + 1) * ell <= g.L;
+        const bool plain = k != 0 && k < g.n_blocks && inside && __all(deep);
+        out[j] = plain ? word : (word | kEvSpecial);
+    }
+    uint4 v;
+    v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+    reinterpret_cast<uint4*>(pk)[(size_t)w * 64 + lane] = v;
+}
+
+// LDS-DMA of one 1-KiB piece (16 bytes per lane) to the wave-uniform LDS byte address lds_dst
+__device__ __forceinline__ void ev_glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ int32_t ev_incl_suffix_max(int32_t v, uint32_t lane) {
+#define QMCP_EV_DPP(x, ctrl) __builtin_amdgcn_update_dpp((int)kEvNeg, (int)(x), (ctrl), 0xF, 0xF, false)
+    v = max(v, QMCP_EV_DPP(v, 0x101));
+    v = max(v, QMCP_EV_DPP(v, 0x102));
+    v = max(v, QMCP_EV_DPP(v, 0x104));
+    v = max(v, QMCP_EV_DPP(v, 0x108));
+#undef QMCP_EV_DPP
+    const int32_t r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32);
+    const int32_t r3 = __builtin_amdgcn_readlane(v, 48);
+    const uint32_t row = lane >> 4;
+    v = max(max(v, row < 1 ? r1 : kEvNeg), max(row < 2 ? r2 : kEvNeg, row < 3 ? r3 : kEvNeg));
+    return v;
+}
+
+// One block in the general (kept-count) form: demand d[] against counts c[]; returns what is handed
+// back past the block's first position and leaves the kept counts in S[].
+template <int E>
+__device__ __forceinline__ uint32_t ev_block_step(const int32_t (&d)[E], const uint32_t (&c)[E], uint32_t lane,
+                                                  uint32_t (&S)[E]) {
+    int32_t T[E], Ml[E];
+    int32_t ls = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) { ls += d[r] - (int32_t)c[r]; T[r] = ls; }
+    const int32_t incl = (int32_t)wave_incl_scan_add((uint32_t)ls);
+    const int32_t before = __builtin_amdgcn_update_dpp(0, incl, 0x138, 0xF, 0xF, false);  // lane 0: 0
+#pragma unroll
+    for (int r = 0; r < E; ++r) T[r] += before;
+    int32_t mx = kEvNeg;
+#pragma unroll
+    for (int r = E - 1; r >= 0; --r) { mx = max(mx, T[r]); Ml[r] = mx; }
+    const int32_t suf = ev_incl_suffix_max(mx, lane);
+    const int32_t after = __builtin_amdgcn_update_dpp((int)kEvNeg, suf, 0x130, 0xF, 0xF, false);  // lane 63: none
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int32_t mx_here = max(Ml[r], after);
+        const int32_t mx_next = r + 1 < E ? max(Ml[r + 1 < E ? r + 1 : r], after) : after;
+        const int32_t t_prev = r > 0 ? T[r > 0 ? r - 1 : 0] : before;
+        const int32_t ov = max(0, mx_here - t_prev);
+        const int32_t ovn = max(0, mx_next - T[r]);
+        S[r] = (uint32_t)(d[r] + ovn - ov);
+    }
+    const int32_t top = __builtin_amdgcn_readlane(max(Ml[0], after), 0);
+    return (uint32_t)max(0, top);
+}
+
+template <int E>
+__global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restrict__ boff,
+                                                         const uint64_t* __restrict__ contig_pos_off,
+                                                         uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
+                                                         const uint32_t* __restrict__ pk,
+                                                         uint32_t* __restrict__ sev,      // ltot + 8: S of changed blocks
+                                                         uint32_t* __restrict__ lastns,   // per block: last changed block <= it
+                                                         uint32_t* __restrict__ iter_stats,
+                                                         const uint32_t* __restrict__ seg) {
+    using P = EvPack<E>;
+    extern __shared__ uint4 s_evring[];
+    const uint32_t lane = threadIdx.x;
+    EvGeom gm;
+    if (!ev_geom(contig_pos_off, seg, blockIdx.x, ell, gm)) return;
+    const uint32_t base = gm.base, L = gm.L, Lrun = gm.Lrun, n_blocks = gm.n_blocks;
+    const uint32_t n_pieces = (n_blocks + 3) / 4;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pk) + (size_t)gm.piece_base * 64 + lane;
+    uint32_t* __restrict__ my_last = lastns + (size_t)gm.piece_base * 4;
+    const uint32_t ring0 = (uint32_t)(uintptr_t)s_evring;
+    __builtin_amdgcn_s_setprio(3);
+
+    // is the stretch's first position a contig's first position?  (a stretch that starts behind a
+    // cut point inherits the reads kept across the cut)
+    bool contig_start = seg == nullptr;
+    if (seg != nullptr) {
+        bool hit = false;
+        for (uint32_t cc = lane; cc < n_contigs; cc += 64) hit |= (uint32_t)contig_pos_off[cc] == base;
+        contig_start = __any(hit);
+    }
+
+    uint32_t g[E];       // S of the block before the current one: this block's expiries
+    uint32_t gp = 0;     // the same, packed like a piece word
+    uint32_t cprevw = 0; // the previous block's packed counts (room for what is handed back)
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        g[r] = 0;
+        if (!contig_start) {
+            // behind a cut point every read covering it is kept: S(p) = c(p) on the ell positions before
+            const uint32_t i = lane * E + r;
+            const uint32_t qpos = base + i;  // position base - ell + i, shifted by ell
+            if (i < ell && qpos >= ell) g[r] = boff[qpos - ell + 1] - boff[qpos - ell];
+        }
+    }
+    uint32_t last_ns = 0, n_changed = 0;
+    uint32_t lastv = 0;  // lane j: last changed block at or before block (current group of 64) + j
+
+#ifdef QMCP_EV_STAMP
+    unsigned long long st_gen = 0, st_wait = 0, st_slow = 0;
+    uint32_t st_slow_pieces = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t issued = 0;
+    auto issue = [&]() {
+        ev_glds16(src + (size_t)issued * 64, ring0 + (issued % kEvSlots) * 1024u);
+        ++issued;
+    };
+    for (uint32_t i = 0; i < kEvDepth && issued < n_pieces; ++i) issue();
+    bool drained = false;
+
+    // one block that is not known to be unchanged
+    auto general_block = [&](uint32_t k, uint32_t word) {
+        uint32_t c[E];
+        int32_t dn[E];
+        bool kill[E];
+        if (word & kEvSpecial) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t i = lane * E + r;
+                const uint32_t pos = k * ell + i;
+                const bool valid = i < ell && pos < L;
+                const uint32_t p = base + min(pos, L);
+                const uint32_t a1 = boff[min(p + 1, ltot)], a0 = boff[p];
+                const uint32_t b1 = boff[p + 1 >= ell ? min(p + 1 - ell, ltot) : 0u];
+                const uint32_t b0 = boff[p >= ell ? p - ell : 0u];
+                const uint32_t need_p = min(a1 - b1, M);
+                uint32_t need_m = min(a0 - b0, M);
+                if (pos == 0 && contig_start) need_m = 0;
+                c[r] = valid ? a1 - a0 : 0u;
+                dn[r] = valid ? (int32_t)need_p - (int32_t)need_m : 0;
+                kill[r] = !valid;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                c[r] = (word >> (r * P::kW)) & P::kSat;
+                dn[r] = 0;
+                kill[r] = false;
+            }
+        }
+        uint32_t S[E];
+        uint32_t pushed = 0;
+        for (uint32_t round = 0; round < 4096; ++round) {  // (bounded: every round hands back at least one more read)
+            int32_t d[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) d[r] = kill[r] ? 0 : (int32_t)g[r] + dn[r];
+            const uint32_t e = ev_block_step<E>(d, c, lane, S);
+            if (e == pushed) break;
+            // hand e - pushed more back into the block before: top-down through its free room
+            const uint32_t rem = e - pushed;
+            pushed = e;
+            uint32_t room[E], pre[E];
+            uint32_t ls = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t cp = (cprevw >> (r * P::kW)) & P::kSat;
+                room[r] = cp > g[r] ? cp - g[r] : 0u;
+                ls += room[r];
+                pre[r] = ls;
+            }
+            const uint32_t incl = wave_incl_scan_add(ls);
+            const uint32_t before = QMCP_DPP(0u, incl, 0x138, 0xF);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t above = total - (before + pre[r]);  // free room in the slots above this one
+                const uint32_t left = rem > above ? rem - above : 0u;
+                g[r] += min(room[r], left);
+            }
+            if (k > 0) {
+                // the block before changed after all: record it
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const uint32_t i = lane * E + r;
+                    const uint32_t pos = (k - 1) * ell + i;
+                    if (i < ell && pos < Lrun) sev[base + pos] = g[r];
+                }
+                if (((k - 1) >> 6) == (k >> 6)) {
+                    lastv = lane >= ((k - 1) & 63) ? k - 1 : lastv;
+                } else if (lane == 0) {
+                    my_last[k - 1] = k - 1;
+                }
+            }
+            if (total < rem) break;  // cannot happen for a feasible demand; do not spin
+        }
+        gp = 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            g[r] = S[r];
+            gp |= min(S[r], P::kSat) << (r * P::kW);
+            const uint32_t i = lane * E + r;
+            const uint32_t pos = k * ell + i;
+            if (i < ell && pos < Lrun) sev[base + pos] = S[r];
+        }
+        if (word & kEvSpecial) {
+            cprevw = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) cprevw |= min(c[r], P::kSat) << (r * P::kW);
+        } else {
+            cprevw = word;
+        }
+        last_ns = k;
+        lastv = lane >= (k & 63) ? k : lastv;
+        ++n_changed;
+    };
+
+    for (uint32_t q = 0; q < n_pieces; ++q) {
+        if (issued < n_pieces) {
+            issue();
+#ifdef QMCP_EV_STAMP
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+#ifdef QMCP_EV_STAMP
+            st_wait += __builtin_amdgcn_s_memtime() - w0;
+#endif
+        } else if (!drained) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drained = true;
+        }
+        const uint4 w = s_evring[(q % kEvSlots) * 64 + lane];
+        const uint32_t x0 = w.x - gp, x1 = w.y - gp, x2 = w.z - gp, x3 = w.w - gp;
+        const uint32_t bad = (((w.x ^ gp ^ x0) | (w.y ^ gp ^ x1) | (w.z ^ gp ^ x2) | (w.w ^ gp ^ x3)) & P::kBorrow) |
+                             ((w.x | w.y | w.z | w.w) & kEvSpecial);
+        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+#ifdef QMCP_EV_STAMP
+            const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+            ++st_slow_pieces;
+#endif
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = 4 * q + j;
+                if (k < n_blocks) {
+                    const uint32_t xj = ws[j] - gp;
+                    const uint32_t bj = ((ws[j] ^ gp ^ xj) & P::kBorrow) | (ws[j] & kEvSpecial);
+                    if (__builtin_amdgcn_ballot_w64(bj != 0) != 0) {
+#ifdef QMCP_EV_STAMP
+                        const unsigned long long g0 = __builtin_amdgcn_s_memtime();
+#endif
+                        general_block(k, ws[j]);
+#ifdef QMCP_EV_STAMP
+                        st_gen += __builtin_amdgcn_s_memtime() - g0;
+#endif
+                    } else cprevw = ws[j];
+                }
+            }
+#ifdef QMCP_EV_STAMP
+            st_slow += __builtin_amdgcn_s_memtime() - s0;
+#endif
+        } else {
+            cprevw = w.w;
+        }
+        if ((q & 15) == 15 || q + 1 == n_pieces) {
+            // 64 blocks done: for each of them the last changed block at or before it
+            const uint32_t kb = (q >> 4) * 64 + lane;
+            if (kb < n_blocks) my_last[kb] = lastv;
+            lastv = last_ns;
+        }
+    }
+    if (iter_stats && lane == 0) {
+        atomicAdd(&iter_stats[0], n_changed);
+        atomicAdd(&iter_stats[1], n_blocks);
+        atomicAdd(&iter_stats[2], 1u);  // stretches swept
+#ifdef QMCP_EV_STAMP
+        atomicAdd(&iter_stats[4], (uint32_t)((__builtin_amdgcn_s_memtime() - st_begin) >> 4));
+        atomicAdd(&iter_stats[5], (uint32_t)(st_gen >> 4));
+        atomicAdd(&iter_stats[6], (uint32_t)(st_wait >> 4));
+        atomicAdd(&iter_stats[7], (uint32_t)(st_slow >> 4));
+        atomicAdd(&iter_stats[8], st_slow_pieces);
+#endif
+    }
+}
+
+// selend[p] = boff[p] + S(p) for every position: S of the last changed block at or before p's block
+template <int E>
+__global__ __launch_bounds__(256) void k_sweep_expand(const uint32_t* __restrict__ boff,
+                                                      const uint64_t* __restrict__ contig_pos_off, uint32_t n_wg,
+                                                      uint32_t ell, uint32_t ltot, const uint32_t* __restrict__ seg,
+                                                      uint32_t n_pieces_max, const uint32_t* __restrict__ sev,
+                                                      const uint32_t* __restrict__ lastns,
+                                                      uint32_t* __restrict__ selend) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t gb = blockIdx.x * 4 + (threadIdx.x >> 6);  // global block slot
+    const uint32_t w = gb >> 2;
+    if (w >= n_pieces_max) return;
+    EvGeom g;
+    uint32_t idx;
+    if (!ev_find(contig_pos_off, seg, n_wg, ell, w, g, idx)) return;
+    const uint32_t k = gb - 4 * g.piece_base;
+    if (k >= g.n_blocks) return;
+    const uint32_t kk = lastns[gb];
+    const uint32_t back = (k - kk) * ell;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t pos = k * ell + i;
+        if (i < ell && pos < g.Lrun) {
+            const uint32_t p = g.base + pos;
+            selend[p] = boff[p] + sev[p - back];
+        }
+    }
+}

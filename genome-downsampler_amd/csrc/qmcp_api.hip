@@ -74,6 +74,7 @@ struct qmcp_hip_ctx {
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
     DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
+    DevBuf evpk, evlast;  // event-driven uniform sweep: packed block words, last-changed-block index per block
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
     int profiling = 0;  // 0 off, 1 every kernel, 2 the selection sweep only
@@ -271,6 +272,10 @@ static uint32_t rank_min_reads() {
     return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 17);
 }
 
+// shortest span the event-driven sweep is used for: its scratch is 256 bytes per block, i.e. grows as
+// the span shrinks; at 32 positions it is 8 bytes per position, what the bucket offsets themselves take
+static uint32_t ev_min_span() { return 32u; }
+
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
@@ -309,6 +314,19 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         KernelSpan sp(c, "k_find_cuts", st);
         seg = qmcp::launch_sweep_segments(st, boff, nullptr, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
         n_seg_max = n_contigs + windows;
+    }
+    // deep data: the event-driven form (a block is only TESTED unless its counts fall below the kept
+    // profile); spans below ev_min_span() would need more scratch than the arena holds for it
+    bool ev = !gen && span >= ev_min_span();
+    if (const char* e = std::getenv("QMCP_HIP_SWEEP")) {
+        if (std::strcmp(e, "ev") == 0) ev = span >= ev_min_span();
+        if (std::strcmp(e, "fast") == 0 || std::strcmp(e, "gen") == 0) ev = false;
+    }
+    if (ev && qmcp::sweep_uniform_ev_supported(span, M)) {
+        KernelSpan sp(c, "k_sweep_uniform_ev(pack, chain, expand)", st);
+        if (qmcp::launch_sweep_uniform_ev(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max,
+                                          (uint32_t*)c->evpk.p, (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p))
+            return QMCP_OK;
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
@@ -356,7 +374,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist2, (size_t)256 * qmcp::part_pass_pitch(n) * sizeof(uint32_t)));
-        TRY(ensure(c, c->cstart, ((size_t)ltot + 1) * sizeof(uint32_t)));
+        TRY(ensure(c, c->cstart, ((size_t)ltot + 8) * sizeof(uint32_t)));  // also the event sweep's changed-block S
+        {
+            // event-driven sweep scratch, sized for the shortest span it can meet (pieces shrink with the span)
+            const uint32_t wg_max = n_contigs + 768;
+            TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ev_min_span(), wg_max)));
+            TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ev_min_span(), wg_max)));
+        }
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
@@ -735,6 +759,15 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
             return solve_on_device(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask, st);
         }
     }
+#ifdef QMCP_EV_STAMP
+    {
+        uint32_t raw[16];
+        HIP_TRY(hipMemcpy(raw, c->scalars.p, sizeof(raw), hipMemcpyDeviceToHost));
+        const uint32_t* it = raw + 4;
+        fprintf(stderr, "[ev stamp] changed %u of %u blocks, stretches %u | x16 cycles: total %u general %u dma-wait %u slow-pieces %u (%u pieces)\n",
+                it[0], it[1], it[2], it[4], it[5], it[6], it[7], it[8]);
+    }
+#endif
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
@@ -865,7 +898,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -19,6 +19,8 @@
 //   sweep_uniform            block forms of the uniform-span sweep, single-wave kernel
 //   sweep_segments           cut points (coverage <= M): contigs split into independently swept stretches
 //   sweep_uniform_pipelines  seven-wave pipelines: fast form with checked fallback, all-general form
+//   sweep_uniform_events     event-driven form for deep data: pack (whole chip), chain (one wave per contig,
+//                            LDS-DMA ring), expand (whole chip)
 //   sweep_mixed              mixed-span event sweeps (register-resident, LDS-cached, plain)
 //   mark_and_next_rows       keep-mask emission for the sort-based routes, coverage probes, FILTER,
 //                            pair compaction / completion
@@ -46,6 +48,7 @@ static constexpr uint32_t kInf = 0x40000000u;
 #include "kernels/sweep_uniform.inc.hip"
 #include "kernels/sweep_segments.inc.hip"
 #include "kernels/sweep_uniform_pipelines.inc.hip"
+#include "kernels/sweep_uniform_events.inc.hip"
 #include "kernels/sweep_mixed.inc.hip"
 #include "kernels/mark_and_next_rows.inc.hip"
 #include "kernels/launchers.inc.hip"
