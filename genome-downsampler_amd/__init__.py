@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     "qmcp_hip_destroy", "qmcp_hip_solve_host", "qmcp_hip_solve_device", "qmcp_hip_coverage_host",
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
-    "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host",
+    "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
+    "qmcp_hip_solve_end",
 )
 
 QMCP_OK = 0
@@ -70,6 +71,9 @@ _hip.qmcp_hip_solve_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p
 _hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.POINTER(Stats)]
+_hip.qmcp_hip_solve_device_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
+                                             C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+_hip.qmcp_hip_solve_end.argtypes = [C.c_void_p, C.POINTER(Stats)]
 _hip.qmcp_hip_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
                                         C.c_uint32, _u32p]
 _hip.qmcp_hip_filtered_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
@@ -219,6 +223,21 @@ class Solver:
                                           int(n_reads), _p64(offs), _p32(lengths), lengths.size,
                                           int(max_coverage), C.c_void_p(d_mask),
                                           C.c_void_p(stream), C.byref(st)))
+        self.last_stats = st
+        return st
+
+    def solve_device_begin(self, d_starts, d_ends, n_reads, contig_lengths, max_coverage, d_mask,
+                           contig_read_offsets=None, stream=0):
+        """enqueue a device-resident solve and return without waiting for it (one pending solve per
+        Solver; pipeline with a second Solver on the same device); solve_end() collects it"""
+        offs, lengths = _contig_tables(n_reads, contig_read_offsets, contig_lengths)
+        _check(_hip.qmcp_hip_solve_device_begin(self._ctx, C.c_void_p(d_starts), C.c_void_p(d_ends),
+                                                int(n_reads), _p64(offs), _p32(lengths), lengths.size,
+                                                int(max_coverage), C.c_void_p(d_mask), C.c_void_p(stream)))
+
+    def solve_end(self):
+        st = Stats()
+        _check(_hip.qmcp_hip_solve_end(self._ctx, C.byref(st)))
         self.last_stats = st
         return st
 

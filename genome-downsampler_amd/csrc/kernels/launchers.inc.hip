@@ -159,8 +159,8 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
 bool sweep_uniform_ev_supported(uint32_t ell, uint32_t M) {
     if (!sweep_uniform_mw_supported(ell)) return false;
     const uint32_t e = (ell + 63) / 64;
-    const uint64_t sat = (1ull << (30 / e)) - 1;
-    return 3ull * M + 1 <= sat;
+    const uint64_t sat = (1ull << (30 / e - 1)) - 1;  // EvPack<E>::kSat
+    return (uint64_t)M + 1 <= sat;  // no kept count can reach a saturated field's value
 }
 uint32_t sweep_ev_pieces(uint32_t ltot, uint32_t ell, uint32_t n_wg) { return ltot / (4u * ell) + n_wg + 1; }
 size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) { return (size_t)sweep_ev_pieces(ltot, ell, n_wg) * 1024; }
@@ -182,7 +182,7 @@ bool launch_sweep_uniform_ev(hipStream_t st, const uint32_t* boff, const uint64_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
         hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, \
                            ell, M, ltot, seg, pieces, pk);                                                \
-        hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(64), lds, st, boff, d_poff, n_contigs, \
+        hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(128), lds, st, boff, d_poff, n_contigs, \
                            ell, M, ltot, pk, sev, lastns, iter_stats, seg);                               \
         hipLaunchKernelGGL(k_sweep_expand<EE>, dim3(pieces), dim3(256), 0, st, boff, d_poff, n_wg, ell,   \
                            ltot, seg, pieces, sev, lastns, selend);                                       \
@@ -374,25 +374,6 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
                            keys, (const Rec*)recs_in, n, shift, n_tiles, g, offs, recs_out);
 }
 
-void launch_digit_bases(hipStream_t st, const uint32_t* hist4, uint32_t* base4) {
-    hipLaunchKernelGGL(k_digit_bases, dim3(1), dim3(256), 0, st, hist4, base4);
-}
-
-void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
-                           uint32_t n, uint32_t shift, const uint32_t* digit_base,
-                           unsigned long long* status, uint32_t epoch, uint32_t* ticket,
-                           uint32_t* timeout_flag, void* recs_out) {
-    const uint32_t n_tiles = sort_tiles(n);
-    if (n_tiles == 0) return;
-    if (first)
-        hipLaunchKernelGGL(k_radix_onesweep<true>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs_in, n, shift, n_tiles, digit_base, status, epoch, ticket,
-                           timeout_flag, (Rec*)recs_out);
-    else
-        hipLaunchKernelGGL(k_radix_onesweep<false>, dim3(n_tiles), dim3(kSortThreads), 0, st, keys,
-                           (const Rec*)recs_in, n, shift, n_tiles, digit_base, status, epoch, ticket,
-                           timeout_flag, (Rec*)recs_out);
-}
 
 // range-ranked uniform path: geometry, partition table, counts, rank + mark
 uint32_t range_shift_for(uint32_t ltot) {

@@ -18,28 +18,37 @@
 // just S of the block before it, and the block changes nothing -- S(p) = S(p - ell) for all its
 // positions -- unless some c(p) < S(p - ell).  On deep data that is rare (cfg4: 8.5 % of the blocks,
 // nearly all of them early in a contig), so the chain wave only has to TEST a block:
-//   k_sweep_pack    (whole chip) packs every block's counts into one word per lane, E saturating
-//                   fields of 30/E bits + a flag bit for blocks that need the general step (not deep,
-//                   first or cut by the contig's end), four blocks per lane as one 16-byte piece;
+//   k_sweep_pack    (whole chip) packs every block's counts into one word per lane -- E saturating
+//                   fields of 30/E bits, the top bit of each a guard, + a flag for blocks the shortcut
+//                   applies to (deep, inside the contig, not the first) -- four blocks per lane as
+//                   one 16-byte piece;
 //   k_sweep_uniform_ev  (one wave per contig or stretch) streams the pieces into an LDS ring by LDS-DMA,
-//                   48 KiB ahead of itself, and tests four blocks with one 16-byte LDS read and
-//                   a field-wise borrow check against the packed profile; only a failing block runs
-//                   the two wave scans above.  It writes S only for the blocks that changed, and for
-//                   every block the index of the last changed block at or before it;
+//                   48 KiB ahead of itself, and tests eight blocks at a time: word - packed profile
+//                   keeps a guard bit exactly where the count is not below the profile's, so the AND
+//                   of eight differences says "nothing changes" in 17 vector instructions.  A block
+//                   that fails takes the one-step form (whatever a position cannot serve is taken by
+//                   the position before it: one shifted read) or, if that does not settle it, the two
+//                   wave scans above.  It writes S only for the blocks that changed, and for every
+//                   block the index of the last changed block at or before it;
 //   k_sweep_expand  (whole chip) writes selend[p] = boff[p] + S(p) for every position from those.
 // Exact for any input (shallow data merely flags every block); the host picks it for deep calls
-// whose M fits the fields (3 M + 1 <= field maximum: then no kept count, demand or pushed-back amount
-// can reach a saturated field's value, and a saturated count behaves like the true one).
+// whose M is below the field maximum: no kept count reaches a saturated field's value then (at most
+// M reads are ever kept from one start position), so a saturated count behaves like the true one.
 
 template <int E> struct EvPack {
-    static constexpr uint32_t kW = 30 / E;                  // field width
-    static constexpr uint32_t kSat = (1u << kW) - 1u;       // field maximum: "at least this many"
-    // borrow INTO these bits = borrow out of a field
-    static constexpr uint32_t kBorrow = E == 1 ? 0x40000000u : E == 2 ? 0x40008000u : E == 3 ? 0x40100400u : 0x10204080u;
+    static constexpr uint32_t kW = 30 / E;                  // field pitch: a count and, above it, a guard bit
+    static constexpr uint32_t kSat = (1u << (kW - 1)) - 1u; // field maximum: "at least this many"
+    // guard bits: set in every block word, clear in the packed profile; word - profile clears a guard
+    // exactly where a count is below the profile's (the borrow stops there), so "all guards still set"
+    // over any number of AND-ed differences says that none of those blocks changes anything
+    static constexpr uint32_t kGuard = E == 1 ? (1u << 29)
+                                     : E == 2 ? ((1u << 14) | (1u << 29))
+                                     : E == 3 ? ((1u << 9) | (1u << 19) | (1u << 29))
+                                              : ((1u << 6) | (1u << 13) | (1u << 20) | (1u << 27));
+    static constexpr uint32_t kPlain = 0x80000000u;         // deep block inside the contig (not the first)
+    static constexpr uint32_t kAll = kGuard | kPlain;
 };
-static constexpr uint32_t kEvSpecial = 0x80000000u;
 static constexpr uint32_t kEvSlots = 64;    // LDS ring: 64 pieces of 1 KiB
-static constexpr uint32_t kEvDepth = 48;    // pieces in flight ahead of the chain (s_waitcnt vmcnt(48))
 static constexpr int32_t kEvNeg = -(1 << 30);
 
 // A stretch's place in the per-piece / per-block side arrays: pieces hold four blocks, a stretch of
@@ -99,7 +108,10 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
         for (int r = 0; r <= E; ++r) {
             const uint32_t p = p0 + r;
             X[r] = boff[min(p, ltot)];
-            Pv[r] = boff[p >= ell ? min(p - ell, ltot) : 0u];
+            // (not `p >= ell ? min(p - ell, ltot) : 0`: hipcc 7.2 folds that select away and reads
+            // boff[min(p - ell wrapped, ltot)] = boff[ltot] for p < ell -- clamp first, subtract after)
+            const uint32_t pm = min(p, ltot + ell);
+            Pv[r] = boff[pm >= ell ? pm - ell : 0u];
         }
         uint32_t word = 0;
         bool deep = true;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
         }
         const bool inside = (uint64_t)(k + 1) * ell <= g.L;
         const bool plain = k != 0 && k < g.n_blocks && inside && __all(deep);
-        out[j] = plain ? word : (word | kEvSpecial);
+        out[j] = word | P::kGuard | (plain ? P::kPlain : 0u);
     }
     uint4 v;
     v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
@@ -175,7 +187,7 @@ __device__ __forceinline__ uint32_t ev_block_step(const int32_t (&d)[E], const u
 }
 
 template <int E>
-__global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restrict__ boff,
+__global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __restrict__ boff,
                                                          const uint64_t* __restrict__ contig_pos_off,
                                                          uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                                                          const uint32_t* __restrict__ pk,
@@ -185,7 +197,14 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
                                                          const uint32_t* __restrict__ seg) {
     using P = EvPack<E>;
     extern __shared__ uint4 s_evring[];
-    const uint32_t lane = threadIdx.x;
+    // two waves: wave 1 only moves pieces into the LDS ring (an LDS-DMA request costs its issuer ~96
+    // cycles, lab/dma_lab.hip -- more than the chain spends on the four blocks in it), wave 0 is the chain
+    __shared__ uint32_t s_ctl_words[2];  // [0] pieces landed, [1] pieces read
+    // (an LDS-qualified pointer, taken by value below: through a generic one these become flat_ loads)
+    typedef __attribute__((address_space(3))) uint32_t LdsWord;
+    volatile LdsWord* const s_ctl = (volatile LdsWord*)s_ctl_words;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     EvGeom gm;
     if (!ev_geom(contig_pos_off, seg, blockIdx.x, ell, gm)) return;
     const uint32_t base = gm.base, L = gm.L, Lrun = gm.Lrun, n_blocks = gm.n_blocks;
@@ -193,6 +212,28 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pk) + (size_t)gm.piece_base * 64 + lane;
     uint32_t* __restrict__ my_last = lastns + (size_t)gm.piece_base * 4;
     const uint32_t ring0 = (uint32_t)(uintptr_t)s_evring;
+    if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+    __syncthreads();
+    if (wv == 1) {
+        // LOADER: keeps the ring full.  A slot is reused once the chain has said it read the piece in it;
+        // "landed" is published 32 requests behind the issue point (counted wait).
+        __builtin_amdgcn_s_setprio(1);
+        uint32_t read_seen = 0;
+        for (uint32_t idx = 0; idx < n_pieces; ++idx) {
+            while (idx - read_seen >= kEvSlots) {
+                read_seen = s_ctl[1];
+                if (idx - read_seen >= kEvSlots) __builtin_amdgcn_s_sleep(2);
+            }
+            ev_glds16(src + (size_t)idx * 64, ring0 + (idx % kEvSlots) * 1024u);
+            if ((idx & 3) == 3 && idx >= 32) {
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                if (lane == 0) s_ctl[0] = idx + 1 - 32;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no request may outlive the workgroup's LDS
+        if (lane == 0) s_ctl[0] = n_pieces;
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
 
     // is the stretch's first position a contig's first position?  (a stretch that starts behind a
@@ -205,7 +246,7 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
     }
 
     uint32_t g[E];       // S of the block before the current one: this block's expiries
-    uint32_t gp = 0;     // the same, packed like a piece word
+    uint32_t gp = 0;     // the same, packed like a piece word (guards clear)
     uint32_t cprevw = 0; // the previous block's packed counts (room for what is handed back)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -221,24 +262,102 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
     uint32_t lastv = 0;  // lane j: last changed block at or before block (current group of 64) + j
 
 #ifdef QMCP_EV_STAMP
-    unsigned long long st_gen = 0, st_wait = 0, st_slow = 0;
-    uint32_t st_slow_pieces = 0;
+    unsigned long long st_gen = 0, st_slow = 0, st_wait = 0;
+    uint32_t st_slow_pieces = 0, st_full = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t issued = 0;
-    auto issue = [&]() {
-        ev_glds16(src + (size_t)issued * 64, ring0 + (issued % kEvSlots) * 1024u);
-        ++issued;
+    // pieces [0, landed) are in the ring; the chain looks at the ring's progress word only when it has
+    // caught up with what it last saw there
+    uint32_t landed = 0;
+    auto wait_for = [&](uint32_t upto) {  // pieces [0, min(upto, n_pieces)) have landed
+        const uint32_t want = min(upto, n_pieces);
+#ifdef QMCP_EV_STAMP
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+        while (landed < want) {
+            landed = s_ctl[0];
+            if (landed < want) __builtin_amdgcn_s_sleep(1);
+        }
+#ifdef QMCP_EV_STAMP
+        st_wait += __builtin_amdgcn_s_memtime() - w0;
+#endif
     };
-    for (uint32_t i = 0; i < kEvDepth && issued < n_pieces; ++i) issue();
-    bool drained = false;
+    wait_for(4);
+    uint4 cur[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = s_evring[i * 64 + lane];
+
+    // the block's kept counts S[] become the profile; they and the block's index are recorded
+    auto commit = [&](uint32_t k, const uint32_t (&S)[E], uint32_t cword) {
+        gp = 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            g[r] = S[r];
+            gp |= S[r] << (r * P::kW);   // S <= M < the field maximum (the launcher checks M)
+        }
+        {
+            // one contiguous store per lane (its E slots are adjacent positions); lanes without E valid
+            // slots write the spare words behind the table, and their valid slots one by one
+            const uint32_t blk_first = k * ell;
+            const uint32_t p0 = blk_first + lane * E;
+            const bool full = lane * E + E <= ell && p0 + E <= Lrun;
+            if constexpr (E == 1) {
+                sev[full ? base + p0 : ltot] = S[0];
+            } else {
+                typedef typename RowVec<E>::type V;
+                V v;
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = S[r];
+                *reinterpret_cast<V*>(sev + (full ? base + p0 : ltot)) = v;
+                if (ell % E != 0 || blk_first + ell > Lrun) {
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        const uint32_t i = lane * E + r;
+                        if (!full && i < ell && blk_first + i < Lrun) sev[base + blk_first + i] = S[r];
+                    }
+                }
+            }
+        }
+        cprevw = cword;
+        last_ns = k;
+        lastv = lane >= (k & 63) ? k : lastv;
+        ++n_changed;
+    };
 
     // one block that is not known to be unchanged
     auto general_block = [&](uint32_t k, uint32_t word) {
         uint32_t c[E];
+        uint32_t S[E];
+        if (word & P::kPlain) {
+            // Deep block: the demand is the profile itself.  Nearly always whatever a position cannot
+            // serve is taken by the position just before it: one shifted read instead of two scans.
+            int32_t t[E], ex[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                c[r] = (word >> (r * P::kW)) & P::kSat;
+                t[r] = (int32_t)g[r] - (int32_t)c[r];
+                ex[r] = max(t[r], 0);
+            }
+            const int32_t up = __builtin_amdgcn_update_dpp(0, ex[0], 0x130, 0xF, 0xF, false);  // next lane's first slot
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int32_t in = r + 1 < E ? ex[r + 1 < E ? r + 1 : r] : up;
+                ok = ok && (in == 0 || in + t[r] <= 0);
+                S[r] = (uint32_t)((int32_t)g[r] - ex[r] + in);
+            }
+            const bool first_ok = __builtin_amdgcn_readfirstlane(ex[0]) == 0;  // nothing handed back past the block
+            if (first_ok && __builtin_amdgcn_ballot_w64(!ok) == 0) {
+                commit(k, S, word);
+                return;
+            }
+        }
+#ifdef QMCP_EV_STAMP
+        ++st_full;
+#endif
         int32_t dn[E];
         bool kill[E];
-        if (word & kEvSpecial) {
+        if (!(word & P::kPlain)) {
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const uint32_t i = lane * E + r;
@@ -246,7 +365,7 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
                 const bool valid = i < ell && pos < L;
                 const uint32_t p = base + min(pos, L);
                 const uint32_t a1 = boff[min(p + 1, ltot)], a0 = boff[p];
-                const uint32_t b1 = boff[p + 1 >= ell ? min(p + 1 - ell, ltot) : 0u];
+                const uint32_t b1 = boff[p + 1 >= ell ? p + 1 - ell : 0u];  // (<= ltot: p <= ltot, ell >= 1)
                 const uint32_t b0 = boff[p >= ell ? p - ell : 0u];
                 const uint32_t need_p = min(a1 - b1, M);
                 uint32_t need_m = min(a0 - b0, M);
@@ -257,13 +376,8 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < E; ++r) {
-                c[r] = (word >> (r * P::kW)) & P::kSat;
-                dn[r] = 0;
-                kill[r] = false;
-            }
+            for (int r = 0; r < E; ++r) { dn[r] = 0; kill[r] = false; }
         }
-        uint32_t S[E];
         uint32_t pushed = 0;
         for (uint32_t round = 0; round < 4096; ++round) {  // (bounded: every round hands back at least one more read)
             int32_t d[E];
@@ -308,80 +422,72 @@ __global__ __launch_bounds__(64) void k_sweep_uniform_ev(const uint32_t* __restr
             }
             if (total < rem) break;  // cannot happen for a feasible demand; do not spin
         }
-        gp = 0;
+        uint32_t cword = word;
+        if (!(word & P::kPlain)) {
+            cword = P::kGuard;
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-            g[r] = S[r];
-            gp |= min(S[r], P::kSat) << (r * P::kW);
-            const uint32_t i = lane * E + r;
-            const uint32_t pos = k * ell + i;
-            if (i < ell && pos < Lrun) sev[base + pos] = S[r];
+            for (int r = 0; r < E; ++r) cword |= min(c[r], P::kSat) << (r * P::kW);
         }
-        if (word & kEvSpecial) {
-            cprevw = 0;
-#pragma unroll
-            for (int r = 0; r < E; ++r) cprevw |= min(c[r], P::kSat) << (r * P::kW);
-        } else {
-            cprevw = word;
-        }
-        last_ns = k;
-        lastv = lane >= (k & 63) ? k : lastv;
-        ++n_changed;
+        commit(k, S, cword);
     };
 
-    for (uint32_t q = 0; q < n_pieces; ++q) {
-        if (issued < n_pieces) {
-            issue();
+    // the four blocks of one piece, one after the other (the profile may change under them)
+    auto slow_piece = [&](uint32_t q, const uint4& w) {
 #ifdef QMCP_EV_STAMP
-            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+        ++st_slow_pieces;
 #endif
-            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        uint32_t wj = w.x, w1 = w.y, w2 = w.z, w3 = w.w;  // (rotated, not indexed: an indexed vector goes to scratch)
+#pragma unroll 1
+        for (uint32_t j = 0; j < 4; ++j, wj = w1, w1 = w2, w2 = w3) {
+            const uint32_t k = 4 * q + j;
+            if (k >= n_blocks) break;
+            if (__builtin_amdgcn_ballot_w64(((wj - gp) & P::kAll) != P::kAll) != 0) {
 #ifdef QMCP_EV_STAMP
-            st_wait += __builtin_amdgcn_s_memtime() - w0;
+                const unsigned long long g0 = __builtin_amdgcn_s_memtime();
 #endif
-        } else if (!drained) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            drained = true;
+                general_block(k, wj);
+#ifdef QMCP_EV_STAMP
+                st_gen += __builtin_amdgcn_s_memtime() - g0;
+#endif
+            } else {
+                cprevw = wj;
+            }
         }
-        const uint4 w = s_evring[(q % kEvSlots) * 64 + lane];
-        const uint32_t x0 = w.x - gp, x1 = w.y - gp, x2 = w.z - gp, x3 = w.w - gp;
-        const uint32_t bad = (((w.x ^ gp ^ x0) | (w.y ^ gp ^ x1) | (w.z ^ gp ^ x2) | (w.w ^ gp ^ x3)) & P::kBorrow) |
-                             ((w.x | w.y | w.z | w.w) & kEvSpecial);
-        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
 #ifdef QMCP_EV_STAMP
-            const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-            ++st_slow_pieces;
+        st_slow += __builtin_amdgcn_s_memtime() - s0;
 #endif
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    };
+
+    // four pieces (sixteen blocks) per round; the next four are read from the ring meanwhile
+    auto piece_and = [&](const uint4& w) { return ((w.x - gp) & (w.y - gp)) & ((w.z - gp) & (w.w - gp)); };
+    for (uint32_t q = 0; q < n_pieces; q += 4) {
+        if (landed < q + 8) wait_for(q + 8);  // pieces q + 4 .. q + 7 are in the ring
+        uint4 nxt[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = 4 * q + j;
-                if (k < n_blocks) {
-                    const uint32_t xj = ws[j] - gp;
-                    const uint32_t bj = ((ws[j] ^ gp ^ xj) & P::kBorrow) | (ws[j] & kEvSpecial);
-                    if (__builtin_amdgcn_ballot_w64(bj != 0) != 0) {
-#ifdef QMCP_EV_STAMP
-                        const unsigned long long g0 = __builtin_amdgcn_s_memtime();
-#endif
-                        general_block(k, ws[j]);
-#ifdef QMCP_EV_STAMP
-                        st_gen += __builtin_amdgcn_s_memtime() - g0;
-#endif
-                    } else cprevw = ws[j];
+        for (int i = 0; i < 4; ++i) nxt[i] = s_evring[((q + 4 + i) % kEvSlots) * 64 + lane];
+        if ((q & 15) == 0 && lane == 0) s_ctl[1] = q;  // every piece before q has been read into registers
+        const uint32_t all = (piece_and(cur[0]) & piece_and(cur[1])) & (piece_and(cur[2]) & piece_and(cur[3]));
+        if (__builtin_amdgcn_ballot_w64((all & P::kAll) != P::kAll) != 0) {
+            // some block changes the profile: piece by piece, each tested against the profile as it is then
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (q + i < n_pieces) {
+                    if (__builtin_amdgcn_ballot_w64((piece_and(cur[i]) & P::kAll) != P::kAll) != 0) slow_piece(q + i, cur[i]);
+                    else cprevw = cur[i].w;
                 }
             }
-#ifdef QMCP_EV_STAMP
-            st_slow += __builtin_amdgcn_s_memtime() - s0;
-#endif
         } else {
-            cprevw = w.w;
+            cprevw = cur[3].w;
         }
-        if ((q & 15) == 15 || q + 1 == n_pieces) {
+        if ((q & 15) == 12 || q + 4 >= n_pieces) {
             // 64 blocks done: for each of them the last changed block at or before it
             const uint32_t kb = (q >> 4) * 64 + lane;
             if (kb < n_blocks) my_last[kb] = lastv;
             lastv = last_ns;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
     }
     if (iter_stats && lane == 0) {
         atomicAdd(&iter_stats[0], n_changed);

@@ -62,15 +62,15 @@ struct qmcp_hip_ctx {
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
-    DevBuf lookback;   // chained radix: (tile, digit) status granules, zeroed when (re)allocated
-    DevBuf radixctl;   // [4][256] digit counts, [4][256] digit bases, 4 tickets, timeout flag
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
-    uint32_t radix_epoch = 0;      // unique per chained pass for the life of the context
-    bool chained_radix_ok = true;  // cleared for good if a look-back ever times out
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
-    uint32_t* h_stats = nullptr;   // pinned landing zone for the prepare statistics / scalars
+    unsigned long long* h_scalars = nullptr;  // pinned landing zone of the solve's result scalars (4 words)
+    // a solve that has been enqueued but not yet completed (qmcp_hip_solve_device_begin / _end)
+    bool pending = false;
+    qmcp_hip_stats pend_stats;
+    uint32_t pend_whole_contig_chains = 0;  // mixed spans without cut points: one chain per non-empty contig
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
     DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
@@ -138,10 +138,14 @@ void collect_spans(qmcp_hip_ctx* c) {
 }
 
 int ensure(qmcp_hip_ctx* c, DevBuf& b, size_t bytes) {
-    (void)c;
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return QMCP_OK;
     if (b.p) {
+        // growing a buffer frees it: nothing queued on this context may still be using the old one
+        // (hipFree would wait for the whole device anyway -- this names the wait and keeps it to the
+        // one case where a later call is larger than every earlier one)
+        if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
         HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -340,9 +344,14 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     return QMCP_OK;
 }
 
-int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
-                    const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
-                    uint32_t M, uint64_t* d_mask, qmcp_hip_stats* st) {
+// Everything of a solve up to and including its last launch; nothing here waits for the device
+// except the one small read-back that picks the path (span statistics, heaviest range), and that
+// wait leaves the device free to work on whatever else is queued.  solve_complete collects.
+int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                  const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
+                  uint32_t M, uint64_t* d_mask) {
+    if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
+    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 4 * sizeof(unsigned long long), hipHostMallocDefault));
     Problem pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n;
@@ -356,8 +365,12 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     if (n == 0 || ltot == 0) {
         if (mask_words) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
         if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (st) *st = local;
+        HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
+        for (int i = EV_PREP; i <= EV_MARK; ++i) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
+        c->h_scalars[0] = c->h_scalars[1] = c->h_scalars[2] = c->h_scalars[3] = 0;
+        c->pend_stats = local;
+        c->pend_whole_contig_chains = 0;
+        c->pending = true;
         return QMCP_OK;
     }
     // size the whole arena before anything is enqueued (growing a buffer frees it, and
@@ -394,28 +407,10 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     TRY(upload_tables(c, roff, pr));
 
     uint32_t hs[3];
-    // Chained radix passes (one kernel per digit, decoupled look-back) are an opt-in experiment:
-    // on cfg4 they measured 1.02 ms per pass against 1.13 ms for histogram + scan + scatter, and
-    // the whole-call digit histograms they need cost k_prepare 0.2 ms -- no net gain until the
-    // look-back is made wave-parallel.  QMCP_HIP_CHAINED_RADIX=1 enables them.
-    const bool try_chained = c->chained_radix_ok && n >= (1u << 16) &&
-                             std::getenv("QMCP_HIP_CHAINED_RADIX") != nullptr;
-    uint32_t* d_ctl = nullptr;
-    if (try_chained) {
-        const uint32_t tiles = qmcp::sort_tiles(n);
-        const size_t lb_bytes = (size_t)tiles * 256 * sizeof(unsigned long long);
-        if (c->lookback.cap < lb_bytes) {
-            TRY(ensure(c, c->lookback, lb_bytes));
-            HIP_TRY(hipMemsetAsync(c->lookback.p, 0, c->lookback.cap, c->stream));
-        }
-        TRY(ensure(c, c->radixctl, (2 * 4 * 256 + 16) * sizeof(uint32_t)));
-        d_ctl = (uint32_t*)c->radixctl.p;
-        HIP_TRY(hipMemsetAsync(d_ctl, 0, (2 * 4 * 256 + 16) * sizeof(uint32_t), c->stream));
-    }
     // the range partition's per-tile histogram is produced by the same pass when the range-ranked
     // path can be taken (uniformity is only known afterwards; the table is cheap)
     const uint32_t range_shift = qmcp::range_shift_for(ltot);
-    const bool may_rank = n >= rank_min_reads() && qmcp::range_path_supported(ltot) && !try_chained;
+    const bool may_rank = n >= rank_min_reads() && qmcp::range_path_supported(ltot);
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 65540;
     uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
@@ -424,7 +419,7 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     bool have_gstart = true;
     if (!may_rank) {
         HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
-        TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, false, range_shift, d_ctl, hs));
+        TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, false, range_shift, nullptr, hs));
         HIP_TRY(hipEventRecord(c->ev[EV_PREP], c->stream));
     } else {
         // Large call that can take the range-ranked route if its spans turn out uniform.  The host
@@ -572,31 +567,9 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     local.sort_passes = ranked ? 1u : passes;  // ranked path: one range partition, no sort
     const uint32_t n_tiles = qmcp::sort_tiles(n);
     int kin = 0, vin = 0;  // buffers holding the sorted output at the end
-    const bool chained = try_chained && uniform;
     if (!ranked && uniform) need_gstart();  // the sort-based routes bucket the bare keys
     if (ranked) {
         // keep mask already written by k_rank_mark
-    } else if (chained) {
-        // one kernel per digit: decoupled look-back over per-tile digit counts
-        uint32_t* d_base = d_ctl + 4 * 256;
-        uint32_t* d_ticket = d_ctl + 8 * 256;
-        uint32_t* d_timeout = d_ctl + 8 * 256 + 8;
-        {
-            KernelSpan sp(c, "k_digit_bases");
-            qmcp::launch_digit_bases(c->stream, d_ctl, d_base);
-        }
-        const void* recs_in = nullptr;
-        for (uint32_t p = 0; p < passes; ++p) {
-            const bool first = p == 0;
-            const int kout = first ? 0 : (kin ^ 1);
-            KernelSpan sp(c, "k_radix_onesweep");
-            qmcp::launch_radix_onesweep(c->stream, first, d_key32, recs_in, n, 8 * p, d_base + p * 256,
-                                        (unsigned long long*)c->lookback.p, ++c->radix_epoch,
-                                        d_ticket + p, d_timeout, c->keys[kout].p);
-            HIP_TRY(hipGetLastError());
-            kin = kout;
-            recs_in = c->keys[kin].p;
-        }
     } else if (!wide) {
         // records {key, read index}: keys[0] <-> keys[1]; the first pass reads bare keys
         const void* recs_in = nullptr;
@@ -744,36 +717,36 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
-    unsigned long long host_scalars[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(host_scalars, c->scalars.p, sizeof(host_scalars), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));
+    c->pend_stats = local;
+    c->pend_whole_contig_chains = 0;
+    if (mixed_whole_contigs)  // one wave per non-empty contig
+        for (uint32_t k = 0; k < n_contigs; ++k) c->pend_whole_contig_chains += lengths[k] != 0 ? 1u : 0u;
+    c->pending = true;
+    return QMCP_OK;
+}
+
+int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
+    if (!c->pending) return fail(QMCP_EINVAL, "no solve is pending on this context");
+    c->pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_spans(c);
-    if (chained) {
-        uint32_t timed_out = 0;
-        HIP_TRY(hipMemcpy(&timed_out, d_ctl + 8 * 256 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (timed_out != 0) {
-            // a look-back spin expired: never trust the chained pass on this context again and
-            // redo the solve with the three-kernel passes
-            c->chained_radix_ok = false;
-            return solve_on_device(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask, st);
-        }
-    }
 #ifdef QMCP_EV_STAMP
-    {
+    if (c->scalars.p) {
         uint32_t raw[16];
         HIP_TRY(hipMemcpy(raw, c->scalars.p, sizeof(raw), hipMemcpyDeviceToHost));
         const uint32_t* it = raw + 4;
-        fprintf(stderr, "[ev stamp] changed %u of %u blocks, stretches %u | x16 cycles: total %u general %u dma-wait %u slow-pieces %u (%u pieces)\n",
+        fprintf(stderr, "[ev stamp] changed %u of %u blocks, stretches %u | x16 cycles: total %u general %u wait-for-ring %u slow-pieces %u (%u pieces)\n",
                 it[0], it[1], it[2], it[4], it[5], it[6], it[7], it[8]);
     }
 #endif
+    qmcp_hip_stats local = c->pend_stats;
+    const unsigned long long* host_scalars = c->h_scalars;
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
-    local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu);
-    if (mixed_whole_contigs)  // one wave per non-empty contig
-        for (uint32_t k = 0; k < n_contigs; ++k) local.sweep_stretches += lengths[k] != 0 ? 1u : 0u;
+    local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu) + c->pend_whole_contig_chains;
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);
@@ -782,6 +755,13 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     local.ms_total = elapsed(c->ev[EV_BEGIN], c->ev[EV_MARK]);
     if (st) *st = local;
     return QMCP_OK;
+}
+
+int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                    const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
+                    uint32_t M, uint64_t* d_mask, qmcp_hip_stats* st) {
+    TRY(solve_enqueue(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask));
+    return solve_complete(c, st);
 }
 
 int use_device(qmcp_hip_ctx* c) {
@@ -898,7 +878,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->lookback, &c->radixctl, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -907,6 +887,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_tables) (void)hipHostFree(c->h_tables);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -942,6 +923,22 @@ int qmcp_hip_solve_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint3
     TRY(order_after(c, hip_stream));
     return solve_on_device(c, d_starts, d_ends, contig_read_offsets, contig_lengths, n_contigs,
                            n_reads, max_coverage, d_keep_mask_out, stats);
+}
+
+int qmcp_hip_solve_device_begin(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
+                                uint64_t n_reads, const uint64_t* contig_read_offsets,
+                                const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t max_coverage,
+                                uint64_t* d_keep_mask_out, void* hip_stream) {
+    TRY(use_device(c));
+    if (n_reads && (!d_starts || !d_ends || !d_keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    TRY(order_after(c, hip_stream));
+    return solve_enqueue(c, d_starts, d_ends, contig_read_offsets, contig_lengths, n_contigs, n_reads,
+                         max_coverage, d_keep_mask_out);
+}
+
+int qmcp_hip_solve_end(qmcp_hip_ctx* c, qmcp_hip_stats* stats) {
+    TRY(use_device(c));
+    return solve_complete(c, stats);
 }
 
 int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,

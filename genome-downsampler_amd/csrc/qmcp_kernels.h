@@ -113,12 +113,6 @@ void launch_amplicon_filter(hipStream_t st, const uint32_t* starts, const uint32
                             uint32_t n_amp, uint32_t min_length, uint32_t min_mapq,
                             uint64_t* pair_keep);
 
-// chained ("onesweep"-style) radix pass on records: one kernel per digit
-void launch_digit_bases(hipStream_t st, const uint32_t* hist4, uint32_t* base4);
-void launch_radix_onesweep(hipStream_t st, bool first, const uint32_t* keys, const void* recs_in,
-                           uint32_t n, uint32_t shift, const uint32_t* digit_base,
-                           unsigned long long* status, uint32_t epoch, uint32_t* ticket,
-                           uint32_t* timeout_flag, void* recs_out);
 // range-ranked uniform path: one stable partition of {start, index} records by position range,
 // then per-range LDS histograms (counts) and per-range ordered ranking against S(p) (keep mask)
 uint32_t range_shift_for(uint32_t ltot);

@@ -14,7 +14,8 @@
 // One translation unit, kept in parts under kernels/ (included below, in dependency order):
 //   wave_primitives          DPP helpers, wave reductions and scans
 //   prepare_scan             k_prepare (validate, statistics, partition histogram), exclusive scan
-//   radix_sort, radix_chained  LSD radix passes (sort-based routes), the opt-in chained pass
+//   radix_sort               LSD radix passes (sort-based routes)
+//   bucket_offsets           sort-based routes: bucket offsets from the sorted keys (heads + reverse min-scan)
 //   ranked_route             range partition (one or two levels), per-range offsets, ordered ranking
 //   sweep_uniform            block forms of the uniform-span sweep, single-wave kernel
 //   sweep_segments           cut points (coverage <= M): contigs split into independently swept stretches
@@ -44,7 +45,7 @@ static constexpr uint32_t kInf = 0x40000000u;
 #include "kernels/prepare_scan.inc.hip"
 #include "kernels/radix_sort.inc.hip"
 #include "kernels/ranked_route.inc.hip"
-#include "kernels/radix_chained.inc.hip"
+#include "kernels/bucket_offsets.inc.hip"
 #include "kernels/sweep_uniform.inc.hip"
 #include "kernels/sweep_segments.inc.hip"
 #include "kernels/sweep_uniform_pipelines.inc.hip"

@@ -131,6 +131,21 @@ int qmcp_hip_solve_device(qmcp_hip_ctx* ctx,
                           uint32_t n_contigs, uint32_t max_coverage,
                           uint64_t* d_keep_mask_out, void* hip_stream, qmcp_hip_stats* stats);
 
+/* The same solve in two halves, for callers that keep more than one solve in flight (one per
+ * context: two contexts on one device let the selection sweep of one call -- a serial chain on a
+ * few compute units -- run beside the bandwidth-bound stages of the next).  _begin orders the solve
+ * after `hip_stream`, enqueues all of it and returns without waiting for the device (it does wait
+ * for one 16-byte read-back that picks the kernels; the device keeps working on other contexts
+ * meanwhile).  _end waits for the solve and fills `stats`.  One pending solve per context: a second
+ * _begin, or any other entry point of the same context, before _end fails with QMCP_EINVAL.
+ * The reference has no counterpart: its solve is one blocking call (src/app.cpp:132-139). */
+int qmcp_hip_solve_device_begin(qmcp_hip_ctx* ctx,
+                                const uint32_t* d_starts, const uint32_t* d_ends, uint64_t n_reads,
+                                const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                                uint32_t n_contigs, uint32_t max_coverage,
+                                uint64_t* d_keep_mask_out, void* hip_stream);
+int qmcp_hip_solve_end(qmcp_hip_ctx* ctx, qmcp_hip_stats* stats);
+
 /* Stage probe for parity tests of the deterministic half of the reference solver:
  * writes cov[p] for every base of every contig (contigs concatenated, sum(contig_lengths)
  * entries) -- the array BamApi::find_input_cover returns (libs/bam-api/src/bam_api.cpp:275-286)

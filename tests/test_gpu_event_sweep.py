@@ -63,12 +63,12 @@ def test_every_lane_layout_deep_and_multi_contig(pkg, oracle, solver, span):
     ss, ee = zip(*[_reads(rng, c, int(L), span) for c, L in zip(counts, lengths)])
     s, e = np.concatenate(ss), np.concatenate(ee)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
-    M = 10 if span > 192 else 40  # 3 M + 1 must fit the 7-bit fields of the four-slot layout
+    M = 10 if span > 192 else 40  # M must stay below the 6-bit counts of the four-slot layout
     _check(solver, oracle, s, e, lengths, M, offs)
     assert solver.last_stats.path == pkg.PATH_UNIFORM
 
 
-@pytest.mark.parametrize("M", [1, 7, 100, 340])
+@pytest.mark.parametrize("M", [1, 7, 100, 510])
 def test_cfg2_shape_with_hot_spots_and_piled_ends(pkg, oracle, solver, M):
     rng = np.random.default_rng(1000 + M)
     L, span = 30_000, 150
@@ -83,9 +83,10 @@ def test_cfg2_shape_with_hot_spots_and_piled_ends(pkg, oracle, solver, M):
 def test_cap_beyond_the_fields_takes_the_scan_kernels(pkg, oracle, solver):
     rng = np.random.default_rng(5)
     s, e = _reads(rng, 400_000, 20_000, 150)
-    _check(solver, oracle, s, e, 20_000, 341, expect_ev=False)   # 3 * 341 + 1 > 1023
+    _check(solver, oracle, s, e, 20_000, 511, expect_ev=False)   # three slots per lane: 9-bit counts
     s, e = _reads(rng, 400_000, 20_000, 200)
-    _check(solver, oracle, s, e, 20_000, 43, expect_ev=False)    # four slots per lane: 7-bit fields
+    _check(solver, oracle, s, e, 20_000, 63, expect_ev=False)    # four slots per lane: 6-bit counts
+    _check(solver, oracle, s, e, 20_000, 62)
 
 
 @pytest.mark.parametrize("depth", [0.3, 1.0, 2.0, 6.0])
@@ -158,3 +159,15 @@ def test_random_cases_forced_event_sweep(pkg, oracle, solver, seed):
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     _check(solver, oracle, s, e, np.array(lengths, np.uint32), M, offs,
            QMCP_HIP_CUTS=str(int(rng.integers(0, 2))))
+
+
+@pytest.mark.parametrize("span", [32, 65, 97, 150, 193, 256])
+def test_tiny_genomes_of_one_to_eight_blocks(pkg, oracle, solver, span):
+    """genomes of a few blocks: the first block, a cut last block and nothing between (a hipcc fold of
+    `x >= ell ? min(x - ell, ltot) : 0` once read the wrong bucket offset here)"""
+    for f in (1.0, 1.01, 1.5, 1.95, 2.0, 2.05, 2.5, 3.99, 4.0, 4.01, 8.2):
+        L = max(span, int(f * span))
+        for M in (1, 11):
+            rng = np.random.default_rng(int(f * 100) + span + M)
+            s, e = _reads(rng, 3000, L, span)
+            _check(solver, oracle, s, e, L, M)
