@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark of the quasi-MCP solver path: Mreads/s selected at target coverage M=100.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2] [--mode per-gpu|sharded]
 
 A step is one pass of the hot path (device-resident reads -> device keep bitmask, plus the
 RCCL gather of the masks when N > 1) over one batch of libs/reads-gen-style synthetic reads.
-Workload per GPU (weak scaling): BASELINE.json configs[3] -- 8 contigs x rand_reads_uniform(
-seed 12345 + c, 6 250 000 pairs, L = 1 000 000, len 150), 100 M reads, M = 100; rank r uses
-seeds 12345 + 8 r + c.  Inputs are resident in HBM when the timed region starts.
+Workload, --mode per-gpu (default, weak scaling): BASELINE.json configs[3] PER GPU -- 8 contigs x
+rand_reads_uniform(seed 12345 + c, 6 250 000 pairs, L = 1 000 000, len 150), 100 M reads, M = 100;
+rank r uses seeds 12345 + 8 r + c.  --mode sharded (strong scaling): ONE configs[3] for the whole
+job, its 8 contigs dealt to the ranks by genome-downsampler_amd.sharding.assign_contigs, every rank
+solving its share, masks gathered (padded to the largest share).  Inputs are resident in HBM when the
+timed region starts.  Two solves are kept in flight per GPU (two solver contexts, the two-phase entry
+qmcp_hip_solve_device_begin / _end): the selection sweep of one -- a serial chain on 8 of 256 compute
+units -- runs beside the bandwidth-bound stages of the next; every solve and gather completes inside
+the timed region.
 
 For N > 1 launch through torch.distributed.run (one rank per GPU over RCCL); rank 0 prints ONE
 JSON line.  The CPU baseline (oracle/, rank 0, N = 1 only) is a reported number, not the target.
@@ -27,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
 # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction), keyed by workload
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic_{workload}.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic_{workload}.json")
 
 WORKLOADS = {
     # name: (contigs per GPU, pairs per contig, contig length, read length, M)
@@ -75,6 +81,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["per-gpu", "sharded"], default="per-gpu",
+                    help="N > 1: the workload per GPU (weak scaling) or one workload sharded by contig (strong)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="solves kept in flight per GPU (two solver contexts)")
     # rehearsal knobs (not used by the driver): run several ranks on ONE GPU over gloo to
     # exercise the N > 1 plumbing on a single-GPU box
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
@@ -104,87 +114,143 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("genome-downsampler_amd")
-    n_contigs, pairs, L, rl, M = WORKLOADS[args.workload]
+    sharding = importlib.import_module("genome-downsampler_amd.sharding")
+    n_contigs_job, pairs, L, rl, M = WORKLOADS[args.workload]
+    sharded = args.mode == "sharded" and world > 1
+    if sharded:
+        # one workload for the whole job: contigs dealt by cost (reads + the longest chain of a rank)
+        owned = sharding.assign_contigs([2 * pairs] * n_contigs_job, world, contig_lengths=[L] * n_contigs_job)
+        my_contigs = owned[rank]
+        seeds = [12345 + c for c in my_contigs]
+    else:
+        owned = None
+        my_contigs = list(range(n_contigs_job))
+        seeds = [12345 + n_contigs_job * rank + c for c in my_contigs]
+    n_contigs = len(my_contigs)
     ss, ee = [], []
-    for c in range(n_contigs):
-        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, pairs, L, rl, seed=12345 + n_contigs * rank + c)
+    for sd in seeds:
+        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, pairs, L, rl, seed=sd)
         ss.append(s)
         ee.append(e)
-    starts = np.concatenate(ss)
-    ends = np.concatenate(ee)
+    starts = np.concatenate(ss) if ss else np.zeros(0, np.uint32)
+    ends = np.concatenate(ee) if ee else np.zeros(0, np.uint32)
     n_reads = starts.size
     offs = (np.arange(n_contigs + 1, dtype=np.uint64) * np.uint64(2 * pairs))
-    lengths = np.full(n_contigs, L, dtype=np.uint32)
-    words = pkg.mask_words(n_reads)
+    lengths = np.full(max(n_contigs, 1), L, dtype=np.uint32)[:n_contigs] if n_contigs else np.full(1, 0, np.uint32)
+    if n_contigs == 0:
+        offs = np.zeros(2, np.uint64)
+    # gathered masks are padded to the largest share (equal shares in per-gpu mode)
+    share_reads = max(len(o) for o in owned) * 2 * pairs if sharded else n_reads
+    words = pkg.mask_words(share_reads)
 
     d_starts = torch.from_numpy(starts.view(np.int32)).to(dev)
     d_ends = torch.from_numpy(ends.view(np.int32)).to(dev)
-    # two mask buffers: the gather of step k (RCCL, its own stream) overlaps the solve of step k+1
-    d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
-    d_alls = [torch.zeros(words * world, dtype=torch.int64, device=dev) for _ in range(2)] \
+    # Four mask buffers in rotation: solve s writes buffer s % 4; its gather (RCCL, its own stream) is
+    # started when the solve is collected one or two steps later and waited for before buffer s % 4
+    # is written again.
+    n_buf = 4
+    d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_buf)]
+    d_alls = [torch.zeros(words * world, dtype=torch.int64, device=dev) for _ in range(n_buf)] \
         if world > 1 else None
-    d_mask = d_masks[0]
-    solver = pkg.Solver(local_rank)
+    depth = args.in_flight
+    solvers = [pkg.Solver(local_rank) for _ in range(depth)]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    pending = [None, None]
+    gathers = [None] * n_buf        # async all_gather handles per mask buffer
+    in_flight = [None] * depth      # per solver context: the mask buffer of its pending solve
     step_no = [0]
+    last_buf = [0]
 
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if pending[k] is not None:  # buffer k is being gathered from two steps ago
-            pending[k].wait()
-            pending[k] = None
-        solver.solve_device(d_starts.data_ptr(), d_ends.data_ptr(), n_reads, lengths, M,
-                            d_masks[k].data_ptr(), contig_read_offsets=offs, stream=stream)
+    def collect(slot):
+        """wait for the solve pending on context `slot`, then start the gather of its mask"""
+        b = in_flight[slot]
+        if b is None:
+            return
+        solvers[slot].solve_end()
+        in_flight[slot] = None
+        last_buf[0] = b
         if world > 1:
             # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
-            pending[k] = dist.all_gather_into_tensor(d_alls[k], d_masks[k], async_op=True)
+            gathers[b] = dist.all_gather_into_tensor(d_alls[b], d_masks[b], async_op=True)
+
+    def step():
+        s_no = step_no[0]
+        step_no[0] += 1
+        slot, b = s_no % depth, s_no % n_buf
+        collect(slot)                      # this context's previous solve (depth steps ago)
+        if gathers[b] is not None:         # buffer b: gathered since n_buf steps ago
+            gathers[b].wait()
+            gathers[b] = None
+        solvers[slot].solve_device_begin(d_starts.data_ptr(), d_ends.data_ptr(), n_reads, lengths, M,
+                                         d_masks[b].data_ptr(), contig_read_offsets=offs, stream=stream)
+        in_flight[slot] = b
 
     def fence():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        for k in range(depth):
+            collect((step_no[0] + k) % depth)   # oldest first
+        for b in range(n_buf):
+            if gathers[b] is not None:
+                gathers[b].wait()
+                gathers[b] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def all_kernel_times():
+        out = {}
+        for sv in solvers:
+            for name, (n, ms) in sv.kernel_times().items():
+                a = out.get(name, (0, 0.0))
+                out[name] = (a[0] + n, a[1] + ms)
+        return out
 
     for _ in range(args.warmup):
         step()
     # Timed region: HIP events (recorded by the library on the stream the kernel is launched on)
     # bracket the dominant kernel -- the selection sweep -- only: every bracket costs a few
     # microseconds of device idle time, and seven of them per step are 2 % of a cfg4 solve.
-    solver.set_profiling(2)
     fence()
+    for sv in solvers:
+        sv.set_profiling(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    ktimes_live = solver.kernel_times()
-    st_live = solver.last_stats  # of the last timed solve
+    ktimes_live = all_kernel_times()
+    st_live = solvers[(step_no[0] - 1) % depth].last_stats  # of the last timed solve
     # Per-kernel breakdown: the same step a few more times, untimed, with every kernel bracketed.
     breakdown_steps = min(args.steps, 5)
-    solver.set_profiling(1)
+    for sv in solvers:
+        sv.set_profiling(1)
     for _ in range(breakdown_steps):
         step()
     fence()
-    ktimes = solver.kernel_times()
-    solver.set_profiling(0)
+    ktimes = all_kernel_times()
+    for sv in solvers:
+        sv.set_profiling(0)
+    # one solve alone on the device: its latency, as opposed to the pipelined rate
+    solvers[0].solve_device(d_starts.data_ptr(), d_ends.data_ptr(), n_reads, lengths, M,
+                            d_masks[0].data_ptr(), contig_read_offsets=offs, stream=stream)
+    alone_ms = float(solvers[0].last_stats.ms_total)
+    d_mask = d_masks[0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_reads = n_reads * world
+    if sharded:
+        total_reads = n_contigs_job * 2 * pairs      # one workload for the whole job
+    else:
+        total_reads = n_reads * world
     value = total_reads * args.steps / elapsed / 1e6
     st = st_live
 
     out = None
     if rank == 0:
         b_alg = algorithmic_bytes(n_reads, n_contigs * L, n_contigs)
+        # dominant kernel: largest summed duration per step (the solves of a pipelined run overlap, so
+        # durations do not add up to the step time)
         dom_name, (dom_launches, dom_ms) = max(ktimes.items(), key=lambda kv: kv[1][1])
         dom_where = "breakdown steps after the timed region"
         if dom_name in ktimes_live:  # the dominant kernel is the one bracketed in the timed region
@@ -192,26 +258,36 @@ def main():
             dom_where = "timed region"
         dom_avg_ms = dom_ms / dom_launches
         achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9
-        dev_ms = float(st.ms_total)  # HIP events around the whole solve
-        traffic = None
+        step_ms = elapsed / args.steps * 1e3
+        traffic, traffic_source, total_traffic = None, None, None
         try:
             pmc = json.load(open(PMC_TRAFFIC_FILE.format(workload=args.workload)))
             traffic = pmc.get(dom_name, {}).get("hbm_bytes_per_launch")
+            total_traffic = pmc.get("_total", {}).get("hbm_bytes_per_solve")
+            traffic_source = ("constant read from " + os.path.relpath(PMC_TRAFFIC_FILE.format(workload=args.workload), ROOT)
+                              + " (" + str(pmc.get("_source", "rocprofv3 --pmc passes, profiles/collect.sh")) + "); not measured in this run")
         except (OSError, ValueError):
             pass
+        # what bounds the dominant kernel itself: the event sweep's chain wave is a serial dependency
+        # chain (issue latency of one wave), the streaming kernels are HBM-bound
+        latency_bound = dom_name.startswith("k_sweep")
         out = {
             "metric": "Mreads/s selected at target coverage M=100",
             "value": round(value, 2), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload} per GPU: {n_contigs} contigs x rand_reads_uniform("
-                            f"{pairs} pairs, L={L}, len={rl}), {n_reads} reads, M={M}; "
+                "workload": (f"{args.workload} sharded over {world} GPUs by contig (one workload for the job): "
+                             if sharded else f"{args.workload} per GPU: ")
+                            + f"{n_contigs_job} contigs x rand_reads_uniform("
+                            f"{pairs} pairs, L={L}, len={rl}), {n_contigs_job * 2 * pairs} reads, M={M}; "
                             "device-resident reads -> device keep bitmask"
-                            + ("; + RCCL all_gather of the keep masks, overlapped with the next "
-                               "step's solve (all completed inside the timed region)"
+                            + ("; + RCCL all_gather of the keep masks, overlapped with the following "
+                               "solves (all completed inside the timed region)"
                                if world > 1 else ""),
+                "multi_gpu_mode": args.mode if world > 1 else "single GPU",
+                "solves_in_flight_per_gpu": depth,
                 "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
                 "path": {1: "uniform-span block sweep", 2: "mixed-span event sweep"}.get(st.path),
                 "kept_reads_per_gpu": int(st.n_kept),
@@ -219,19 +295,26 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": b_alg,
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_launches,
+                "kernel_bound": "latency (one wave's dependency chain; see kernel_own_GBps)" if latency_bound else "hbm",
+                "kernel_own_GBps": (round(traffic / (dom_avg_ms * 1e-3) / 1e9, 2) if traffic else None),
                 "whole_solve": {
-                    "device_ms": round(dev_ms, 4),
-                    "achieved": round(b_alg / (dev_ms * 1e-3) / 1e9, 2),
-                    "frac": round(b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "note": "algorithmic bytes of one solve over the time one solve takes: pipelined "
+                            "(ms_per_step, two in flight) and alone on the device (HIP events)",
+                    "pipelined_ms": round(step_ms, 4),
+                    "achieved": round(b_alg / (step_ms * 1e-3) / 1e9, 2),
+                    "frac": round(b_alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "alone_device_ms": round(alone_ms, 4),
+                    "alone_frac": round(b_alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "hbm_traffic_per_solve": total_traffic,
                 },
                 "measured_in": dom_where,
                 "kernels_ms_per_step": {k: round(ms / breakdown_steps, 4) for k, (_, ms) in
                                         sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
                 "kernels_measured_in": f"{breakdown_steps} extra steps after the timed region, "
-                                       "every kernel bracketed",
+                                       "every kernel bracketed (solves overlap: the sum exceeds a step)",
             },
         }
         if world == 1:
@@ -241,12 +324,12 @@ def main():
             e2e = []
             for _ in range(3):
                 t1 = time.perf_counter()
-                solver.solve(starts, ends, lengths, M, contig_read_offsets=offs)
+                solvers[0].solve(starts, ends, lengths, M, contig_read_offsets=offs)
                 e2e.append(time.perf_counter() - t1)
             out["host_entry"] = {"e2e_ms": round(min(e2e) * 1e3, 3),
                                  "Mreads_per_s": round(n_reads / min(e2e) / 1e6, 1),
-                                 "h2d_ms": round(float(solver.last_stats.ms_h2d), 3),
-                                 "d2h_ms": round(float(solver.last_stats.ms_d2h), 3),
+                                 "h2d_ms": round(float(solvers[0].last_stats.ms_h2d), 3),
+                                 "d2h_ms": round(float(solvers[0].last_stats.ms_d2h), 3),
                                  "note": "PCIe-inclusive; reported beside, never as, value"}
         if world == 1 and not args.no_cpu_baseline:
             base, oracle_mask = cpu_baseline(pkg, args.workload)
@@ -259,7 +342,8 @@ def main():
                                   oracle_mask[:w0 - (1 if tail_bits else 0)])
             out["parity_vs_oracle_on_sample"] = bool(same)
         print(json.dumps(out), flush=True)
-    solver.close()
+    for sv in solvers:
+        sv.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -167,36 +167,57 @@ size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) { return 
 size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {
     return ((size_t)sweep_ev_pieces(ltot, ell, n_wg) * 4 + 64) * sizeof(uint32_t);
 }
-bool launch_sweep_uniform_ev(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
-                             uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                             uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                             uint32_t* pk, uint32_t* sev, uint32_t* lastns) {
+// the three launches of the event-driven form, separately (the host brackets each with events)
+#define QMCP_EV_DISPATCH(e, CALL)              \
+    switch (e) {                                \
+        case 1: { CALL(1) } break;              \
+        case 2: { CALL(2) } break;              \
+        case 3: { CALL(3) } break;              \
+        case 4: { CALL(4) } break;              \
+        default: return false;                  \
+    }
+bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
+                          uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
+                          uint32_t* pk) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
-    const uint32_t e = (ell + 63) / 64;
-#define QMCP_SWEEP_EV(EE)                                                                                \
-    {                                                                                                     \
-        const size_t lds = (size_t)kEvSlots * 1024;                                                       \
-        (void)hipFuncSetAttribute((const void*)k_sweep_uniform_ev<EE>,                                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-        hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, \
-                           ell, M, ltot, seg, pieces, pk);                                                \
-        hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(128), lds, st, boff, d_poff, n_contigs, \
-                           ell, M, ltot, pk, sev, lastns, iter_stats, seg);                               \
-        hipLaunchKernelGGL(k_sweep_expand<EE>, dim3(pieces), dim3(256), 0, st, boff, d_poff, n_wg, ell,   \
-                           ltot, seg, pieces, sev, lastns, selend);                                       \
-    }
-    switch (e) {
-        case 1: QMCP_SWEEP_EV(1); break;
-        case 2: QMCP_SWEEP_EV(2); break;
-        case 3: QMCP_SWEEP_EV(3); break;
-        case 4: QMCP_SWEEP_EV(4); break;
-        default: return false;
-    }
-#undef QMCP_SWEEP_EV
+#define QMCP_CALL(EE)                                                                                      \
+    hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, ell, \
+                       M, ltot, seg, pieces, pk);
+    QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
+#undef QMCP_CALL
     return true;
 }
+bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
+                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
+                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats) {
+    if (!sweep_uniform_ev_supported(ell, M)) return false;
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
+    const size_t lds = (size_t)kEvSlots * 1024;
+#define QMCP_CALL(EE)                                                                                       \
+    (void)hipFuncSetAttribute((const void*)k_sweep_uniform_ev<EE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                    \
+    hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(128), lds, st, boff, d_poff, n_contigs, ell,  \
+                       M, ltot, pk, sev, lastns, iter_stats, seg);
+    QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
+#undef QMCP_CALL
+    return true;
+}
+bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
+                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
+                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend) {
+    if (!sweep_uniform_ev_supported(ell, M)) return false;
+    const uint32_t n_wg = seg ? n_seg_max : n_contigs;
+    const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
+#define QMCP_CALL(EE)                                                                                    \
+    hipLaunchKernelGGL(k_sweep_expand<EE>, dim3(pieces), dim3(256), 0, st, boff, d_poff, n_wg, ell, ltot, \
+                       seg, pieces, sev, lastns, selend);
+    QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
+#undef QMCP_CALL
+    return true;
+}
+#undef QMCP_EV_DISPATCH
 
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,

@@ -327,10 +327,20 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         if (std::strcmp(e, "fast") == 0 || std::strcmp(e, "gen") == 0) ev = false;
     }
     if (ev && qmcp::sweep_uniform_ev_supported(span, M)) {
-        KernelSpan sp(c, "k_sweep_uniform_ev(pack, chain, expand)", st);
-        if (qmcp::launch_sweep_uniform_ev(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max,
-                                          (uint32_t*)c->evpk.p, (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p))
-            return QMCP_OK;
+        uint32_t* pk = (uint32_t*)c->evpk.p;
+        uint32_t* sev = (uint32_t*)c->cstart.p;
+        uint32_t* lastns = (uint32_t*)c->evlast.p;
+        {
+            KernelSpan sp(c, "k_sweep_pack", st);
+            qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk);
+        }
+        {
+            KernelSpan sp(c, "k_sweep_uniform_ev", st);
+            qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk, sev, lastns, d_iters);
+        }
+        KernelSpan sp(c, "k_sweep_expand", st);
+        qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, sev, lastns, selend);
+        return QMCP_OK;
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);

@@ -8,16 +8,35 @@ contigs are sliced, and how per-rank masks merge back into one global ReadIndex 
 import numpy as np
 
 
-def assign_contigs(read_counts, world_size):
-    """longest-processing-time assignment of contigs to ranks by read count; deterministic.
+# Cost model of one rank's share (measured on MI355X): the bandwidth-bound stages
+# cost time per READ and add up over a rank's contigs; the selection sweep is one serial chain per
+# contig, all of a rank's chains side by side, so it costs the LONGEST contig's length.
+NS_PER_READ = 0.008        # prepare + partition + offsets + ranking: ~0.8 ms per 1e8 reads
+NS_PER_POSITION = 1.5      # block-scan sweep on shallow data; deep data (event sweep) is ~0.5
+
+
+def rank_cost(read_counts, contig_lengths, contigs):
+    reads = sum(int(read_counts[c]) for c in contigs)
+    longest = max((int(contig_lengths[c]) for c in contigs), default=0)
+    return NS_PER_READ * reads + NS_PER_POSITION * longest
+
+
+def assign_contigs(read_counts, world_size, contig_lengths=None):
+    """deterministic longest-processing-time assignment of contigs to ranks.  With contig_lengths the
+    cost of a rank is reads * NS_PER_READ + (its longest contig) * NS_PER_POSITION -- the sweep's
+    chains run side by side, so a rank pays for its longest one --, without it the read count alone.
     Returns a list (per rank) of ascending contig ids."""
-    order = sorted(range(len(read_counts)), key=lambda c: (-int(read_counts[c]), c))
-    load = [0] * world_size
+    n = len(read_counts)
+    if contig_lengths is None:
+        contig_lengths = [0] * n
+    def alone(c):
+        return NS_PER_READ * int(read_counts[c]) + NS_PER_POSITION * int(contig_lengths[c])
+    order = sorted(range(n), key=lambda c: (-alone(c), c))
     owned = [[] for _ in range(world_size)]
     for c in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
+        # the rank whose cost AFTER taking c is smallest
+        r = min(range(world_size), key=lambda k: (rank_cost(read_counts, contig_lengths, owned[k] + [c]), k))
         owned[r].append(c)
-        load[r] += int(read_counts[c])
     return [sorted(o) for o in owned]
 
 
