@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
     "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
-    "qmcp_hip_solve_end",
+    "qmcp_hip_solve_end", "qmcp_hip_demand_host",
 )
 
 QMCP_OK = 0
@@ -74,6 +74,8 @@ _hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 _hip.qmcp_hip_solve_device_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 _hip.qmcp_hip_solve_end.argtypes = [C.c_void_p, C.POINTER(Stats)]
+_hip.qmcp_hip_demand_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 _hip.qmcp_hip_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
                                         C.c_uint32, _u32p]
 _hip.qmcp_hip_filtered_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
@@ -255,6 +257,17 @@ class Solver:
                                                         _p64(offs), _p32(lengths), lengths.size,
                                                         _p64(km), _p32(cov)))
         return cov[:int(lengths.sum())]
+
+    def demand(self, starts, ends, ref_genome_length, max_coverage):
+        """(b, d) of the reference's flow network for one contig, computed on the device:
+        create_b_function / create_demand_function, quasi_mcp_cpu_max_flow_solver.cpp:58-87"""
+        s, e = _u32(starts), _u32(ends)
+        b = np.zeros(int(ref_genome_length) + 1, np.int32)
+        d = np.zeros(int(ref_genome_length) + 1, np.int32)
+        _check(_hip.qmcp_hip_demand_host(self._ctx, _p32(s), _p32(e), s.size, int(ref_genome_length),
+                                         int(max_coverage), b.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         d.ctypes.data_as(C.POINTER(C.c_int32))))
+        return b, d
 
     def complete_pairs(self, mask, n_reads):
         out = np.ascontiguousarray(mask, dtype=np.uint64).copy()

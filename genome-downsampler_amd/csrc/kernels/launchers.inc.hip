@@ -523,6 +523,10 @@ void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
     hipLaunchKernelGGL(k_coverage, dim3(grid_for(ltot, 256)), dim3(256), 0, st, boff, eoff, ltot, cov);
 }
 
+void launch_b_and_demand(hipStream_t st, const uint32_t* cov, uint32_t n, uint32_t M, int32_t* b, int32_t* d) {
+    const uint32_t grid = (n + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_b_and_demand, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, st, cov, n, M, b, d);
+}
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads) {
     hipLaunchKernelGGL(k_complete_pairs, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask,
                        n_words, n_reads);

@@ -35,6 +35,21 @@ __global__ __launch_bounds__(256) void k_coverage(const uint32_t* __restrict__ b
         cov[p] = boff[p + 1] - eoff[p];
 }
 
+// b and d of the reference's flow network from the coverage (stage probe): create_b_function's result
+// after its cap loop (quasi_mcp_cpu_max_flow_solver.cpp:58-73) is b[0] = 0, b[p + 1] = min(cov[p], M);
+// create_demand_function (:75-87) turns it, in place and ascending, into d[0] = -b[1],
+// d[i] = b[i] - b[i + 1] for 1 <= i < n, and leaves d[n] = b[n] (its loop stops at i < n).
+__global__ __launch_bounds__(256) void k_b_and_demand(const uint32_t* __restrict__ cov, uint32_t n, uint32_t M,
+                                                      int32_t* __restrict__ b, int32_t* __restrict__ d) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+        const int32_t bi = i == 0 ? 0 : (int32_t)min(cov[i - 1], M);
+        const int32_t bn = i < n ? (int32_t)min(cov[i], M) : 0;  // b[i + 1]
+        b[i] = bi;
+        d[i] = i == 0 ? -bn : (i < n ? bi - bn : bi);
+    }
+}
+
 // ------------------------------------------------------------------ "next" rows
 // BamApi::find_pairs on the bitmask (bam_api.cpp:239-273): mates are (2q, 2q+1).
 __global__ __launch_bounds__(256) void k_complete_pairs(uint64_t* __restrict__ mask,

@@ -794,12 +794,20 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
                     const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* cov_out) {
     TRY(use_device(c));
-    if (!cov_out || (n64 && (!starts || !ends))) return fail(QMCP_EINVAL, "null buffer");
+    if (c->pending) return fail(QMCP_EINVAL, "a solve is pending on this context (call qmcp_hip_solve_end)");
+    if (n64 && (!starts || !ends)) return fail(QMCP_EINVAL, "null buffer");
     Problem pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot;
     if (ltot == 0) return n ? fail(QMCP_EREAD, "reads given for zero-length contigs") : QMCP_OK;
-    if (n == 0) { std::memset(cov_out, 0, (size_t)ltot * sizeof(uint32_t)); return QMCP_OK; }
+    if (n == 0) {
+        // (cov_out == null: the caller wants the coverage left in the context's device buffer)
+        if (cov_out) std::memset(cov_out, 0, (size_t)ltot * sizeof(uint32_t));
+        TRY(ensure(c, c->cov, (size_t)ltot * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->cov.p, 0, (size_t)ltot * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return QMCP_OK;
+    }
     TRY(ensure(c, c->in_starts, (size_t)n * 4));
     TRY(ensure(c, c->in_ends, (size_t)n * 4));
     HIP_TRY(hipMemcpyAsync(c->in_starts.p, starts, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -827,8 +835,9 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     qmcp::launch_coverage(c->stream, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p, ltot,
                           (uint32_t*)c->cov.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(cov_out, c->cov.p, (size_t)ltot * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                           c->stream));
+    if (cov_out)
+        HIP_TRY(hipMemcpyAsync(cov_out, c->cov.p, (size_t)ltot * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return QMCP_OK;
 }
@@ -1004,6 +1013,7 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
 int qmcp_hip_coverage_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,
                            uint64_t n_reads, const uint64_t* contig_read_offsets,
                            const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t* cov_out) {
+    if (!cov_out) return fail(QMCP_EINVAL, "null buffer");
     return coverage_common(c, starts, ends, n_reads, contig_read_offsets, contig_lengths, n_contigs,
                            nullptr, cov_out);
 }
@@ -1012,9 +1022,27 @@ int qmcp_hip_filtered_coverage_host(qmcp_hip_ctx* c, const uint32_t* starts, con
                                     uint64_t n_reads, const uint64_t* contig_read_offsets,
                                     const uint32_t* contig_lengths, uint32_t n_contigs,
                                     const uint64_t* keep_mask, uint32_t* cov_out) {
-    if (!keep_mask && n_reads) return fail(QMCP_EINVAL, "keep_mask is null");
+    if ((!keep_mask && n_reads) || !cov_out) return fail(QMCP_EINVAL, "null buffer");
     return coverage_common(c, starts, ends, n_reads, contig_read_offsets, contig_lengths, n_contigs,
                            keep_mask, cov_out);
+}
+
+int qmcp_hip_demand_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                         uint32_t ref_genome_length, uint32_t max_coverage, int32_t* b_out, int32_t* d_out) {
+    if (!b_out || !d_out) return fail(QMCP_EINVAL, "null buffer");
+    if (ref_genome_length == 0) return fail(QMCP_EINVAL, "ref_genome_length == 0");
+    const uint64_t offs[2] = {0, n_reads};
+    TRY(coverage_common(c, starts, ends, n_reads, offs, &ref_genome_length, 1, nullptr, nullptr));
+    const size_t nb = ((size_t)ref_genome_length + 1) * sizeof(int32_t);
+    TRY(ensure(c, c->ecnt, nb));  // free after the coverage: b
+    TRY(ensure(c, c->eoff, nb));  //                          d
+    qmcp::launch_b_and_demand(c->stream, (const uint32_t*)c->cov.p, ref_genome_length, max_coverage,
+                              (int32_t*)c->ecnt.p, (int32_t*)c->eoff.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b_out, c->ecnt.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_out, c->eoff.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMCP_OK;
 }
 
 int qmcp_hip_complete_pairs_device(qmcp_hip_ctx* c, uint64_t* d_keep_mask, uint64_t n_reads,

@@ -105,6 +105,7 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
                               uint32_t n, uint32_t shift, const uint32_t* offs, void* recs_out);
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,
                      uint32_t* cov);
+void launch_b_and_demand(hipStream_t st, const uint32_t* cov, uint32_t n, uint32_t M, int32_t* b, int32_t* d);
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads);
 void launch_word_popcounts(hipStream_t st, const uint64_t* words, uint32_t n_words, uint32_t* counts);
 void launch_compact_pairs(hipStream_t st, const uint32_t* starts, const uint32_t* ends,

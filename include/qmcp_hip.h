@@ -164,6 +164,16 @@ int qmcp_hip_filtered_coverage_host(qmcp_hip_ctx* ctx,
                                     const uint32_t* contig_lengths, uint32_t n_contigs,
                                     const uint64_t* keep_mask, uint32_t* cov_out);
 
+/* Stage probe: the capped coverage b and the demand d of the reference's flow network for one
+ * contig, computed on the device -- create_b_function (quasi_mcp_cpu_max_flow_solver.cpp:58-73):
+ * b[0] = 0, b[p + 1] = min(cov[p], M); create_demand_function (:75-87): d[0] = -b[1],
+ * d[i] = b[i] - b[i + 1] for 1 <= i < n, d[n] = b[n].  Both outputs have ref_genome_length + 1
+ * entries (the reference's std::vector<int>). */
+int qmcp_hip_demand_host(qmcp_hip_ctx* ctx,
+                         const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                         uint32_t ref_genome_length, uint32_t max_coverage,
+                         int32_t* b_out, int32_t* d_out);
+
 /* BamApi::find_pairs (libs/bam-api/src/bam_api.cpp:239-273) on the bitmask: mates sit at
  * indices (2q, 2q+1) (bam_api.cpp:456-461), so completing pairs is an OR inside each
  * aligned bit pair.  In place on a device mask of ceil(n_reads/64) words. */

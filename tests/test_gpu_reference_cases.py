@@ -28,11 +28,33 @@ def test_reference_case(pkg, oracle, solver, name, kind, pairs, L, M):
     # ... which themselves must equal BamApi::find_input_cover / find_filtered_cover
     assert np.array_equal(in_cov, oracle.cover(s, e, L))
     assert np.array_equal(out_cov, oracle.cover(s, e, L, keep_mask=got))
+    # the device's b and d == create_b_function / create_demand_function (per-base loop, in-place
+    # differences with the i < n bound: quasi_mcp_cpu_max_flow_solver.cpp:58-87)
+    b_dev, d_dev = solver.demand(s, e, L, M)
+    assert np.array_equal(b_dev, oracle.b_function(s, e, L, M))
+    assert np.array_equal(d_dev, oracle.demand_function(s, e, L, M))
     # bit-identical kept set and a valid maximum flow of the reference network
     want = oracle.solve(s, e, L, M)
     assert np.array_equal(got, want)
     ok, value = oracle.check_flow(s, e, L, M, got)
     assert ok and value == oracle.graph(s, e, L, M).total_supply
+
+
+def test_small_fixture_b_and_d_on_the_device(pkg, oracle, solver):
+    """the reference's 16-read example (src/tests/coverage_tester.cpp:72-93): b and d from the device
+    equal the golden vectors captured from the reference's own code (tests/golden)"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+    fx = gold["small_fixture"]
+    s = np.array(fx["starts"], np.uint32)
+    e = np.array(fx["ends"], np.uint32)
+    b_dev, d_dev = solver.demand(s, e, fx["ref_genome_length"], fx["M"])
+    assert b_dev.tolist() == fx["b"] and d_dev.tolist() == fx["d"]
+    for M in (0, 1, 3, 100):
+        b_dev, d_dev = solver.demand(s, e, fx["ref_genome_length"], M)
+        assert np.array_equal(b_dev, oracle.b_function(s, e, fx["ref_genome_length"], M))
+        assert np.array_equal(d_dev, oracle.demand_function(s, e, fx["ref_genome_length"], M))
 
 
 def test_cfg2_one_million_reads(pkg, oracle, solver):
