@@ -331,6 +331,23 @@ def main():
                                  "h2d_ms": round(float(solvers[0].last_stats.ms_h2d), 3),
                                  "d2h_ms": round(float(solvers[0].last_stats.ms_d2h), 3),
                                  "note": "PCIe-inclusive; reported beside, never as, value"}
+        if world == 1:
+            # The plugin boundary itself (SURVEY section 8d T_e2e; the span src/app.cpp:132-139 brackets):
+            # BamApi holding SOAPairedReads (size_t columns) -> QuasiMcpHipSolver::solve -> Solution
+            # (vector<size_t>), one contig -- the reference is single-contig.  Best of three.
+            best = None
+            for _ in range(3):
+                kept, tms = pkg.plugin_solve_timed("quasi-mcp-hip", ss[0], ee[0], L, M)
+                if best is None or tms["solve_call_ms"] < best["solve_call_ms"]:
+                    best = tms
+            pcie_ms = 8.0 * ss[0].size / (n_reads * 8.0 / (float(solvers[0].last_stats.ms_h2d) * 1e-3)) * 1e3 \
+                if float(solvers[0].last_stats.ms_h2d) > 0 else None
+            best.update({"reads": int(ss[0].size), "kept": int(kept.size),
+                         "Mreads_per_s": round(ss[0].size / best["solve_call_ms"] / 1e3, 1),
+                         "pcie_floor_ms": round(pcie_ms, 3) if pcie_ms else None,
+                         "note": "one contig of the workload through SolverManager -> Solver::solve(M, BamApi&); "
+                                 "pcie_floor_ms = 8 B/read at the pageable-copy rate host_entry measured"})
+            out["plugin_entry"] = best
         if world == 1 and not args.no_cpu_baseline:
             base, oracle_mask = cpu_baseline(pkg, args.workload)
             out["cpu_baseline"] = base

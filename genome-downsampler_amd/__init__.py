@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
     "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
-    "qmcp_hip_solve_end", "qmcp_hip_demand_host",
+    "qmcp_hip_solve_end", "qmcp_hip_demand_host", "qmcp_hip_solve_host64",
 )
 
 QMCP_OK = 0
@@ -98,6 +98,9 @@ if _host is not None:
     _host.qmcp_host_solve.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.c_int, _u64p]
     _host.qmcp_host_solve.restype = C.c_int64
+    _host.qmcp_host_plugin_solve_timed.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32,
+                                                   C.c_uint32, _u64p, C.POINTER(C.c_float)]
+    _host.qmcp_host_plugin_solve_timed.restype = C.c_int64
     _host.qmcp_host_bamapi_probe.argtypes = [_u32p, _u32p, C.c_uint64, C.c_uint32, C.c_int, _u64p,
                                              C.c_uint64, _u32p, _u32p, _u64p]
     _host.qmcp_host_bamapi_probe.restype = C.c_int64
@@ -386,3 +389,21 @@ def host_solve(solver_name, starts, ends, ref_genome_length, max_coverage, with_
     if n < 0:
         raise KeyError(solver_name)
     return kept[:n].copy()
+
+
+def plugin_solve_timed(solver_name, starts, ends, ref_genome_length, max_coverage):
+    """the reference's "solve took" span (src/app.cpp:132-139) at the plugin boundary: a BamApi holding
+    SOAPairedReads (size_t columns) -> Solver::solve -> Solution.  Returns (kept ReadIndex array, dict of
+    host wall-clock milliseconds)"""
+    _need_host()
+    starts, ends = _u32(starts), _u32(ends)
+    kept = np.empty(max(starts.size, 1), dtype=np.uint64)
+    t = (C.c_float * 8)()
+    n = _host.qmcp_host_plugin_solve_timed(solver_name.encode(), _p32(starts), _p32(ends), starts.size,
+                                           int(ref_genome_length), int(max_coverage), _p64(kept), t)
+    if n < 0:
+        raise KeyError(solver_name)
+    names = ("solve_call_ms", "library_ms", "narrow_h2d_ms", "device_solve_ms", "d2h_ms", "expand_ms")
+    out = {k: round(float(t[i]), 3) for i, k in enumerate(names)}
+    out["host_threads"], out["chunks"] = int(t[6]), int(t[7])
+    return kept[:n].copy(), out

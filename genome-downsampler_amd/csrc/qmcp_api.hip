@@ -10,12 +10,15 @@
 // One host round trip (12 bytes) after `prepare` picks the path and the radix width.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "qmcp_hip.h"
@@ -67,6 +70,14 @@ struct qmcp_hip_ctx {
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     unsigned long long* h_scalars = nullptr;  // pinned landing zone of the solve's result scalars (4 words)
+    // qmcp_hip_solve_host64: pinned staging, two slots per narrowing thread, and a pinned mask landing zone
+    uint32_t* h_stage = nullptr;
+    size_t h_stage_words = 0;
+    uint64_t* h_mask = nullptr;
+    size_t h_mask_words = 0;
+    std::vector<hipEvent_t> stage_ev;
+    std::vector<hipStream_t> stage_streams;  // copy streams: one DMA engine moves ~29 GB/s, PCIe twice that
+    std::vector<hipEvent_t> stage_done;
     // a solve that has been enqueued but not yet completed (qmcp_hip_solve_device_begin / _end)
     bool pending = false;
     qmcp_hip_stats pend_stats;
@@ -907,6 +918,11 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_tables) (void)hipHostFree(c->h_tables);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_mask) (void)hipHostFree(c->h_mask);
+    for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->stage_done) (void)hipEventDestroy(e);
+    for (hipStream_t st : c->stage_streams) (void)hipStreamDestroy(st);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1008,6 +1024,135 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     (void)hipEventDestroy(t2); (void)hipEventDestroy(t3);
     return rc;
+}
+
+int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uint64_t* end_inds,
+                          uint64_t n_reads, const uint64_t* contig_read_offsets,
+                          const uint32_t* contig_lengths, uint32_t n_contigs, uint32_t max_coverage,
+                          uint64_t* keep_mask_out, qmcp_hip_stats* stats, qmcp_hip_host_breakdown* breakdown) {
+    using clock = std::chrono::steady_clock;
+    auto ms_since = [](clock::time_point t) { return std::chrono::duration<float, std::milli>(clock::now() - t).count(); };
+    const clock::time_point t_begin = clock::now();
+    TRY(use_device(c));
+    if (c->pending) return fail(QMCP_EINVAL, "a solve is pending on this context (call qmcp_hip_solve_end)");
+    if (n_reads && (!start_inds || !end_inds || !keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    if (n_reads > (1ull << 30)) return fail(QMCP_ERANGE, "n_reads exceeds 2^30 per call");
+    const size_t n = (size_t)n_reads;
+    const size_t words = (n + 63) / 64;
+    TRY(ensure(c, c->in_starts, n * sizeof(uint32_t)));
+    TRY(ensure(c, c->in_ends, n * sizeof(uint32_t)));
+    TRY(ensure(c, c->mask, words * sizeof(uint64_t)));
+    // chunks of 256 Ki reads (2 MiB of staging, 1 MiB per copy); thread t takes chunks t, t + T, ... and
+    // owns two staging slots, so no slot is ever shared: before reusing a slot it waits for the copy it
+    // issued from it two chunks ago
+    constexpr size_t kChunk = 1u << 18;
+    const size_t n_chunks = (n + kChunk - 1) / kChunk;
+    unsigned want = 8;
+    if (const char* e = std::getenv("QMCP_HIP_HOST_THREADS")) want = (unsigned)std::strtoul(e, nullptr, 10);
+    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = want < 1 ? 1 : want;
+    if (hw != 0 && T > hw) T = hw;
+    if (T > n_chunks) T = (unsigned)(n_chunks ? n_chunks : 1);
+    const size_t stage_words = (size_t)T * 2 * 2 * kChunk;  // T threads x 2 slots x (starts + ends)
+    if (c->h_stage_words < stage_words) {
+        if (c->h_stage) HIP_TRY(hipHostFree(c->h_stage));
+        c->h_stage = nullptr;
+        c->h_stage_words = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_stage, stage_words * sizeof(uint32_t), hipHostMallocDefault));
+        c->h_stage_words = stage_words;
+    }
+    if (c->h_mask_words < words) {
+        if (c->h_mask) HIP_TRY(hipHostFree(c->h_mask));
+        c->h_mask = nullptr;
+        c->h_mask_words = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_mask, (words ? words : 1) * sizeof(uint64_t), hipHostMallocDefault));
+        c->h_mask_words = words ? words : 1;
+    }
+    while (c->stage_ev.size() < (size_t)T * 2) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->stage_ev.push_back(e);
+    }
+    unsigned n_streams = 4;
+    if (const char* e = std::getenv("QMCP_HIP_COPY_STREAMS")) n_streams = (unsigned)std::strtoul(e, nullptr, 10);
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > 8) n_streams = 8;
+    while (c->stage_streams.size() < n_streams) {
+        hipStream_t st = nullptr;
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->stage_streams.push_back(st);
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->stage_done.push_back(e);
+    }
+    const clock::time_point t_copy = clock::now();
+    std::atomic<uint64_t> high_bits{0};
+    std::atomic<int> hip_failed{0};
+    auto worker = [&](unsigned t) {
+        if (hipSetDevice(c->device) != hipSuccess) { hip_failed = 1; return; }
+        uint64_t hi = 0;
+        unsigned use = 0;
+        hipStream_t cs = c->stage_streams[t % n_streams];
+        for (size_t k = t; k < n_chunks; k += T, ++use) {
+            const unsigned slot = use & 1u;
+            hipEvent_t ev = c->stage_ev[(size_t)t * 2 + slot];
+            if (use >= 2 && hipEventSynchronize(ev) != hipSuccess) { hip_failed = 1; return; }
+            uint32_t* ss = c->h_stage + ((size_t)t * 2 + slot) * 2 * kChunk;
+            uint32_t* ee = ss + kChunk;
+            const size_t lo = k * kChunk, cnt = (lo + kChunk <= n ? kChunk : n - lo);
+            const uint64_t* s64 = start_inds + lo;
+            const uint64_t* e64 = end_inds + lo;
+            for (size_t i = 0; i < cnt; ++i) {  // (branch-free: the range check is one OR per element)
+                const uint64_t a = s64[i], b = e64[i];
+                hi |= a | b;
+                ss[i] = (uint32_t)a;
+                ee[i] = (uint32_t)b;
+            }
+            if (hipMemcpyAsync((uint32_t*)c->in_starts.p + lo, ss, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
+                hipMemcpyAsync((uint32_t*)c->in_ends.p + lo, ee, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
+                hipEventRecord(ev, cs) != hipSuccess) { hip_failed = 1; return; }
+        }
+        high_bits.fetch_or(hi >> 32);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(worker, t);
+        worker(0);
+        for (auto& th : pool) th.join();
+    }
+    if (hip_failed.load()) return fail(QMCP_EHIP, "staging copy failed: %s", hipGetErrorString(hipGetLastError()));
+    if (high_bits.load() != 0) {
+        for (unsigned i = 0; i < n_streams; ++i) (void)hipStreamSynchronize(c->stage_streams[i]);
+        return fail(QMCP_ERANGE, "a read coordinate exceeds 2^32 - 1");
+    }
+    // the solve follows the copies: an event edge from every copy stream to the solver stream
+    for (unsigned i = 0; i < n_streams; ++i) {
+        HIP_TRY(hipEventRecord(c->stage_done[i], c->stage_streams[i]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->stage_done[i], 0));
+    }
+    for (unsigned i = 0; i < n_streams; ++i) HIP_TRY(hipStreamSynchronize(c->stage_streams[i]));  // (for the breakdown)
+    const float ms_copy = ms_since(t_copy);
+    const clock::time_point t_solve = clock::now();
+    TRY(solve_on_device(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, contig_read_offsets,
+                        contig_lengths, n_contigs, n_reads, max_coverage, (uint64_t*)c->mask.p, stats));
+    const float ms_solve = ms_since(t_solve);
+    const clock::time_point t_d2h = clock::now();
+    if (words) {
+        HIP_TRY(hipMemcpyAsync(c->h_mask, c->mask.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(keep_mask_out, c->h_mask, words * sizeof(uint64_t));
+    }
+    const float ms_d2h = ms_since(t_d2h);
+    if (stats) { stats->ms_h2d = ms_copy; stats->ms_d2h = ms_d2h; }
+    if (breakdown) {
+        breakdown->ms_total = ms_since(t_begin);
+        breakdown->ms_narrow_h2d = ms_copy;
+        breakdown->ms_solve = ms_solve;
+        breakdown->ms_d2h = ms_d2h;
+        breakdown->host_threads = T;
+        breakdown->chunks = (uint32_t)n_chunks;
+    }
+    return QMCP_OK;
 }
 
 int qmcp_hip_coverage_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends,

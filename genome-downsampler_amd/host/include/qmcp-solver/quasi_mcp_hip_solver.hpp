@@ -3,7 +3,7 @@
 // (libs/qmcp-solver/include/qmcp-solver/quasi_mcp_cuda_max_flow_solver.hpp:17-36):
 // same base class, same two overrides, uses_quality_of_reads() == false so the app selects
 // amplicon FILTER (src/app.cpp:121-127).  All device work goes through the C ABI in
-// include/qmcp_hip.h; this class only narrows the SoA columns and expands the keep mask.
+// include/qmcp_hip.h; this class only hands over the SoA columns and expands the keep mask.
 #ifndef QMCP_AMD_QUASI_MCP_HIP_SOLVER_HPP
 #define QMCP_AMD_QUASI_MCP_HIP_SOLVER_HPP
 
@@ -31,12 +31,18 @@ class QuasiMcpHipSolver : public Solver {
     // host with BamApi::find_pairs); off by default, like the reference solvers
     void set_complete_pairs(bool on) { complete_pairs_ = on; }
     const qmcp_hip_stats& last_stats() const { return stats_; }
+    // host wall-clock of the last solve(): the library's parts, the mask -> Solution expansion, the whole call
+    const qmcp_hip_host_breakdown& last_breakdown() const { return breakdown_; }
+    float last_expand_ms() const { return ms_expand_; }
+    float last_solve_call_ms() const { return ms_solve_call_; }
 
    private:
     qmcp_hip_ctx* ctx_ = nullptr;  // created on first solve, reused across solves
     int device_ = 0;
     bool complete_pairs_ = false;
     qmcp_hip_stats stats_{};
+    qmcp_hip_host_breakdown breakdown_{};
+    float ms_expand_ = 0.f, ms_solve_call_ = 0.f;
 };
 
 }  // namespace qmcp

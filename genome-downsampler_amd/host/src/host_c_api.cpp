@@ -1,6 +1,7 @@
 // C entry points of libqmcp_host.so for ctypes callers (tests, bench.py): the reads-gen
 // restatement and the C++ solver adapter driven exactly as the reference drives a solver
 // (SolverManager::get(name).solve(M, BamApi)).
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -153,6 +154,39 @@ std::int64_t qmcp_host_solve(const char* solver_name, const std::uint32_t* start
     std::vector<bam_api::ReadIndex> ids = with_pairs ? api.find_pairs(*solution) : *solution;
     for (std::size_t i = 0; i < ids.size(); ++i) kept_out[i] = ids[i];
     return static_cast<std::int64_t>(ids.size());
+}
+
+// The span the reference times as "solve took" (src/app.cpp:132-139) at the plugin boundary: a BamApi
+// that already holds the reads as SOAPairedReads (size_t columns) -> solver.solve(M, api) -> Solution.
+// Building the BamApi is outside the span, as parsing the BAM is in the reference.  `times` receives
+// {wall of solve(), library total, narrow + H2D, device solve, D2H, mask expansion, threads, chunks};
+// returns the number of kept reads (kept_out may be NULL), negative on an unknown solver.
+std::int64_t qmcp_host_plugin_solve_timed(const char* solver_name, const std::uint32_t* starts,
+                                          const std::uint32_t* ends, std::uint64_t n,
+                                          std::uint32_t ref_genome_length, std::uint32_t max_coverage,
+                                          std::uint64_t* kept_out, float* times) {
+    if (!manager().contains(solver_name)) return -1;
+    bam_api::SOAPairedReads soa;
+    soa.ref_genome_length = ref_genome_length;
+    soa.reserve(n);
+    for (std::uint64_t i = 0; i < n; ++i)
+        soa.push_back(bam_api::Read(i, starts[i], ends[i], 0, ends[i] - starts[i] + 1, i % 2 == 0));
+    bam_api::BamApi api(soa);
+    qmcp::Solver& solver = manager().get(solver_name);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto solution = solver.solve(max_coverage, api);
+    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (times) {
+        for (int i = 0; i < 8; ++i) times[i] = 0.f;
+        times[0] = wall;
+        if (auto* hip = dynamic_cast<qmcp::QuasiMcpHipSolver*>(&solver)) {
+            const qmcp_hip_host_breakdown& b = hip->last_breakdown();
+            times[1] = b.ms_total; times[2] = b.ms_narrow_h2d; times[3] = b.ms_solve; times[4] = b.ms_d2h;
+            times[5] = hip->last_expand_ms(); times[6] = (float)b.host_threads; times[7] = (float)b.chunks;
+        }
+    }
+    if (kept_out) for (std::size_t i = 0; i < solution->size(); ++i) kept_out[i] = (*solution)[i];
+    return static_cast<std::int64_t>(solution->size());
 }
 
 }  // extern "C"

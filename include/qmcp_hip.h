@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMCP_HIP_ABI_VERSION 1
+#define QMCP_HIP_ABI_VERSION 2
 
 enum {
     QMCP_OK = 0,
@@ -120,6 +120,29 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* ctx,
                         const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
                         uint32_t n_contigs, uint32_t max_coverage,
                         uint64_t* keep_mask_out, qmcp_hip_stats* stats);
+
+/* The same for callers that hold the reference's own columns: SOAPairedReads::start_inds / end_inds are
+ * std::vector<size_t> (libs/bam-api/include/bam-api/soa_paired_reads.hpp:19-24, read.hpp:11-13), i.e.
+ * 64-bit.  The narrowing to uint32 (the reference's CUDA solver narrows too:
+ * quasi_mcp_cuda_max_flow_solver.hpp:19) runs here, chunk by chunk on several host threads into pinned
+ * staging owned by the context, each chunk's host-to-device copy issued as soon as it is narrowed, so
+ * the span the reference times as "solve took" (src/app.cpp:132-139) is the PCIe transfer plus little.
+ * A coordinate above 2^32 - 1 fails with QMCP_ERANGE.  `breakdown` (may be NULL) receives host
+ * wall-clock milliseconds of the call's parts. */
+typedef struct qmcp_hip_host_breakdown {
+    float ms_total;        /* the whole call                                                        */
+    float ms_narrow_h2d;   /* narrowing + host-to-device copies (overlapped with each other)        */
+    float ms_solve;        /* enqueue to completion of the device solve                             */
+    float ms_d2h;          /* keep mask to the host                                                 */
+    uint32_t host_threads; /* threads that narrowed                                                 */
+    uint32_t chunks;
+} qmcp_hip_host_breakdown;
+int qmcp_hip_solve_host64(qmcp_hip_ctx* ctx,
+                          const uint64_t* start_inds, const uint64_t* end_inds, uint64_t n_reads,
+                          const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                          uint32_t n_contigs, uint32_t max_coverage,
+                          uint64_t* keep_mask_out, qmcp_hip_stats* stats,
+                          qmcp_hip_host_breakdown* breakdown);
 
 /* Same solve with reads and mask already resident in this context's device memory
  * (d_* are device pointers; contig tables stay on the host).  `hip_stream` is a

@@ -35,3 +35,16 @@ def test_cpp_adapter_matches_c_abi(pkg, oracle, solver):
     assert np.array_equal(m, oracle.find_pairs(oracle.solve(s, e, 5000, 40), s.size))
     with pytest.raises(KeyError):
         pkg.host_solve("quasi-mcp-cpu", s, e, 5000, 40)
+
+
+def test_plugin_boundary_from_size_t_columns(pkg, oracle):
+    """BamApi(SOAPairedReads) -> SolverManager -> QuasiMcpHipSolver::solve: the 64-bit columns are narrowed
+    inside the library (threads + pinned staging, qmcp_hip_solve_host64); same Solution as the oracle"""
+    import numpy as np
+    s, e = pkg.reads_gen(pkg.KIND_UNIFORM, 1_600_000, 300_000, seed=5)   # 3.2 M reads: 13 chunks of 256 Ki, several threads
+    kept, times = pkg.plugin_solve_timed("quasi-mcp-hip", s, e, 300_000, 100)
+    want = pkg.mask_to_indices(oracle.solve(s, e, 300_000, 100), s.size)
+    assert np.array_equal(kept, want)
+    assert times["chunks"] == 13 and 1 <= times["host_threads"] <= 13 and times["solve_call_ms"] >= times["library_ms"] > 0
+    kept1, _ = pkg.plugin_solve_timed("quasi-mcp-hip", s[:10], e[:10], 300_000, 3)   # a partial chunk
+    assert np.array_equal(kept1, pkg.mask_to_indices(oracle.solve(s[:10], e[:10], 300_000, 3), 10))
