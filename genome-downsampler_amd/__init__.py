@@ -24,7 +24,8 @@ ABI_SYMBOLS = (
     "qmcp_hip_filtered_coverage_host", "qmcp_hip_complete_pairs_device",
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
     "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
-    "qmcp_hip_solve_end", "qmcp_hip_demand_host", "qmcp_hip_solve_host64",
+    "qmcp_hip_solve_end", "qmcp_hip_demand_host", "qmcp_hip_solve_host64", "qmcp_hip_multi_create",
+    "qmcp_hip_multi_destroy", "qmcp_hip_multi_solve_host",
 )
 
 QMCP_OK = 0
@@ -74,6 +75,11 @@ _hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 _hip.qmcp_hip_solve_device_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 _hip.qmcp_hip_solve_end.argtypes = [C.c_void_p, C.POINTER(Stats)]
+_hip.qmcp_hip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+_hip.qmcp_hip_multi_destroy.argtypes = [C.c_void_p]
+_hip.qmcp_hip_multi_destroy.restype = None
+_hip.qmcp_hip_multi_solve_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p, C.c_uint32,
+                                           C.c_uint32, _u64p, C.POINTER(Stats), C.POINTER(C.c_int)]
 _hip.qmcp_hip_demand_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 _hip.qmcp_hip_coverage_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
@@ -318,6 +324,43 @@ class Solver:
 
 
 # ---------------------------------------------------------------- host mirror (libqmcp_host.so)
+class MultiSolver:
+    """several devices behind one call (qmcp_hip_multi_*): contigs dealt to the devices by cost, one
+    context and one host thread per entry of `devices` (a device may be named more than once)"""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self._m = C.c_void_p()
+        _check(_hip.qmcp_hip_multi_create(arr, len(self.devices), C.byref(self._m)))
+        self.last_stats = []
+        self.last_assignment = None
+
+    def close(self):
+        if getattr(self, "_m", None):
+            _hip.qmcp_hip_multi_destroy(self._m)
+            self._m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def solve(self, starts, ends, contig_lengths, max_coverage, contig_read_offsets=None):
+        starts, ends = _u32(starts), _u32(ends)
+        offs, lengths = _contig_tables(starts.size, contig_read_offsets, contig_lengths)
+        mask = np.zeros(mask_words(starts.size), dtype=np.uint64)
+        stats = (Stats * len(self.devices))()
+        where = (C.c_int * lengths.size)()
+        _check(_hip.qmcp_hip_multi_solve_host(self._m, _p32(starts), _p32(ends), starts.size, _p64(offs),
+                                              _p32(lengths), lengths.size, int(max_coverage), _p64(mask),
+                                              stats, where))
+        self.last_stats = list(stats)
+        self.last_assignment = list(where)
+        return mask
+
+
 def _need_host():
     if _host is None:
         raise ImportError(f"{HOST_LIB_PATH} is missing: build it with `make lib`")

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <vector>
 
 #include "qmcp-solver/solver.hpp"
 #include "qmcp_hip.h"
@@ -27,6 +28,11 @@ class QuasiMcpHipSolver : public Solver {
     bool uses_quality_of_reads() override { return false; }
 
     void set_device(int device);  // before the first solve; default 0
+    // devices for multi-contig callers of the C ABI's qmcp_hip_multi_* entry points; the reference's BamApi
+    // holds ONE contig (libs/bam-api/src/bam_api.cpp:422), which is one independent problem, so solve()
+    // below runs it on the first device of the list
+    void set_devices(const std::vector<int>& devices) { if (!devices.empty()) { devices_ = devices; device_ = devices[0]; } }
+    const std::vector<int>& devices() const { return devices_; }
     // complete mate pairs on the device before returning (what src/app.cpp:141 does on the
     // host with BamApi::find_pairs); off by default, like the reference solvers
     void set_complete_pairs(bool on) { complete_pairs_ = on; }
@@ -39,6 +45,7 @@ class QuasiMcpHipSolver : public Solver {
    private:
     qmcp_hip_ctx* ctx_ = nullptr;  // created on first solve, reused across solves
     int device_ = 0;
+    std::vector<int> devices_{0};
     bool complete_pairs_ = false;
     qmcp_hip_stats stats_{};
     qmcp_hip_host_breakdown breakdown_{};

@@ -169,6 +169,25 @@ int qmcp_hip_solve_device_begin(qmcp_hip_ctx* ctx,
                                 uint64_t* d_keep_mask_out, void* hip_stream);
 int qmcp_hip_solve_end(qmcp_hip_ctx* ctx, qmcp_hip_stats* stats);
 
+/* Several devices behind one call (the reference has no counterpart: src/solver_manager.hpp:18-27
+ * registers single-device solvers).  Contigs are independent problems (the reference is single-contig,
+ * libs/bam-api/src/bam_api.cpp:422), so they are dealt to the devices -- by a cost of reads plus the
+ * longest contig a device owns (its sweep chains run side by side), longest-processing-time first --
+ * and every device solves its share in its own context on its own host thread: no data-path exchange
+ * between devices.  The per-device keep masks are merged into global ReadIndex bit positions on the
+ * host (contig boundaries need not be multiples of 64).  `devices` may name a device more than once
+ * (separate contexts on it).  per_device_stats: n_devices entries or NULL; contig_device_out:
+ * n_contigs entries (index into `devices`) or NULL. */
+typedef struct qmcp_hip_multi qmcp_hip_multi;
+int qmcp_hip_multi_create(const int* devices, int n_devices, qmcp_hip_multi** out);
+void qmcp_hip_multi_destroy(qmcp_hip_multi* m);
+int qmcp_hip_multi_solve_host(qmcp_hip_multi* m,
+                              const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                              const uint64_t* contig_read_offsets, const uint32_t* contig_lengths,
+                              uint32_t n_contigs, uint32_t max_coverage,
+                              uint64_t* keep_mask_out, qmcp_hip_stats* per_device_stats,
+                              int* contig_device_out);
+
 /* Stage probe for parity tests of the deterministic half of the reference solver:
  * writes cov[p] for every base of every contig (contigs concatenated, sum(contig_lengths)
  * entries) -- the array BamApi::find_input_cover returns (libs/bam-api/src/bam_api.cpp:275-286)

@@ -86,3 +86,29 @@ def test_ranks_emulated_on_one_gpu(pkg, oracle, solver, world):
     # the assignment balances the modelled cost (reads + the longest chain of a rank)
     costs = [sh.rank_cost(counts, lengths, o) for o in owned]
     assert max(costs) <= 2.0 * (sum(sh.NS_PER_READ * c for c in counts) / world + sh.NS_PER_POSITION * int(lengths.max()))
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_multi_device_entry_with_contexts_on_one_device(pkg, oracle, solver, n_ctx):
+    """qmcp_hip_multi_solve_host with devices = {0, 0[, 0]}: one context and host thread per entry, contigs
+    dealt by cost, masks merged at bit positions that are not multiples of 64 == the one-device solve"""
+    sh = importlib.import_module("genome-downsampler_amd.sharding")
+    rng = np.random.default_rng(70 + n_ctx)
+    lengths = np.array([120_000, 7_000, 400_000, 300, 90_001, 55_555, 1_000_000], np.uint32)
+    counts = [200_001, 9_999, 700_003, 0, 150_007, 33_333, 1_250_001]      # odd counts: unaligned boundaries
+    ss = [rng.integers(0, int(L) - 150 + 1, size=c).astype(np.uint32) for L, c in zip(lengths, counts)]
+    s = np.concatenate(ss)
+    e = (s + np.uint32(149)).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    with pkg.MultiSolver([0] * n_ctx) as ms:
+        got = ms.solve(s, e, lengths, 25, contig_read_offsets=offs)
+        where = ms.last_assignment
+        kept = sum(int(st.n_kept) for st in ms.last_stats)
+        again = ms.solve(s, e, lengths, 25, contig_read_offsets=offs)
+    one = solver.solve(s, e, lengths, 25, contig_read_offsets=offs)
+    assert np.array_equal(got, one) and np.array_equal(again, one)
+    assert np.array_equal(one, oracle.solve(s, e, lengths, 25, contig_read_offsets=offs))
+    assert kept == int(np.unpackbits(one.view(np.uint8)).sum())
+    # the C side deals the contigs exactly as sharding.assign_contigs does
+    owned = sh.assign_contigs(counts, n_ctx, contig_lengths=lengths)
+    assert [where[c] for c in range(len(counts))] == [next(r for r, o in enumerate(owned) if c in o) for c in range(len(counts))]
