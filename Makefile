@@ -33,11 +33,11 @@ $(LIBDIR)/libqmcp_hip.so: $(LIBDIR)/qmcp_kernels.o $(LIBDIR)/qmcp_api.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
 
 HOST_SRCS := $(HOST)/src/bam_api.cpp $(HOST)/src/reads_gen.cpp $(HOST)/src/quasi_mcp_hip_solver.cpp \
-             $(HOST)/src/amplicon_set.cpp \
+             $(HOST)/src/amplicon_set.cpp $(HOST)/src/bam_io.cpp \
              $(HOST)/src/host_c_api.cpp
 $(LIBDIR)/libqmcp_host.so: $(HOST_SRCS) $(wildcard $(HOST)/include/*.hpp $(HOST)/include/*/*.hpp) \
                            $(LIBDIR)/libqmcp_hip.so include/qmcp_hip.h
-	$(CXX) $(CXXFLAGS) -shared $(HOST_SRCS) -L$(LIBDIR) -lqmcp_hip -Wl,-rpath,'$$ORIGIN' -o $@
+	$(CXX) $(CXXFLAGS) -shared $(HOST_SRCS) -L$(LIBDIR) -lqmcp_hip -lz -lpthread -Wl,-rpath,'$$ORIGIN' -o $@
 
 oracle: oracle/libqmcp_oracle.so
 oracle/libqmcp_oracle.so: oracle/qmcp_oracle.c oracle/qmcp_oracle.h

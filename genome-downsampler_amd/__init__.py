@@ -107,6 +107,16 @@ if _host is not None:
     _host.qmcp_host_plugin_solve_timed.argtypes = [C.c_char_p, _u32p, _u32p, C.c_uint64, C.c_uint32,
                                                    C.c_uint32, _u64p, C.POINTER(C.c_float)]
     _host.qmcp_host_plugin_solve_timed.restype = C.c_int64
+    _u16p, _u8p = C.POINTER(C.c_uint16), C.POINTER(C.c_uint8)
+    _host.qmcp_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, _u32p, _u16p, _u32p,
+                                                    _u8p, _u32p, _u32p, _u32p, _u32p]
+    _host.qmcp_host_read_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32,
+                                         C.c_uint64, _u64p, _u32p, _u32p, _u32p, _u32p, _u8p, C.c_uint64, _u64p,
+                                         _u64p, _u32p]
+    _host.qmcp_host_read_bam.restype = C.c_int64
+    _host.qmcp_host_downsample_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
+                                               C.c_uint32, C.c_uint32]
+    _host.qmcp_host_downsample_bam.restype = C.c_int64
     _host.qmcp_host_bamapi_probe.argtypes = [_u32p, _u32p, C.c_uint64, C.c_uint32, C.c_int, _u64p,
                                              C.c_uint64, _u32p, _u32p, _u64p]
     _host.qmcp_host_bamapi_probe.restype = C.c_int64
@@ -450,3 +460,52 @@ def plugin_solve_timed(solver_name, starts, ends, ref_genome_length, max_coverag
     out = {k: round(float(t[i]), 3) for i, k in enumerate(names)}
     out["host_threads"], out["chunks"] = int(t[6]), int(t[7])
     return kept[:n].copy(), out
+
+
+def write_synthetic_bam(path, ref_length, names, flags, pos, mapq, clip_front, match, deletion, match2):
+    """single-reference BAM whose record i has qname "q<names[i]>" and CIGAR <clip>S<match>M<del>D<match2>M
+    (zero-length parts left out); written by the in-repo BGZF writer (tests only)"""
+    _need_host()
+    n = len(names)
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    names, pos, clip_front, match, deletion, match2 = (a(x, np.uint32) for x in (names, pos, clip_front, match, deletion, match2))
+    flags, mapq = a(flags, np.uint16), a(mapq, np.uint8)
+    rc = _host.qmcp_host_write_synthetic_bam(str(path).encode(), int(ref_length), n, _p32(names),
+                                             flags.ctypes.data_as(C.POINTER(C.c_uint16)), _p32(pos),
+                                             mapq.ctypes.data_as(C.POINTER(C.c_uint8)), _p32(clip_front),
+                                             _p32(match), _p32(deletion), _p32(match2))
+    if rc != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def read_bam(path, bed=None, tsv=None, amplicon_mode=0, min_length=0, min_mapq=0, capacity=1 << 24):
+    """BamApi(path, config).get_paired_reads_soa() of the host mirror: dict of columns + filtered-out ids"""
+    _need_host()
+    ids = np.empty(capacity, np.uint64)
+    cols = {k: np.empty(capacity, np.uint32) for k in ("starts", "ends", "qualities", "seq_lengths")}
+    first = np.empty(capacity, np.uint8)
+    filt = np.empty(capacity, np.uint64)
+    nf, ref = C.c_uint64(0), C.c_uint32(0)
+    n = _host.qmcp_host_read_bam(str(path).encode(), str(bed).encode() if bed else None,
+                                 str(tsv).encode() if tsv else None, int(amplicon_mode), int(min_length),
+                                 int(min_mapq), capacity, _p64(ids), _p32(cols["starts"]), _p32(cols["ends"]),
+                                 _p32(cols["qualities"]), _p32(cols["seq_lengths"]),
+                                 first.ctypes.data_as(C.POINTER(C.c_uint8)), capacity, _p64(filt), C.byref(nf),
+                                 C.byref(ref))
+    if n < 0:
+        raise OSError(f"read_bam({path}) failed ({n})")
+    out = {k: v[:n].copy() for k, v in cols.items()}
+    out.update(bam_ids=ids[:n].copy(), is_first=first[:n].astype(bool), filtered_out=filt[:nf.value].copy(),
+               ref_genome_length=int(ref.value))
+    return out
+
+
+def downsample_bam(solver_name, in_path, out_path, max_coverage, filtered_path=None, min_length=0, min_mapq=0):
+    """BamApi(in) -> solve -> find_pairs -> write_paired_reads(out): App::execute's file-to-file flow"""
+    _need_host()
+    n = _host.qmcp_host_downsample_bam(solver_name.encode(), str(in_path).encode(), str(out_path).encode(),
+                                       str(filtered_path).encode() if filtered_path else None,
+                                       int(max_coverage), int(min_length), int(min_mapq))
+    if n < 0:
+        raise KeyError(solver_name)
+    return int(n)

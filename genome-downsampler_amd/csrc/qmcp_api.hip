@@ -786,8 +786,10 @@ int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d
     return solve_complete(c, st);
 }
 
-int use_device(qmcp_hip_ctx* c) {
+int use_device(qmcp_hip_ctx* c, bool may_be_pending = false) {
     if (!c) return fail(QMCP_EINVAL, "null context");
+    if (c->pending && !may_be_pending)
+        return fail(QMCP_EINVAL, "a solve is pending on this context (call qmcp_hip_solve_end first)");
     HIP_TRY(hipSetDevice(c->device));
     return QMCP_OK;
 }
@@ -973,7 +975,7 @@ int qmcp_hip_solve_device_begin(qmcp_hip_ctx* c, const uint32_t* d_starts, const
 }
 
 int qmcp_hip_solve_end(qmcp_hip_ctx* c, qmcp_hip_stats* stats) {
-    TRY(use_device(c));
+    TRY(use_device(c, true));
     return solve_complete(c, stats);
 }
 

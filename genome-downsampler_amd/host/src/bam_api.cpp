@@ -1,7 +1,56 @@
 // In-memory BamApi (see include/bam-api/bam_api.hpp for the reference lines mirrored).
 #include "bam-api/bam_api.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
+#include "bam-api/bam_io.hpp"
+
 namespace bam_api {
+
+// bam_api.cpp:32-43: filters from the config; amplicons only when a BED file is given
+BamApi::BamApi(const std::filesystem::path& input_filepath, const BamApiConfig& config)
+    : input_filepath_(input_filepath), min_seq_length_(config.min_seq_length), min_mapq_(config.min_mapq) {
+    if (!config.bed_filepath.empty()) {
+        if (!amplicon_set_from_files(config.bed_filepath, config.tsv_filepath, amplicon_set_)) {
+            std::fprintf(stderr, "[ERROR] could not open %s\n", config.bed_filepath.c_str());
+            std::exit(EXIT_FAILURE);  // the reference exits the process on an unreadable input
+        }
+        amplicon_behaviour_ = config.amplicon_behaviour;
+    }
+}
+
+void BamApi::read_bam_into(PairedReads& reads) {
+    BamFilters f;
+    f.min_seq_length = min_seq_length_;
+    f.min_mapq = min_mapq_;
+    f.amplicon_behaviour = amplicon_behaviour_;
+    f.amplicons = &amplicon_set_;
+    std::string err;
+    if (!read_bam(input_filepath_, f, reads, filtered_out_reads_, nullptr, &err)) {
+        std::fprintf(stderr, "[ERROR] %s\n", err.c_str());
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+std::uint32_t BamApi::write_paired_reads(const std::filesystem::path& output_filepath,
+                                         std::vector<ReadIndex>& active_ids) const {
+    const PairedReads& reads = get_paired_reads();
+    std::vector<BAMReadId> bam_ids;
+    bam_ids.reserve(active_ids.size());
+    for (ReadIndex id : active_ids) bam_ids.push_back(reads.get_read_by_index(id).bam_id);
+    std::string err;
+    const std::uint32_t n = write_bam(input_filepath_, output_filepath, bam_ids, &err);
+    if (n == UINT32_MAX) { std::fprintf(stderr, "[ERROR] %s\n", err.c_str()); std::exit(EXIT_FAILURE); }
+    return n;
+}
+
+std::uint32_t BamApi::write_bam_api_filtered_out_reads(const std::filesystem::path& output_filepath) {
+    std::string err;
+    const std::uint32_t n = write_bam(input_filepath_, output_filepath, filtered_out_reads_, &err);
+    if (n == UINT32_MAX) { std::fprintf(stderr, "[ERROR] %s\n", err.c_str()); std::exit(EXIT_FAILURE); }
+    return n;
+}
 
 BamApi::BamApi(const AOSPairedReads& paired_reads)
     : aos_paired_reads_(paired_reads), is_aos_loaded_(true) {}
@@ -13,7 +62,8 @@ BamApi::BamApi(const SOAPairedReads& paired_reads)
 // (bam_api.cpp:189-233); same here.
 const AOSPairedReads& BamApi::get_paired_reads_aos() {
     if (!is_aos_loaded_) {
-        aos_paired_reads_.from(soa_paired_reads_);
+        if (is_soa_loaded_ || input_filepath_.empty()) aos_paired_reads_.from(soa_paired_reads_);
+        else read_bam_into(aos_paired_reads_);
         is_aos_loaded_ = true;
     }
     return aos_paired_reads_;
@@ -21,7 +71,8 @@ const AOSPairedReads& BamApi::get_paired_reads_aos() {
 
 const SOAPairedReads& BamApi::get_paired_reads_soa() {
     if (!is_soa_loaded_) {
-        soa_paired_reads_.from(aos_paired_reads_);
+        if (is_aos_loaded_ || input_filepath_.empty()) soa_paired_reads_.from(aos_paired_reads_);
+        else read_bam_into(soa_paired_reads_);
         is_soa_loaded_ = true;
     }
     return soa_paired_reads_;

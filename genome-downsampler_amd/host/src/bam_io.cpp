@@ -1,0 +1,374 @@
+// BAM ingest / emit on zlib alone (see include/bam-api/bam_io.hpp for the reference lines mirrored).
+#include "bam-api/bam_io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace bam_api {
+namespace {
+
+constexpr std::size_t kBgzfMaxBlock = 0x10000;   // a BGZF block inflates to at most 64 KiB
+constexpr std::size_t kBgzfFill = 0xFF00;        // payload per written block (htslib's choice)
+
+std::uint16_t le16(const unsigned char* p) { return (std::uint16_t)(p[0] | (p[1] << 8)); }
+std::uint32_t le32(const unsigned char* p) {
+    return (std::uint32_t)p[0] | ((std::uint32_t)p[1] << 8) | ((std::uint32_t)p[2] << 16) | ((std::uint32_t)p[3] << 24);
+}
+void put16(std::vector<unsigned char>& v, std::uint16_t x) { v.push_back((unsigned char)(x & 0xFF)); v.push_back((unsigned char)(x >> 8)); }
+void put32(std::vector<unsigned char>& v, std::uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((unsigned char)((x >> (8 * i)) & 0xFF)); }
+
+bool set_err(std::string* err, const std::string& msg) {
+    if (err) *err = msg;
+    return false;
+}
+
+// Sequential reader of the uncompressed stream of a BGZF file: one gzip member (with the "BC" extra
+// subfield giving its size) at a time, raw inflate of its payload, CRC and length checked.
+class BgzfReader {
+   public:
+    ~BgzfReader() { if (f_) std::fclose(f_); }
+    bool open(const std::filesystem::path& p) {
+        f_ = std::fopen(p.c_str(), "rb");
+        return f_ != nullptr;
+    }
+    // reads exactly n bytes; false at a clean end of file before the first byte (eof() tells) or on error
+    bool read(void* dst, std::size_t n) {
+        unsigned char* out = static_cast<unsigned char*>(dst);
+        while (n != 0) {
+            if (pos_ == block_.size() && !next_block()) return false;
+            const std::size_t take = std::min(n, block_.size() - pos_);
+            std::memcpy(out, block_.data() + pos_, take);
+            pos_ += take; out += take; n -= take;
+        }
+        return true;
+    }
+    bool eof() const { return eof_; }
+    const std::string& error() const { return error_; }
+
+   private:
+    bool next_block() {
+        for (;;) {  // (empty blocks -- the end-of-file marker is one -- are skipped)
+            unsigned char hdr[12];
+            const std::size_t got = std::fread(hdr, 1, sizeof(hdr), f_);
+            if (got == 0) { eof_ = true; return false; }
+            if (got != sizeof(hdr) || hdr[0] != 0x1F || hdr[1] != 0x8B || hdr[2] != 8 || !(hdr[3] & 4)) {
+                error_ = "not a BGZF block (gzip header without an extra field)";
+                return false;
+            }
+            const std::uint16_t xlen = le16(hdr + 10);
+            std::vector<unsigned char> extra(xlen);
+            if (std::fread(extra.data(), 1, xlen, f_) != xlen) { error_ = "truncated BGZF header"; return false; }
+            std::uint32_t bsize = 0;
+            for (std::size_t o = 0; o + 4 <= extra.size();) {
+                const std::uint16_t slen = le16(extra.data() + o + 2);
+                if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) bsize = le16(extra.data() + o + 4) + 1u;
+                o += 4u + slen;
+            }
+            if (bsize < 12u + xlen + 8u) { error_ = "BGZF block without a BC size field"; return false; }
+            const std::size_t payload = bsize - 12u - xlen - 8u;
+            comp_.resize(payload + 8);
+            if (std::fread(comp_.data(), 1, comp_.size(), f_) != comp_.size()) { error_ = "truncated BGZF block"; return false; }
+            const std::uint32_t crc = le32(comp_.data() + payload), isize = le32(comp_.data() + payload + 4);
+            if (isize > kBgzfMaxBlock) { error_ = "BGZF block larger than 64 KiB"; return false; }
+            block_.resize(isize);
+            pos_ = 0;
+            if (isize != 0) {
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { error_ = "inflateInit2 failed"; return false; }
+                zs.next_in = comp_.data(); zs.avail_in = (uInt)payload;
+                zs.next_out = block_.data(); zs.avail_out = (uInt)isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { error_ = "BGZF block does not inflate to its stated size"; return false; }
+                if (crc32(crc32(0L, Z_NULL, 0), block_.data(), (uInt)isize) != crc) { error_ = "BGZF block checksum mismatch"; return false; }
+                return true;
+            }
+        }
+    }
+    std::FILE* f_ = nullptr;
+    std::vector<unsigned char> comp_, block_;
+    std::size_t pos_ = 0;
+    bool eof_ = false;
+    std::string error_;
+};
+
+class BgzfWriter {
+   public:
+    ~BgzfWriter() { if (f_) std::fclose(f_); }
+    bool open(const std::filesystem::path& p) {
+        f_ = std::fopen(p.c_str(), "wb");
+        return f_ != nullptr;
+    }
+    bool write(const void* src, std::size_t n) {
+        const unsigned char* in = static_cast<const unsigned char*>(src);
+        while (n != 0) {
+            const std::size_t take = std::min(n, kBgzfFill - buf_.size());
+            buf_.insert(buf_.end(), in, in + take);
+            in += take; n -= take;
+            if (buf_.size() == kBgzfFill && !flush_block()) return false;
+        }
+        return true;
+    }
+    bool close() {
+        if (!f_) return false;
+        bool ok = buf_.empty() || flush_block();
+        ok = ok && flush_block();  // the empty block that marks the end of a BGZF file
+        ok = (std::fclose(f_) == 0) && ok;
+        f_ = nullptr;
+        return ok;
+    }
+
+   private:
+    bool flush_block() {
+        std::vector<unsigned char> comp(compressBound((uLong)buf_.size()) + 64);
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
+        zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+        const int rc = deflate(&zs, Z_FINISH);
+        const std::size_t clen = comp.size() - zs.avail_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+        std::vector<unsigned char> out;
+        const unsigned char head[] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0};
+        out.insert(out.end(), head, head + sizeof(head));
+        put16(out, (std::uint16_t)(18 + clen + 8 - 1));  // BSIZE = total block size - 1
+        out.insert(out.end(), comp.begin(), comp.begin() + (std::ptrdiff_t)clen);
+        put32(out, (std::uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size()));
+        put32(out, (std::uint32_t)buf_.size());
+        buf_.clear();
+        return std::fwrite(out.data(), 1, out.size(), f_) == out.size();
+    }
+    std::FILE* f_ = nullptr;
+    std::vector<unsigned char> buf_;
+};
+
+// the BAM header (magic, text, reference names and lengths), kept verbatim for the copy in write_bam
+struct BamHeader {
+    std::vector<unsigned char> raw;
+    std::uint32_t n_ref = 0;
+    std::uint32_t first_ref_length = 0;
+};
+
+bool read_header(BgzfReader& in, BamHeader& h, std::string* err) {
+    unsigned char b[8];
+    if (!in.read(b, 8) || std::memcmp(b, "BAM\1", 4) != 0) return set_err(err, in.error().empty() ? "not a BAM file (magic)" : in.error());
+    h.raw.assign(b, b + 8);
+    const std::uint32_t l_text = le32(b + 4);
+    std::vector<unsigned char> text(l_text);
+    if (l_text && !in.read(text.data(), l_text)) return set_err(err, "truncated BAM header text");
+    h.raw.insert(h.raw.end(), text.begin(), text.end());
+    if (!in.read(b, 4)) return set_err(err, "truncated BAM header (n_ref)");
+    h.raw.insert(h.raw.end(), b, b + 4);
+    h.n_ref = le32(b);
+    for (std::uint32_t r = 0; r < h.n_ref; ++r) {
+        if (!in.read(b, 4)) return set_err(err, "truncated BAM reference list");
+        h.raw.insert(h.raw.end(), b, b + 4);
+        const std::uint32_t l_name = le32(b);
+        std::vector<unsigned char> name(l_name + 4);
+        if (!in.read(name.data(), name.size())) return set_err(err, "truncated BAM reference entry");
+        h.raw.insert(h.raw.end(), name.begin(), name.end());
+        if (r == 0) h.first_ref_length = le32(name.data() + l_name);
+    }
+    return true;
+}
+
+// one alignment record: block_size then the block; false at the end of the file (err stays empty) or on error
+bool read_record(BgzfReader& in, std::vector<unsigned char>& rec, std::string* err) {
+    unsigned char b[4];
+    if (!in.read(b, 4)) {
+        if (!in.eof()) set_err(err, in.error().empty() ? "truncated BAM record" : in.error());
+        return false;
+    }
+    const std::uint32_t block_size = le32(b);
+    if (block_size < 32) return set_err(err, "BAM record shorter than its fixed fields");
+    rec.resize(4 + block_size);
+    std::memcpy(rec.data(), b, 4);
+    if (!in.read(rec.data() + 4, block_size)) return set_err(err, in.error().empty() ? "truncated BAM record" : in.error());
+    return true;
+}
+
+// Read::Read(BAMReadId, bam1_t*), read.cpp:5-14: rlen = bases of the reference the CIGAR consumes (M D N = X)
+bool record_to_read(const std::vector<unsigned char>& rec, BAMReadId id, Read& out, std::string& qname) {
+    const unsigned char* p = rec.data() + 4;
+    const std::int32_t pos = (std::int32_t)le32(p + 4);
+    const std::uint32_t l_read_name = p[8];
+    const std::uint32_t mapq = p[9];
+    const std::uint32_t n_cigar = le16(p + 12);
+    const std::uint16_t flag = le16(p + 14);
+    const std::uint32_t l_seq = le32(p + 16);
+    if (32u + l_read_name + 4u * n_cigar > rec.size() - 4) return false;
+    qname.assign(reinterpret_cast<const char*>(p + 32), l_read_name ? l_read_name - 1 : 0);
+    std::uint64_t rlen = 0;
+    const unsigned char* cg = p + 32 + l_read_name;
+    for (std::uint32_t k = 0; k < n_cigar; ++k) {
+        const std::uint32_t v = le32(cg + 4 * k), op = v & 0xF, len = v >> 4;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += len;
+    }
+    out = Read(id, static_cast<Index>(pos), static_cast<Index>((std::int64_t)pos + (std::int64_t)rlen - 1), mapq,
+               l_seq, (flag & 0x40) != 0);
+    return true;
+}
+
+}  // namespace
+
+bool read_bam(const std::filesystem::path& path, const BamFilters& filters, PairedReads& out,
+              std::vector<BAMReadId>& filtered_out, BamIngestStats* stats, std::string* err) {
+    BgzfReader in;
+    if (!in.open(path)) return set_err(err, "could not open " + path.string());
+    BamHeader h;
+    if (!read_header(in, h, err)) return false;
+    if (h.n_ref == 0) return set_err(err, "BAM without a reference sequence");
+    out.ref_genome_length = h.first_ref_length;  // bam_api.cpp:422: single contig, target_len[0]
+
+    BamIngestStats st;
+    std::vector<bool> is_accepted, in_single_amplicon;
+    std::map<std::string, Read> read_map;
+    std::vector<unsigned char> rec;
+    std::string qname, rec_err;
+    BAMReadId id = 0;
+    const bool filter_amplicons = filters.amplicon_behaviour == AmpliconBehaviour::FILTER && filters.amplicons != nullptr;
+    const bool grade = filters.amplicon_behaviour == AmpliconBehaviour::GRADE && filters.amplicons != nullptr;
+    while (read_record(in, rec, &rec_err)) {
+        Read current(id, 0, 0, 0, 0, false);
+        if (!record_to_read(rec, id, current, qname)) return set_err(err, "BAM record with fields past its end");
+        is_accepted.push_back(false);
+        auto it = read_map.find(qname);
+        if (it != read_map.end()) {
+            // bam_api.cpp:434-461: the pair is appended when its second mate is met; r1 IS the map entry
+            Read& r1 = it->second;
+            Read& r2 = current;
+            bool drop = !(r1.quality >= filters.min_mapq && r2.quality >= filters.min_mapq) ||
+                        !(r1.seq_length >= filters.min_seq_length && r2.seq_length >= filters.min_seq_length);
+            if (filter_amplicons) drop = drop || !filters.amplicons->member_includes_both(r1, r2);
+            if (drop) { ++id; continue; }
+            if (grade) {
+                for (const Read* r : {&r1, &r2}) {
+                    st.min_imported_mapq = std::min(st.min_imported_mapq, (std::uint32_t)r->quality);
+                    st.max_imported_mapq = std::max(st.max_imported_mapq, (std::uint32_t)r->quality);
+                }
+                const bool single = filters.amplicons->member_includes_both(r1, r2);
+                in_single_amplicon.push_back(single);
+                in_single_amplicon.push_back(single);
+            }
+            if (r2.is_first_read) std::swap(r1, r2);   // (swaps the map entry too, as the reference does)
+            out.push_back(r1);
+            out.push_back(r2);
+            is_accepted[r1.bam_id] = true;
+            is_accepted[r2.bam_id] = true;
+        } else {
+            read_map.insert({qname, current});
+        }
+        ++id;
+    }
+    if (!rec_err.empty()) return set_err(err, rec_err);
+    filtered_out.clear();
+    for (BAMReadId b = 0; b < is_accepted.size(); ++b)
+        if (!is_accepted[b]) filtered_out.push_back(b);
+    if (grade && st.max_imported_mapq > 0 && st.min_imported_mapq < UINT32_MAX) {
+        // apply_amplicon_inclusion_grading, bam_api.cpp:334-349
+        for (ReadIndex i = 0; i < out.get_reads_count(); ++i) {
+            ReadQuality q = out.get_quality(i);
+            q -= st.min_imported_mapq;
+            if (in_single_amplicon[i]) q += st.max_imported_mapq - st.min_imported_mapq;
+            out.set_quality(i, q);
+        }
+    }
+    st.records = id;
+    st.imported = out.get_reads_count();
+    if (stats) *stats = st;
+    return true;
+}
+
+std::uint32_t write_bam(const std::filesystem::path& input, const std::filesystem::path& output,
+                        std::vector<BAMReadId>& bam_ids, std::string* err) {
+    BgzfReader in;
+    if (!in.open(input)) { set_err(err, "could not open " + input.string()); return UINT32_MAX; }
+    BamHeader h;
+    if (!read_header(in, h, err)) return UINT32_MAX;
+    BgzfWriter out;
+    if (!out.open(output)) { set_err(err, "could not open " + output.string()); return UINT32_MAX; }
+    if (!out.write(h.raw.data(), h.raw.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+    std::sort(bam_ids.begin(), bam_ids.end());   // bam_api.cpp:603
+    auto next = bam_ids.begin();
+    std::vector<unsigned char> rec;
+    std::string rec_err;
+    BAMReadId id = 0;
+    std::uint32_t written = 0;
+    while (next != bam_ids.end() && read_record(in, rec, &rec_err)) {
+        if (id == *next) {
+            if (!out.write(rec.data(), rec.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+            ++written;
+            ++next;
+        }
+        ++id;
+    }
+    if (!rec_err.empty()) { set_err(err, rec_err); return UINT32_MAX; }
+    if (!out.close()) { set_err(err, "closing " + output.string() + " failed"); return UINT32_MAX; }
+    return written;
+}
+
+bool write_synthetic_bam(const std::filesystem::path& path, const std::string& ref_name,
+                         std::uint32_t ref_length, const std::vector<BamRecordSpec>& records,
+                         std::string* err) {
+    BgzfWriter out;
+    if (!out.open(path)) return set_err(err, "could not open " + path.string());
+    std::vector<unsigned char> b;
+    const std::string text = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:" + ref_name + "\tLN:" + std::to_string(ref_length) + "\n";
+    b.insert(b.end(), {'B', 'A', 'M', 1});
+    put32(b, (std::uint32_t)text.size());
+    b.insert(b.end(), text.begin(), text.end());
+    put32(b, 1);
+    put32(b, (std::uint32_t)ref_name.size() + 1);
+    b.insert(b.end(), ref_name.begin(), ref_name.end());
+    b.push_back(0);
+    put32(b, ref_length);
+    if (!out.write(b.data(), b.size())) return set_err(err, "write failed");
+    const std::string ops = "MIDNSHP=X";
+    for (const BamRecordSpec& r : records) {
+        std::vector<unsigned char> blk;
+        std::uint64_t rlen = 0;
+        for (const auto& c : r.cigar)
+            if (c.second == 'M' || c.second == 'D' || c.second == 'N' || c.second == '=' || c.second == 'X') rlen += c.first;
+        // reg2bin of [pos, end): the bin field is not used on this path, but a reader may check it
+        std::uint32_t beg = (std::uint32_t)r.pos, end = (std::uint32_t)(r.pos + (rlen ? rlen : 1)) - 1, bin = 0;
+        if (beg >> 14 == end >> 14) bin = ((1u << 15) - 1) / 7 + (beg >> 14);
+        else if (beg >> 17 == end >> 17) bin = ((1u << 12) - 1) / 7 + (beg >> 17);
+        else if (beg >> 20 == end >> 20) bin = ((1u << 9) - 1) / 7 + (beg >> 20);
+        else if (beg >> 23 == end >> 23) bin = ((1u << 6) - 1) / 7 + (beg >> 23);
+        else if (beg >> 26 == end >> 26) bin = ((1u << 3) - 1) / 7 + (beg >> 26);
+        put32(blk, 0);                                  // refID
+        put32(blk, (std::uint32_t)r.pos);
+        blk.push_back((unsigned char)(r.qname.size() + 1));
+        blk.push_back(r.mapq);
+        put16(blk, (std::uint16_t)bin);
+        put16(blk, (std::uint16_t)r.cigar.size());
+        put16(blk, r.flag);
+        put32(blk, r.l_seq);
+        put32(blk, 0xFFFFFFFFu);                        // next_refID = -1
+        put32(blk, 0xFFFFFFFFu);                        // next_pos = -1
+        put32(blk, 0);                                  // tlen
+        blk.insert(blk.end(), r.qname.begin(), r.qname.end());
+        blk.push_back(0);
+        for (const auto& c : r.cigar) {
+            const std::size_t op = ops.find(c.second);
+            if (op == std::string::npos) return set_err(err, std::string("unknown CIGAR operation ") + c.second);
+            put32(blk, (c.first << 4) | (std::uint32_t)op);
+        }
+        blk.insert(blk.end(), (r.l_seq + 1) / 2, 0x11);  // sequence: 'A' nibbles
+        blk.insert(blk.end(), r.l_seq, 0xFF);            // qualities: absent
+        std::vector<unsigned char> sz;
+        put32(sz, (std::uint32_t)blk.size());
+        if (!out.write(sz.data(), 4) || !out.write(blk.data(), blk.size())) return set_err(err, "write failed");
+    }
+    if (!out.close()) return set_err(err, "closing " + path.string() + " failed");
+    return true;
+}
+
+}  // namespace bam_api

@@ -10,6 +10,7 @@
 
 #include "bam-api/amplicon_set.hpp"
 #include "bam-api/bam_api.hpp"
+#include "bam-api/bam_io.hpp"
 #include "reads_gen.hpp"
 #include "solver_manager.hpp"
 
@@ -154,6 +155,79 @@ std::int64_t qmcp_host_solve(const char* solver_name, const std::uint32_t* start
     std::vector<bam_api::ReadIndex> ids = with_pairs ? api.find_pairs(*solution) : *solution;
     for (std::size_t i = 0; i < ids.size(); ++i) kept_out[i] = ids[i];
     return static_cast<std::int64_t>(ids.size());
+}
+
+// ---- BAM ingest / emit (bam-api/bam_io.hpp) for ctypes callers
+// Writes a synthetic single-reference BAM: record i = {qname "q<names[i]>", flags[i], pos[i], mapq[i], CIGAR
+// "<clip_front[i]>S<match[i]>M<del[i]>D<match2[i]>M" with zero-length parts left out, l_seq = sum of S and M}.
+int qmcp_host_write_synthetic_bam(const char* path, std::uint32_t ref_length, std::uint64_t n,
+                                  const std::uint32_t* names, const std::uint16_t* flags,
+                                  const std::uint32_t* pos, const std::uint8_t* mapq,
+                                  const std::uint32_t* clip_front, const std::uint32_t* match,
+                                  const std::uint32_t* del, const std::uint32_t* match2) {
+    std::vector<bam_api::BamRecordSpec> recs(n);
+    for (std::uint64_t i = 0; i < n; ++i) {
+        bam_api::BamRecordSpec& r = recs[i];
+        r.qname = "q" + std::to_string(names[i]);
+        r.flag = flags[i];
+        r.pos = (std::int32_t)pos[i];
+        r.mapq = mapq[i];
+        if (clip_front[i]) r.cigar.push_back({clip_front[i], 'S'});
+        if (match[i]) r.cigar.push_back({match[i], 'M'});
+        if (del[i]) r.cigar.push_back({del[i], 'D'});
+        if (match2[i]) r.cigar.push_back({match2[i], 'M'});
+        r.l_seq = clip_front[i] + match[i] + match2[i];
+    }
+    std::string err;
+    return bam_api::write_synthetic_bam(path, "ref1", ref_length, recs, &err) ? 0 : -1;
+}
+
+// BamApi(path, config) -> get_paired_reads_soa(): columns out (capacity cap reads); returns the number of
+// imported reads, *n_filtered_out = size of get_filtered_out_reads() (ids into filtered_out, capacity cap_f),
+// *ref_len = ref_genome_length.  amplicon_mode: 0 IGNORE, 1 FILTER, 2 GRADE (bed/tsv may be NULL or "").
+std::int64_t qmcp_host_read_bam(const char* path, const char* bed, const char* tsv, int amplicon_mode,
+                                std::uint32_t min_len, std::uint32_t min_mapq, std::uint64_t cap,
+                                std::uint64_t* bam_ids, std::uint32_t* starts, std::uint32_t* ends,
+                                std::uint32_t* qualities, std::uint32_t* seq_lengths, std::uint8_t* is_first,
+                                std::uint64_t cap_f, std::uint64_t* filtered_out, std::uint64_t* n_filtered_out,
+                                std::uint32_t* ref_len) {
+    bam_api::BamApiConfig cfg;
+    if (bed && bed[0]) cfg.bed_filepath = bed;
+    if (tsv && tsv[0]) cfg.tsv_filepath = tsv;
+    cfg.min_seq_length = min_len;
+    cfg.min_mapq = min_mapq;
+    cfg.amplicon_behaviour = amplicon_mode == 1 ? bam_api::AmpliconBehaviour::FILTER
+                           : amplicon_mode == 2 ? bam_api::AmpliconBehaviour::GRADE : bam_api::AmpliconBehaviour::IGNORE;
+    bam_api::BamApi api(path, cfg);
+    const bam_api::SOAPairedReads& r = api.get_paired_reads_soa();
+    const std::uint64_t n = r.ids.size();
+    if (n > cap || api.get_filtered_out_reads().size() > cap_f) return -2;
+    for (std::uint64_t i = 0; i < n; ++i) {
+        bam_ids[i] = r.ids[i]; starts[i] = (std::uint32_t)r.start_inds[i]; ends[i] = (std::uint32_t)r.end_inds[i];
+        qualities[i] = r.qualities[i]; seq_lengths[i] = r.seq_lengths[i]; is_first[i] = r.is_first_reads[i] ? 1 : 0;
+    }
+    *n_filtered_out = api.get_filtered_out_reads().size();
+    for (std::size_t i = 0; i < api.get_filtered_out_reads().size(); ++i) filtered_out[i] = api.get_filtered_out_reads()[i];
+    *ref_len = (std::uint32_t)r.ref_genome_length;
+    return (std::int64_t)n;
+}
+
+// The file-to-file flow of App::execute (src/app.cpp:113-151) for one solver: BamApi(path) -> solve ->
+// find_pairs -> write_paired_reads(out) (+ write_bam_api_filtered_out_reads(filtered) if given).
+// Returns the number of records written to `out_path`, negative on an unknown solver.
+std::int64_t qmcp_host_downsample_bam(const char* solver_name, const char* in_path, const char* out_path,
+                                      const char* filtered_path, std::uint32_t max_coverage,
+                                      std::uint32_t min_len, std::uint32_t min_mapq) {
+    if (!manager().contains(solver_name)) return -1;
+    bam_api::BamApiConfig cfg;
+    cfg.min_seq_length = min_len;
+    cfg.min_mapq = min_mapq;
+    bam_api::BamApi api(in_path, cfg);
+    auto solution = manager().get(solver_name).solve(max_coverage, api);
+    std::vector<bam_api::ReadIndex> paired = api.find_pairs(*solution);
+    const std::uint32_t written = api.write_paired_reads(out_path, paired);
+    if (filtered_path && filtered_path[0]) api.write_bam_api_filtered_out_reads(filtered_path);
+    return written;
 }
 
 // The span the reference times as "solve took" (src/app.cpp:132-139) at the plugin boundary: a BamApi

@@ -1,0 +1,118 @@
+"""BAM ingest / emit of the host mirror: read_bam's qname-map pairing and
+filters (libs/bam-api/src/bam_api.cpp:359-507), end = pos + CIGAR reference length - 1 (read.cpp:11-13),
+write_bam's second pass (bam_api.cpp:534-656).  The reference holds no BAM fixture and HTSlib is absent here,
+so the in-repo reader / writer (zlib) are checked against an independent Python reading of the same files
+(tests/bam_py.py) and against a Python restatement of the pairing rules: parity unpinned, self-consistent."""
+import importlib
+
+import numpy as np
+import pytest
+
+import bam_py
+
+
+def _synthetic(tmp_path, n_pairs=4000, L=20_000, seed=3, triples=True):
+    pkg = importlib.import_module("genome-downsampler_amd")
+    rng = np.random.default_rng(seed)
+    n = 2 * n_pairs
+    names = np.repeat(np.arange(n_pairs), 2)
+    first = np.tile([True, False], n_pairs)
+    flags = np.where(first, 0x41, 0x81).astype(np.uint16)          # paired + first / last in pair
+    match = rng.integers(60, 151, size=n)
+    clip = np.where(rng.random(n) < 0.15, rng.integers(1, 30, size=n), 0)
+    dele = np.where(rng.random(n) < 0.10, rng.integers(1, 12, size=n), 0)
+    match2 = np.where(dele > 0, rng.integers(5, 40, size=n), 0)
+    pos = rng.integers(0, L - 250, size=n)
+    mapq = rng.integers(0, 61, size=n)
+    order = rng.permutation(n)                                      # mates are NOT adjacent in the file
+    # quirks: some second mates come first in the file, a few names occur once or three times
+    cols = [a[order] for a in (names, flags, pos, mapq, clip, match, dele, match2)]
+    extra = 40
+    # (a name that occurs three times imports its first record twice; write_bam, given an id twice, stops
+    # matching after it -- bam_api.cpp:605-616 -- so the file-to-file test leaves such names out)
+    again = rng.integers(0, n_pairs, size=extra // 2) if triples else n_pairs + extra + np.arange(extra // 2)
+    cols[0] = np.concatenate([cols[0], again, n_pairs + np.arange(extra // 2)])
+    for k in range(1, 8):
+        cols[k] = np.concatenate([cols[k], cols[k][:extra]])
+    path = tmp_path / "in.bam"
+    pkg.write_synthetic_bam(path, L, *cols)
+    return pkg, path, L
+
+
+def test_reader_matches_an_independent_parse_and_the_pairing_rules(tmp_path):
+    pkg, path, L = _synthetic(tmp_path)
+    header, recs, ref_lengths = bam_py.parse(path)
+    assert ref_lengths == [L] and len(recs) == 8040
+    got = pkg.read_bam(path)
+    want, filtered = bam_py.pair_like_the_reference(recs)
+    assert got["ref_genome_length"] == L
+    assert got["bam_ids"].tolist() == [r["bam_id"] for r in want]
+    assert got["starts"].tolist() == [r["start"] for r in want]
+    assert got["ends"].tolist() == [r["end"] for r in want]           # pos + M/D/N/=/X lengths - 1
+    assert got["qualities"].tolist() == [r["q"] for r in want]
+    assert got["seq_lengths"].tolist() == [r["l"] for r in want]
+    assert got["is_first"].tolist() == [r["first"] for r in want]
+    assert got["filtered_out"].tolist() == filtered and len(filtered) > 0
+    # bam_api.cpp:481 asserts imported + filtered == records; a name that occurs three times pairs its first
+    # record twice (the map entry is never erased), so the identity holds on distinct ids only
+    assert len({r["bam_id"] for r in want}) + len(filtered) == len(recs)
+    # the reference's defaults -l 90 -q 30 (src/app.hpp:22-25)
+    got = pkg.read_bam(path, min_length=90, min_mapq=30)
+    want, filtered = bam_py.pair_like_the_reference(recs, min_len=90, min_mapq=30)
+    assert got["bam_ids"].tolist() == [r["bam_id"] for r in want] and got["filtered_out"].tolist() == filtered
+
+
+def test_amplicon_filter_and_grade_while_ingesting(tmp_path):
+    pkg, path, L = _synthetic(tmp_path, n_pairs=1500, seed=9)
+    bed = tmp_path / "p.bed"
+    bed.write_text("".join(f"ref1\t{a}\t{a + 20}\tA{k}_LEFT\nref1\t{a + 900}\t{a + 920}\tA{k}_RIGHT\n"
+                           for k, a in enumerate(range(0, L - 1000, 700))))
+    tsv = tmp_path / "p.tsv"
+    tsv.write_text("".join(f"A{k}_LEFT\tA{k}_RIGHT\n" for k, _ in enumerate(range(0, L - 1000, 700))))
+    a0, a1 = pkg.amplicons_from_files(bed, tsv)
+    _, recs, _ = bam_py.parse(path)
+    inside = lambda r1, r2: any(lo <= r1["start"] and r1["end"] <= hi and lo <= r2["start"] and r2["end"] <= hi
+                                for lo, hi in zip(a0.tolist(), a1.tolist()))
+    got = pkg.read_bam(path, bed=bed, tsv=tsv, amplicon_mode=1)       # FILTER (bam_api.cpp:311-319)
+    want, filtered = bam_py.pair_like_the_reference(recs, inside=inside)
+    assert got["bam_ids"].tolist() == [r["bam_id"] for r in want] and got["filtered_out"].tolist() == filtered
+    assert 0 < len(want) < len(recs) - 100
+    # GRADE (bam_api.cpp:334-357): quality - min + (max - min if the pair sits in one amplicon)
+    got = pkg.read_bam(path, bed=bed, tsv=tsv, amplicon_mode=2)
+    want, _ = bam_py.pair_like_the_reference(recs)
+    qs = [r["q"] for r in want]
+    lo, hi = min(qs), max(qs)
+    grades = [q - lo + ((hi - lo) if inside(want[i - i % 2], want[i - i % 2 + 1]) else 0) for i, q in enumerate(qs)]
+    assert got["qualities"].tolist() == grades
+
+
+def test_bgzf_layer_of_the_writer_reads_back_with_pythons_gzip(tmp_path):
+    pkg, path, L = _synthetic(tmp_path, n_pairs=2500, seed=4)
+    header, recs, _ = bam_py.parse(path)
+    assert header.startswith(b"BAM\x01") and b"@SQ\tSN:ref1" in header
+    # round trip of the BGZF layer: the file the in-repo writer produced inflates (by Python's gzip) to
+    # records that re-parse to the inputs -- and ends with the 28-byte BGZF end-of-file block
+    raw = open(path, "rb").read()
+    assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert sum(len(r["raw"]) for r in recs) + len(header) == len(__import__("gzip").decompress(raw))
+
+
+@pytest.mark.gpu
+def test_file_to_file_downsampling(tmp_path):
+    """App::execute's flow on files (src/app.cpp:113-151): BamApi(in.bam) -> quasi-mcp-hip -> find_pairs ->
+    write_paired_reads(out.bam); the output holds exactly the records of the oracle's kept pairs, in file
+    order, and the header, byte for byte"""
+    import oracle_py
+    pkg, path, L = _synthetic(tmp_path, n_pairs=6000, L=5_000, seed=12, triples=False)
+    header, recs, _ = bam_py.parse(path)
+    reads = pkg.read_bam(path)
+    M = 40
+    out, filt = tmp_path / "out.bam", tmp_path / "filtered.bam"
+    written = pkg.downsample_bam("quasi-mcp-hip", path, out, M, filtered_path=filt)
+    mask = oracle_py.find_pairs(oracle_py.solve(reads["starts"], reads["ends"], L, M), reads["starts"].size)
+    kept_ids = np.sort(reads["bam_ids"][pkg.mask_to_indices(mask, reads["starts"].size).astype(np.int64)])
+    oh, orecs, _ = bam_py.parse(out)
+    assert written == kept_ids.size == len(orecs) and oh == header
+    assert [r["raw"] for r in orecs] == [recs[i]["raw"] for i in kept_ids.tolist()]
+    _, frecs, _ = bam_py.parse(filt)
+    assert [r["raw"] for r in frecs] == [recs[i]["raw"] for i in reads["filtered_out"].tolist()]

@@ -46,3 +46,30 @@ def test_error_paths_leave_context_usable(pkg, solver):
     # (spans beyond the LDS rings are fine: rings in global memory)
     assert pkg.mask_to_indices(solver.solve([0, 5], [20000, 6], 30000, 1), 2).tolist() == [0]
     assert solver.solve([0, 5], [9, 6], 10, 1).size == 1
+
+
+def test_two_phase_entry_and_two_contexts_in_flight(pkg, oracle):
+    """qmcp_hip_solve_device_begin / _end: one pending solve per context, every other entry point of the
+    context refused meanwhile; two contexts keep two solves in flight and agree with the blocking call"""
+    import torch
+    s, e = pkg.reads_gen(pkg.KIND_UNIFORM, 400_000, 60_000, seed=77)
+    d_s = torch.from_numpy(s.view(np.int32)).cuda()
+    d_e = torch.from_numpy(e.view(np.int32)).cuda()
+    words = pkg.mask_words(s.size)
+    masks = [torch.zeros(words, dtype=torch.int64, device="cuda") for _ in range(2)]
+    want = oracle.solve(s, e, 60_000, 50)
+    with pkg.Solver(0) as a, pkg.Solver(0) as b:
+        a.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, 60_000, 50, masks[0].data_ptr())
+        b.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, 60_000, 50, masks[1].data_ptr())
+        with pytest.raises(pkg.QmcpError):       # a second begin on a busy context
+            a.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, 60_000, 50, masks[0].data_ptr())
+        with pytest.raises(pkg.QmcpError):       # ... and any other entry point of it
+            a.coverage(s, e, 60_000)
+        st_a, st_b = a.solve_end(), b.solve_end()
+        with pytest.raises(pkg.QmcpError):       # nothing pending any more
+            a.solve_end()
+        assert st_a.n_kept == st_b.n_kept == int(np.unpackbits(want.view(np.uint8)).sum())
+        for m in masks:
+            assert np.array_equal(m.cpu().numpy().view(np.uint64), want)
+        # the context is usable again
+        assert np.array_equal(a.solve(s, e, 60_000, 50), want)
