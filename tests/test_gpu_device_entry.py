@@ -73,3 +73,43 @@ def test_two_phase_entry_and_two_contexts_in_flight(pkg, oracle):
             assert np.array_equal(m.cpu().numpy().view(np.uint64), want)
         # the context is usable again
         assert np.array_equal(a.solve(s, e, 60_000, 50), want)
+
+
+def test_two_phase_entry_over_batches_of_one_shape_and_different_content(pkg, oracle):
+    """same-shaped batches back to back through _begin / _end on one context: another read length, mixed
+    lengths, an invalid read -- nothing of an earlier batch may leak into a later one (assuming the previous
+    batch's span statistics instead of waiting for them was tried: it un-staggers two pipelined solves and
+    costs 12 %)"""
+    import torch
+    n, L = 400_000, 50_000
+    rng = np.random.default_rng(31)
+
+    def batch(span_lo, span_hi):
+        span = rng.integers(span_lo, span_hi + 1, size=n)
+        s = (rng.random(n) * (L - span + 1)).astype(np.int64)
+        return s.astype(np.uint32), (s + span - 1).astype(np.uint32)
+
+    batches = [batch(150, 150), batch(150, 150), batch(100, 100), batch(100, 100), batch(90, 140), batch(150, 150)]
+    words = pkg.mask_words(n)
+    d_mask = torch.zeros(words, dtype=torch.int64, device="cuda")
+    with pkg.Solver(0) as sv:
+        for k, (s, e) in enumerate(batches):
+            d_s = torch.from_numpy(s.view(np.int32)).cuda()
+            d_e = torch.from_numpy(e.view(np.int32)).cuda()
+            sv.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), n, L, 20, d_mask.data_ptr())
+            st = sv.solve_end()
+            want = oracle.solve(s, e, L, 20)
+            assert np.array_equal(d_mask.cpu().numpy().view(np.uint64), want), k
+            assert st.min_span == int((e - s + 1).min()) and st.max_span == int((e - s + 1).max())
+        # same shape again, but one read now ends past the contig
+        s, e = batches[-1]
+        e = e.copy()
+        e[12345] = L + 7
+        d_s = torch.from_numpy(s.view(np.int32)).cuda()
+        d_e = torch.from_numpy(e.view(np.int32)).cuda()
+        with pytest.raises(pkg.QmcpError):
+            sv.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), n, L, 20, d_mask.data_ptr())
+            sv.solve_end()
+        # and the context still works
+        s, e = batches[0]
+        assert np.array_equal(sv.solve(s, e, L, 20), oracle.solve(s, e, L, 20))
