@@ -31,7 +31,23 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
-                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt) {
+                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt, uint32_t ecnt_len) {
+    // small genomes (the end counts fit a workgroup's LDS) with many reads per position: count in LDS
+    constexpr uint32_t kLdsBins = 36u * 1024;
+    if (ecnt != nullptr && ecnt_len != 0 && ecnt_len <= kLdsBins && n >= 16u * ecnt_len) {
+        const size_t lds = (size_t)ecnt_len * sizeof(uint32_t);
+        const uint32_t grid = 256;
+        if (wide) {
+            (void)hipFuncSetAttribute((const void*)k_general_keys_lds<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_general_keys_lds<uint64_t>, dim3(grid), dim3(1024), lds, st, gstart, starts, ends, n,
+                               span_bits, max_span, keep_mask, (uint64_t*)keys, ecnt, ecnt_len);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k_general_keys_lds<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_general_keys_lds<uint32_t>, dim3(grid), dim3(1024), lds, st, gstart, starts, ends, n,
+                               span_bits, max_span, keep_mask, (uint32_t*)keys, ecnt, ecnt_len);
+        }
+        return;
+    }
     if (wide)
         hipLaunchKernelGGL(k_general_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, gstart,
                            starts, ends, n, span_bits, max_span, keep_mask, (uint64_t*)keys, ecnt);

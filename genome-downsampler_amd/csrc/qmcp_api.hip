@@ -544,7 +544,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         {
             KernelSpan sp(c, "k_general_keys");
             qmcp::launch_general_keys(c->stream, wide, d_gstart, d_starts, d_ends, n, span_bits,
-                                      max_span, nullptr, key_dst, (uint32_t*)c->ecnt.p);
+                                      max_span, nullptr, key_dst, (uint32_t*)c->ecnt.p, ltot + 1);
         }
         HIP_TRY(hipGetLastError());
         TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
@@ -842,7 +842,7 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, ((size_t)ltot + 1) * sizeof(uint32_t), c->stream));
     qmcp::launch_general_keys(c->stream, false, (const uint32_t*)c->vals[1].p,
                               (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, n, 0,
-                              hs[1], d_keep, nullptr, (uint32_t*)c->ecnt.p);
+                              hs[1], d_keep, nullptr, (uint32_t*)c->ecnt.p, ltot + 1);
     HIP_TRY(hipGetLastError());
     TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
     TRY(ensure(c, c->cov, (size_t)ltot * sizeof(uint32_t)));

@@ -23,7 +23,8 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     unsigned long long* zero_mask /* keep mask to clear (ceil(n/64) words), or null */);
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
-                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt);
+                         const uint64_t* keep_mask, void* keys, uint32_t* ecnt,
+                         uint32_t ecnt_len /* entries of ecnt (positions + 1), 0: unknown */);
 uint32_t scan_spine_entries(uint32_t n);
 void launch_exclusive_scan(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out,
                            uint32_t* spine, bool write_total);

@@ -127,3 +127,24 @@ def test_filter_solve_pipeline_matches_composed_oracle(pkg, oracle, solver, pair
     assert dropped == s.size // 2 and not got.any()
     with pytest.raises(pkg.QmcpError):
         solver.filter_solve(s[:-1], e[:-1], 29_903, 50)
+
+
+def test_cfg3_shape_with_a_clipped_tail_takes_the_mixed_span_route(pkg, oracle, solver):
+    """what a real amplicon BAM looks like: 85 % of the reads at the modal length, the rest soft-clipped
+    shorter (read.cpp:11-13: the span is the CIGAR's reference length).  One different length sends the call
+    to the mixed-span event sweep; same contract: bit-identical to the oracle (tie-break: end desc, start
+    desc, index asc -- DESIGN.md section 2)"""
+    n_pairs = 1_500_000
+    s, e, a0, a1, _ = workloads.amplicon_reads(n_pairs, seed=77, straddle_fraction=0.0)
+    rng = np.random.default_rng(6)
+    clipped = rng.random(s.size) < 0.15
+    cut = rng.integers(1, 51, size=s.size)
+    front = rng.random(s.size) < 0.5
+    s2 = np.where(clipped & front, s + cut, s).astype(np.uint32)
+    e2 = np.where(clipped & ~front, e - cut, e).astype(np.uint32)
+    got = solver.solve(s2, e2, 29_903, 200)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_GENERAL and st.min_span == 100 and st.max_span == 150
+    assert np.array_equal(got, oracle.solve(s2, e2, 29_903, 200))
+    ok, _ = oracle.check_flow(s2, e2, 29_903, 200, got)
+    assert ok
