@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "qmcp_hip_complete_pairs_host", "qmcp_hip_amplicon_filter_host", "qmcp_hip_set_profiling",
     "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
     "qmcp_hip_solve_end", "qmcp_hip_demand_host", "qmcp_hip_solve_host64", "qmcp_hip_multi_create",
-    "qmcp_hip_multi_destroy", "qmcp_hip_multi_solve_host",
+    "qmcp_hip_multi_destroy", "qmcp_hip_multi_solve_host", "qmcp_hip_kept_indices_host",
 )
 
 QMCP_OK = 0

@@ -554,6 +554,10 @@ void launch_word_popcounts(hipStream_t st, const uint64_t* words, uint32_t n_wor
     hipLaunchKernelGGL(k_word_popcounts, dim3(grid_for(n_words, 256)), dim3(256), 0, st, words, n_words,
                        counts);
 }
+void launch_mask_to_indices(hipStream_t st, const uint64_t* mask, uint32_t n_words, const uint32_t* word_base,
+                            unsigned long long* out) {
+    hipLaunchKernelGGL(k_mask_to_indices, dim3(grid_for(n_words, 256)), dim3(256), 0, st, mask, n_words, word_base, out);
+}
 void launch_compact_pairs(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
                           const uint64_t* pair_keep, const uint32_t* word_base, uint64_t n_pairs,
                           uint32_t* starts_c, uint32_t* ends_c, uint32_t* orig_pair) {

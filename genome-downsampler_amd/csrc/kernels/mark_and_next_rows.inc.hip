@@ -130,6 +130,22 @@ __global__ __launch_bounds__(256) void k_word_popcounts(const uint64_t* __restri
         counts[w] = __popcll(words[w]);
 }
 
+// keep mask -> ascending ReadIndex list (what obtain_sequence returns, quasi_mcp_cpu_max_flow_solver.cpp:89-100):
+// word w writes its set bits from word_base[w] on (exclusive scan of the words' popcounts)
+__global__ __launch_bounds__(256) void k_mask_to_indices(const uint64_t* __restrict__ mask, uint32_t n_words,
+                                                         const uint32_t* __restrict__ word_base,
+                                                         unsigned long long* __restrict__ out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        uint64_t bits = mask[w];
+        uint32_t dst = word_base[w];
+        while (bits != 0) {
+            out[dst++] = (unsigned long long)w * 64ull + (unsigned long long)(__ffsll((long long)bits) - 1);
+            bits &= bits - 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_compact_pairs(const uint32_t* __restrict__ starts,
                                                        const uint32_t* __restrict__ ends,
                                                        const uint64_t* __restrict__ pair_keep,

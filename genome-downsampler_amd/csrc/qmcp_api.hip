@@ -86,6 +86,8 @@ struct qmcp_hip_ctx {
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
     DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
+    DevBuf kidx;          // qmcp_hip_kept_indices_host: the expanded index list
+    uint64_t mask_reads = 0;  // reads the context's own mask buffer (c->mask) currently describes
     DevBuf evpk, evlast;  // event-driven uniform sweep: packed block words, last-changed-block index per block
     uint32_t last_iters = 0, last_blocks = 0;
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
@@ -839,6 +841,7 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     if (keep_mask) {
         const size_t words = (size_t)((n64 + 63) / 64);
         TRY(ensure(c, c->mask, words * 8));
+        c->mask_reads = n64;
         HIP_TRY(hipMemcpyAsync(c->mask.p, keep_mask, words * 8, hipMemcpyHostToDevice, c->stream));
         d_keep = (const uint64_t*)c->mask.p;
     }
@@ -920,7 +923,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -1014,10 +1017,12 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
             }
         }
         (void)hipEventRecord(t1, c->stream);
+        c->mask_reads = 0;
         rc = solve_on_device(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p,
                              contig_read_offsets, contig_lengths, n_contigs, n_reads, max_coverage,
                              (uint64_t*)c->mask.p, stats);
         if (rc != QMCP_OK) break;
+        c->mask_reads = n_reads;
         (void)hipEventRecord(t2, c->stream);
         if (words) {
             if (hipMemcpyAsync(keep_mask_out, c->mask.p, words * sizeof(uint64_t),
@@ -1047,8 +1052,9 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
     const clock::time_point t_begin = clock::now();
     TRY(use_device(c));
     if (c->pending) return fail(QMCP_EINVAL, "a solve is pending on this context (call qmcp_hip_solve_end)");
-    if (n_reads && (!start_inds || !end_inds || !keep_mask_out)) return fail(QMCP_EINVAL, "null buffer");
+    if (n_reads && (!start_inds || !end_inds)) return fail(QMCP_EINVAL, "null buffer");
     if (n_reads > (1ull << 30)) return fail(QMCP_ERANGE, "n_reads exceeds 2^30 per call");
+    c->mask_reads = 0;
     const size_t n = (size_t)n_reads;
     const size_t words = (n + 63) / 64;
     TRY(ensure(c, c->in_starts, n * sizeof(uint32_t)));
@@ -1148,8 +1154,9 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
     TRY(solve_on_device(c, (const uint32_t*)c->in_starts.p, (const uint32_t*)c->in_ends.p, contig_read_offsets,
                         contig_lengths, n_contigs, n_reads, max_coverage, (uint64_t*)c->mask.p, stats));
     const float ms_solve = ms_since(t_solve);
+    c->mask_reads = n_reads;
     const clock::time_point t_d2h = clock::now();
-    if (words) {
+    if (words && keep_mask_out) {  // (NULL: the caller will ask for qmcp_hip_kept_indices_host instead)
         HIP_TRY(hipMemcpyAsync(c->h_mask, c->mask.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::memcpy(keep_mask_out, c->h_mask, words * sizeof(uint64_t));
@@ -1164,6 +1171,38 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
         breakdown->host_threads = T;
         breakdown->chunks = (uint32_t)n_chunks;
     }
+    return QMCP_OK;
+}
+
+int qmcp_hip_kept_indices_host(qmcp_hip_ctx* c, uint64_t n_reads, uint64_t* indices_out, uint64_t capacity,
+                               uint64_t* n_out) {
+    TRY(use_device(c));
+    if (!n_out) return fail(QMCP_EINVAL, "null n_out");
+    *n_out = 0;
+    if (n_reads == 0) return QMCP_OK;
+    if (c->mask_reads != n_reads || !c->mask.p)
+        return fail(QMCP_EINVAL, "the context holds no keep mask of %llu reads (call a host solve first)",
+                    (unsigned long long)n_reads);
+    const uint32_t words = (uint32_t)((n_reads + 63) / 64);
+    TRY(ensure(c, c->f_words, ((size_t)words + 2) * sizeof(uint32_t)));
+    TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries(words + 1) + 1) * sizeof(uint32_t) + 16));
+    qmcp::launch_word_popcounts(c->stream, (const uint64_t*)c->mask.p, words, (uint32_t*)c->f_words.p);
+    qmcp::launch_exclusive_scan(c->stream, (const uint32_t*)c->f_words.p, words, (uint32_t*)c->f_words.p,
+                                (uint32_t*)c->spine.p, true);
+    HIP_TRY(hipGetLastError());
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, (uint32_t*)c->f_words.p + words, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_out = total;
+    if (total == 0) return QMCP_OK;
+    if (!indices_out || capacity < total) return fail(QMCP_EINVAL, "indices_out holds %llu entries, %u are kept",
+                                                      (unsigned long long)capacity, total);
+    TRY(ensure(c, c->kidx, (size_t)total * sizeof(uint64_t)));
+    qmcp::launch_mask_to_indices(c->stream, (const uint64_t*)c->mask.p, words, (const uint32_t*)c->f_words.p,
+                                 (unsigned long long*)c->kidx.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(indices_out, c->kidx.p, (size_t)total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return QMCP_OK;
 }
 
@@ -1222,6 +1261,7 @@ int qmcp_hip_complete_pairs_host(qmcp_hip_ctx* c, uint64_t* keep_mask, uint64_t 
     if (words == 0) return QMCP_OK;
     if (!keep_mask) return fail(QMCP_EINVAL, "null mask");
     TRY(ensure(c, c->mask, words * 8));
+    c->mask_reads = n_reads;
     HIP_TRY(hipMemcpyAsync(c->mask.p, keep_mask, words * 8, hipMemcpyHostToDevice, c->stream));
     qmcp::launch_complete_pairs(c->stream, (uint64_t*)c->mask.p, (uint32_t)words, n_reads);
     HIP_TRY(hipGetLastError());
@@ -1266,6 +1306,7 @@ int qmcp_hip_amplicon_filter_host(qmcp_hip_ctx* c, const uint32_t* starts, const
         HIP_TRY(hipMemcpyAsync(d_ae, amp_ends, (size_t)n_amplicons * 4, hipMemcpyHostToDevice, c->stream));
     }
     TRY(ensure(c, c->mask, words * 8));
+    c->mask_reads = 0;  // (the buffer now holds pair bits)
     qmcp::launch_amplicon_filter(c->stream, (const uint32_t*)c->in_starts.p,
                                  (const uint32_t*)c->in_ends.p, d_len, d_q, n_pairs, d_as, d_ae,
                                  n_amplicons, min_length, min_mapq, (uint64_t*)c->mask.p);
@@ -1370,6 +1411,7 @@ int qmcp_hip_filter_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const ui
     }
     HIP_TRY(hipMemcpyAsync(keep_mask_out, c->mask.p, words * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    c->mask_reads = n_reads;
     return QMCP_OK;
 }
 
@@ -1488,6 +1530,7 @@ int qmcp_hip_multi_solve_host(qmcp_hip_multi* m, const uint32_t* starts, const u
             TRY(ensure(c, c->in_ends, (size_t)ln * sizeof(uint32_t)));
             const size_t lwords = (size_t)((ln + 63) / 64);
             TRY(ensure(c, c->mask, lwords * sizeof(uint64_t)));
+            c->mask_reads = 0;
             // a device's reads are its contigs' slices of the caller's arrays, copied one contig at a time
             // straight to their place in the local problem (no host-side concatenation)
             for (size_t i = 0; i < mine.size(); ++i) {

@@ -111,6 +111,8 @@ void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
 void launch_b_and_demand(hipStream_t st, const uint32_t* cov, uint32_t n, uint32_t M, int32_t* b, int32_t* d);
 void launch_complete_pairs(hipStream_t st, uint64_t* mask, uint32_t n_words, uint64_t n_reads);
 void launch_word_popcounts(hipStream_t st, const uint64_t* words, uint32_t n_words, uint32_t* counts);
+void launch_mask_to_indices(hipStream_t st, const uint64_t* mask, uint32_t n_words, const uint32_t* word_base,
+                            unsigned long long* out);
 void launch_compact_pairs(hipStream_t st, const uint32_t* starts, const uint32_t* ends,
                           const uint64_t* pair_keep, const uint32_t* word_base, uint64_t n_pairs,
                           uint32_t* starts_c, uint32_t* ends_c, uint32_t* orig_pair);

@@ -3,9 +3,8 @@
 #include <chrono>
 #include <cstdio>
 #include <exception>
+#include <algorithm>
 #include <limits>
-#include <thread>
-#include <utility>
 #include <vector>
 
 namespace qmcp {
@@ -49,47 +48,31 @@ std::unique_ptr<Solution> QuasiMcpHipSolver::solve(std::uint32_t required_cover,
     // threads straight into pinned staging, each chunk's copy to the device issued as it is ready
     const std::uint64_t offsets[2] = {0, n};
     const std::uint32_t length = static_cast<std::uint32_t>(reads.ref_genome_length);
-    std::vector<std::uint64_t> mask((n + 63) / 64, 0);
+    // complete_pairs needs the mask on the host side of the ABI; otherwise it stays on the device and only
+    // the Solution comes back
+    std::vector<std::uint64_t> mask;
+    if (complete_pairs_) mask.assign((n + 63) / 64, 0);
     int rc = qmcp_hip_solve_host64(ctx_, reinterpret_cast<const std::uint64_t*>(reads.start_inds.data()),
                                    reinterpret_cast<const std::uint64_t*>(reads.end_inds.data()), n, offsets,
-                                   &length, 1, required_cover, mask.data(), &stats_, &breakdown_);
+                                   &length, 1, required_cover, complete_pairs_ ? mask.data() : nullptr, &stats_,
+                                   &breakdown_);
     if (rc != QMCP_OK) die("qmcp_hip_solve_host64", rc);
     if (complete_pairs_) {
-        rc = qmcp_hip_complete_pairs_host(ctx_, mask.data(), n);
+        rc = qmcp_hip_complete_pairs_host(ctx_, mask.data(), n);   // (leaves the completed mask in the context)
         if (rc != QMCP_OK) die("qmcp_hip_complete_pairs_host", rc);
     }
     const auto t1 = std::chrono::steady_clock::now();
 
-    // ascending ReadIndex, as obtain_sequence produces (quasi_mcp_cpu_max_flow_solver.cpp:93-97): the mask
-    // is cut into word ranges, each counted and then expanded by its own thread into its slice
+    // ascending ReadIndex, as obtain_sequence produces (quasi_mcp_cpu_max_flow_solver.cpp:93-97): expanded from
+    // the keep mask on the device (popcounts, scan, scatter) and copied out -- 5 % of the reads at cfg4's depth
     auto kept = std::make_unique<Solution>();
-    const std::size_t n_words = mask.size();
-    const unsigned parts = n_words >= (1u << 16) ? 4u : 1u;
-    std::vector<std::size_t> first(parts + 1, 0);
-    auto range = [&](unsigned p) { return std::pair<std::size_t, std::size_t>(n_words * p / parts, n_words * (p + 1) / parts); };
-    auto run = [&](auto&& body) {
-        std::vector<std::thread> pool;
-        for (unsigned p = 1; p < parts; ++p) pool.emplace_back(body, p);
-        body(0u);
-        for (auto& th : pool) th.join();
-    };
-    run([&](unsigned p) {
-        std::size_t cnt = 0;
-        for (std::size_t w = range(p).first; w < range(p).second; ++w) cnt += (std::size_t)__builtin_popcountll(mask[w]);
-        first[p + 1] = cnt;
-    });
-    for (unsigned p = 0; p < parts; ++p) first[p + 1] += first[p];
-    kept->resize(first[parts]);
-    run([&](unsigned p) {
-        std::size_t* out = kept->data() + first[p];
-        for (std::size_t w = range(p).first; w < range(p).second; ++w) {
-            std::uint64_t bits = mask[w];
-            while (bits != 0) {
-                *out++ = w * 64 + static_cast<std::size_t>(__builtin_ctzll(bits));
-                bits &= bits - 1;
-            }
-        }
-    });
+    static_assert(sizeof(bam_api::ReadIndex) == sizeof(std::uint64_t), "ReadIndex is size_t on an LP64 host");
+    const std::uint64_t upper = complete_pairs_ ? std::min<std::uint64_t>(n, 2 * stats_.n_kept) : stats_.n_kept;
+    kept->resize(upper);
+    std::uint64_t n_out = 0;
+    rc = qmcp_hip_kept_indices_host(ctx_, n, reinterpret_cast<std::uint64_t*>(kept->data()), upper, &n_out);
+    if (rc != QMCP_OK) die("qmcp_hip_kept_indices_host", rc);
+    kept->resize(n_out);
     const auto t2 = std::chrono::steady_clock::now();
     ms_expand_ = std::chrono::duration<float, std::milli>(t2 - t1).count();
     ms_solve_call_ = std::chrono::duration<float, std::milli>(t2 - t0).count();

@@ -144,6 +144,14 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* ctx,
                           uint64_t* keep_mask_out, qmcp_hip_stats* stats,
                           qmcp_hip_host_breakdown* breakdown);
 
+/* Solution of the last qmcp_hip_solve_host / _host64 / complete_pairs_host call on this context as the
+ * reference returns it: the ascending ReadIndex list of obtain_sequence
+ * (quasi_mcp_cpu_max_flow_solver.cpp:89-100), expanded from the context's keep mask on the device
+ * (per-word popcounts, a scan, one scatter) and copied out -- for a plugin adapter this replaces a host
+ * loop over the mask.  `capacity` entries at least stats.n_kept; *n_out receives the count. */
+int qmcp_hip_kept_indices_host(qmcp_hip_ctx* ctx, uint64_t n_reads, uint64_t* indices_out, uint64_t capacity,
+                               uint64_t* n_out);
+
 /* Same solve with reads and mask already resident in this context's device memory
  * (d_* are device pointers; contig tables stay on the host).  `hip_stream` is a
  * hipStream_t the caller's producer work was enqueued on, or NULL: the solve is ordered
