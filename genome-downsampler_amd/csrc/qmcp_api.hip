@@ -342,6 +342,13 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         if (std::strcmp(e, "fast") == 0 || std::strcmp(e, "gen") == 0) ev = false;
     }
     if (ev && qmcp::sweep_uniform_ev_supported(span, M)) {
+        // scratch of the event-driven form: 256 bytes per block, so it depends on the span, which is only
+        // known here -- grown on the first deep call of a size (ensure() waits for the streams then), kept after
+        {
+            const uint32_t wg_max = n_contigs + 768;
+            TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, span, wg_max)));
+            TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, span, wg_max)));
+        }
         uint32_t* pk = (uint32_t*)c->evpk.p;
         uint32_t* sev = (uint32_t*)c->cstart.p;
         uint32_t* lastns = (uint32_t*)c->evlast.p;
@@ -421,12 +428,6 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist2, (size_t)256 * qmcp::part_pass_pitch(n) * sizeof(uint32_t)));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 8) * sizeof(uint32_t)));  // also the event sweep's changed-block S
-        {
-            // event-driven sweep scratch, sized for the shortest span it can meet (pieces shrink with the span)
-            const uint32_t wg_max = n_contigs + 768;
-            TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ev_min_span(), wg_max)));
-            TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ev_min_span(), wg_max)));
-        }
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
