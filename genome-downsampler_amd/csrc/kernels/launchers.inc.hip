@@ -125,8 +125,7 @@ bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 
 
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                             uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                             const uint32_t* ev_choice) {
+                             uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_MW(EE)                                                                              \
@@ -135,7 +134,7 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_mw<EE>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(k_sweep_uniform_mw<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,       \
-                           ell, M, ltot, selend, iter_stats, seg, ev_choice);                                \
+                           ell, M, ltot, selend, iter_stats, seg);                                           \
     }
     switch (e) {
         case 1: QMCP_SWEEP_MW(1); break;
@@ -195,21 +194,20 @@ size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {
     }
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk, uint32_t* choice) {
+                          uint32_t* pk) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
 #define QMCP_CALL(EE)                                                                                      \
     hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, ell, \
-                       M, ltot, seg, pieces, pk, choice);
+                       M, ltot, seg, pieces, pk);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;
 }
 bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats,
-                           const uint32_t* choice) {
+                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const size_t lds = (size_t)kEvSlots * 1024;
@@ -217,20 +215,20 @@ bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t*
     (void)hipFuncSetAttribute((const void*)k_sweep_uniform_ev<EE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                    \
     hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(128), lds, st, boff, d_poff, n_contigs, ell,  \
-                       M, ltot, pk, sev, lastns, iter_stats, seg, choice);
+                       M, ltot, pk, sev, lastns, iter_stats, seg);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;
 }
 bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend, const uint32_t* choice) {
+                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
 #define QMCP_CALL(EE)                                                                                    \
     hipLaunchKernelGGL(k_sweep_expand<EE>, dim3(pieces), dim3(256), 0, st, boff, d_poff, n_wg, ell, ltot, \
-                       seg, pieces, sev, lastns, selend, choice);
+                       seg, pieces, sev, lastns, selend);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;

@@ -89,8 +89,7 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ contig_pos_off, uint32_t n_wg,
                                                     uint32_t ell, uint32_t M, uint32_t ltot,
                                                     const uint32_t* __restrict__ seg, uint32_t n_pieces_max,
-                                                    uint32_t* __restrict__ pk,
-                                                    uint32_t* __restrict__ choice /* [0] plain blocks, [1] of them with an empty start position */) {
+                                                    uint32_t* __restrict__ pk) {
     using P = EvPack<E>;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
     if (!ev_find(contig_pos_off, seg, n_wg, ell, w, g, idx)) return;
     const uint32_t q = w - g.piece_base;
     uint32_t out[4];
-    uint32_t n_plain = 0, n_holey = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t k = 4 * q + j;
@@ -116,13 +114,12 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
             Pv[r] = boff[pm >= ell ? pm - ell : 0u];
         }
         uint32_t word = 0;
-        bool deep = true, hole = false;
+        bool deep = true;
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const uint32_t i = lane * E + r;
             const bool valid = i < ell && k * ell + i < g.L;
             const uint32_t c = valid ? X[r + 1] - X[r] : 0u;
-            hole = hole || (valid && c == 0);
             word |= min(c, P::kSat) << (r * P::kW);
             // need(p) == need(p - 1) == M
             if (i < ell) deep = deep && (X[r + 1] - Pv[r + 1] >= M) && (X[r] - Pv[r] >= M);
@@ -130,28 +127,10 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
         const bool inside = (uint64_t)(k + 1) * ell <= g.L;
         const bool plain = k != 0 && k < g.n_blocks && inside && __all(deep);
         out[j] = word | P::kGuard | (plain ? P::kPlain : 0u);
-        if (plain) {
-            ++n_plain;
-            if (__any(hole)) ++n_holey;
-        }
-    }
-    // (one pair of adds per wave) what the chain kernel and the block-scan kernel behind it look at to
-    // decide, on the device, which of them runs: see k_sweep_uniform_ev
-    if (choice != nullptr && lane == 0 && n_plain != 0) {
-        atomicAdd(&choice[0], n_plain);
-        if (n_holey != 0) atomicAdd(&choice[1], n_holey);
     }
     uint4 v;
     v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
     reinterpret_cast<uint4*>(pk)[(size_t)w * 64 + lane] = v;
-}
-
-// Which kernel sweeps: the event-driven chain tests blocks cheaply but pays ~6 x the block-scan pipeline's
-// chain step for a block that changes the kept profile, and a block with a start position that holds no
-// read nearly always does (amplicon panels: reads start in a few windows -- cfg3 took 0.16 ms here against
-// 0.05 ms).  k_sweep_pack counts such blocks; both kernels are launched and the one not chosen leaves at once.
-__device__ __forceinline__ bool ev_chosen(const uint32_t* __restrict__ choice) {
-    return choice == nullptr || 2u * choice[1] <= choice[0];
 }
 
 // LDS-DMA of one 1-KiB piece (16 bytes per lane) to the wave-uniform LDS byte address lds_dst
@@ -215,11 +194,9 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
                                                          uint32_t* __restrict__ sev,      // ltot + 8: S of changed blocks
                                                          uint32_t* __restrict__ lastns,   // per block: last changed block <= it
                                                          uint32_t* __restrict__ iter_stats,
-                                                         const uint32_t* __restrict__ seg,
-                                                         const uint32_t* __restrict__ choice) {
+                                                         const uint32_t* __restrict__ seg) {
     using P = EvPack<E>;
     extern __shared__ uint4 s_evring[];
-    if (!ev_chosen(choice)) return;  // (uniform over the grid) the block-scan kernel launched behind sweeps
     // two waves: wave 1 only moves pieces into the LDS ring (an LDS-DMA request costs its issuer ~96
     // cycles, lab/dma_lab.hip -- more than the chain spends on the four blocks in it), wave 0 is the chain
     __shared__ uint32_t s_ctl_words[2];  // [0] pieces landed, [1] pieces read
@@ -533,9 +510,7 @@ __global__ __launch_bounds__(256) void k_sweep_expand(const uint32_t* __restrict
                                                       uint32_t ell, uint32_t ltot, const uint32_t* __restrict__ seg,
                                                       uint32_t n_pieces_max, const uint32_t* __restrict__ sev,
                                                       const uint32_t* __restrict__ lastns,
-                                                      uint32_t* __restrict__ selend,
-                                                      const uint32_t* __restrict__ choice) {
-    if (!ev_chosen(choice)) return;  // the block-scan kernel wrote selend itself
+                                                      uint32_t* __restrict__ selend) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t gb = blockIdx.x * 4 + (threadIdx.x >> 6);  // global block slot
     const uint32_t w = gb >> 2;

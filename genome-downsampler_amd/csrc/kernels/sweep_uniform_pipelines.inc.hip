@@ -120,11 +120,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_mw(const uint32_t* __rest
                                                           uint32_t ell, uint32_t M, uint32_t ltot,
                                                           uint32_t* __restrict__ selend,
                                                           uint32_t* __restrict__ iter_stats,
-                                                          const uint32_t* __restrict__ seg,
-                                                          const uint32_t* __restrict__ ev_choice /* null, or the event-driven sweep's
-                                                              counters: this kernel leaves if that one is sweeping */) {
+                                                          const uint32_t* __restrict__ seg) {
     using Ly = MwLayout<E>;
-    if (ev_choice != nullptr && 2u * ev_choice[1] <= ev_choice[0]) return;  // (uniform over the grid)
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
     uint32_t* s_flag = s_mw + (size_t)Ly::kSlots * kG * Ly::kWords * 64;

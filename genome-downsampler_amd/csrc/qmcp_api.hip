@@ -336,9 +336,8 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // deep data: the event-driven form (a block is only TESTED unless its counts fall below the kept
     // profile); spans below ev_min_span() would need more scratch than the arena holds for it
     bool ev = !gen && span >= ev_min_span();
-    bool forced_ev = false;
     if (const char* e = std::getenv("QMCP_HIP_SWEEP")) {
-        if (std::strcmp(e, "ev") == 0) { ev = span >= ev_min_span(); forced_ev = true; }
+        if (std::strcmp(e, "ev") == 0) ev = span >= ev_min_span();
         if (std::strcmp(e, "fast") == 0 || std::strcmp(e, "gen") == 0) ev = false;
     }
     if (ev && qmcp::sweep_uniform_ev_supported(span, M)) {
@@ -352,30 +351,22 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         uint32_t* pk = (uint32_t*)c->evpk.p;
         uint32_t* sev = (uint32_t*)c->cstart.p;
         uint32_t* lastns = (uint32_t*)c->evlast.p;
-        // The event-driven chain and the block-scan pipeline are BOTH launched; k_sweep_pack counts the blocks
-        // with a start position that holds no read, and the kernel that data does not suit leaves at once
-        // (QMCP_HIP_SWEEP=ev: no such choice, the event-driven form sweeps whatever the data).
-        uint32_t* choice = forced_ev ? nullptr : d_iters + 10;  // two words of the zeroed scalars block
         {
             KernelSpan sp(c, "k_sweep_pack", st);
-            qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk, choice);
+            qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk);
         }
         {
             KernelSpan sp(c, "k_sweep_uniform_ev", st);
-            qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk, sev, lastns, d_iters, choice);
-        }
-        if (choice != nullptr) {
-            KernelSpan sp(c, "k_sweep_uniform_mw", st);
-            qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max, choice);
+            qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk, sev, lastns, d_iters);
         }
         KernelSpan sp(c, "k_sweep_expand", st);
-        qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, sev, lastns, selend, choice);
+        qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, sev, lastns, selend);
         return QMCP_OK;
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
         const bool ok = gen ? qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max)
-                            : qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max, nullptr);
+                            : qmcp::launch_sweep_uniform_mw(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max);
         if (ok) return QMCP_OK;
     }
     KernelSpan sp(c, "k_sweep_uniform", st);

@@ -58,8 +58,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
-                             uint32_t n_seg_max,
-                             const uint32_t* ev_choice /* null, or the event-driven sweep's choice counters */);
+                             uint32_t n_seg_max);
 // event-driven form for deep data (kernels/sweep_uniform_events.inc.hip): pack, chain, expand.
 // pk / lastns are scratch of sweep_ev_pack_bytes / sweep_ev_last_bytes; sev has ltot + 8 words.
 bool sweep_uniform_ev_supported(uint32_t ell, uint32_t M);
@@ -67,14 +66,13 @@ size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk, uint32_t* choice /* two counters, zeroed by the caller */);
+                          uint32_t* pk);
 bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats,
-                           const uint32_t* choice);
+                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats);
 bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend, const uint32_t* choice);
+                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend);
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                           uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,

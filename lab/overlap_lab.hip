@@ -48,7 +48,7 @@ int main() {
             hipDeviceSynchronize();
             if (with_hog) { hipEventRecord(ha, sb); for (int r = 0; r < 6; ++r) hipLaunchKernelGGL(k_hog, dim3(4096), dim3(256), 0, sb, h_in, h_out, hog_n); hipEventRecord(hb, sb); }
             hipEventRecord(a, ss);
-            launch_sweep_uniform_mw(ss, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0, nullptr);
+            launch_sweep_uniform_mw(ss, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b, ss);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;

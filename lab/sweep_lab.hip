@@ -49,7 +49,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
             // the table was just written by other CUs)
             hipMemsetAsync(d_flush, it, 768u << 20, 0);
             hipEventRecord(a);
-            launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0, nullptr);
+            launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float msc; hipEventElapsedTime(&msc, a, b);
             if (msc < cold) cold = msc;
         }
@@ -57,7 +57,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         hipMemset(d_it, 0, 128);
         for (int it = 0; it < reps; ++it) {
             hipEventRecord(a);
-            ok = launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0, nullptr);
+            ok = launch_sweep_uniform_mw(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best2) best2 = ms;
         }
         hipError_t e = hipDeviceSynchronize();
@@ -90,7 +90,7 @@ static void run_case(const char* name, double mean, uint32_t L, uint32_t ell, ui
         float best3 = 1e9;
         for (int it = 0; it < reps; ++it) {
             hipEventRecord(a);
-            launch_sweep_uniform_gen(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0, nullptr);
+            launch_sweep_uniform_gen(0, d_boff, d_poff, contigs, ell, M, (uint32_t)Lt, d_sel, d_it, nullptr, 0);
             hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best3) best3 = ms;
         }
         hipError_t e = hipDeviceSynchronize();
