@@ -507,13 +507,13 @@ void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uin
                        n_contigs, gstart);
 }
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
-                          uint32_t shift, uint32_t ltot, uint32_t* boff) {
+                          uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
     const size_t lds = (((size_t)1 << shift) + ((size_t)1 << shift) / 32 + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_range_offsets, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(k_range_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, range_start, shift,
-                       ltot, boff);
+                       ltot, boff, empty_positions);
 }
 bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n) {
     return (size_t)n < (size_t)((ltot >> shift) + 1) * ((size_t)1 << shift);

@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256) void k_seg_range_table(const uint32_t* __restr
 __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restrict__ keys16,
                                                         const uint32_t* __restrict__ range_start,
                                                         uint32_t shift, uint32_t ltot,
-                                                        uint32_t* __restrict__ boff) {
+                                                        uint32_t* __restrict__ boff,
+                                                        uint32_t* __restrict__ empty_positions /* += positions of the
+                                                            range that start no read (one add per workgroup); or null */) {
     // [1 << shift] counters, one pad word after every 32: a thread's 32 consecutive positions then
     // sit in 32 different banks during the scan
     extern __shared__ uint32_t s_cnt32[];
@@ -346,12 +348,22 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
     // the array needs no separate scan pass over the whole genome
     const uint32_t per = width >= 1024u ? width >> 10 : 1u;  // positions per thread
     const uint32_t first = threadIdx.x * per;
-    uint32_t sum = 0;
+    uint32_t sum = 0, empties = 0;
     if (first < width)
-        for (uint32_t q = 0; q < per; ++q) sum += s_cnt32[PADDED(first + q)];
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t cq = s_cnt32[PADDED(first + q)];
+            sum += cq;
+            empties += (cq == 0 && pos0 + first + q < ltot) ? 1u : 0u;
+        }
     const uint32_t inc = wave_incl_scan_add(sum);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (lane == 63) s_wsum[w] = inc;
+    if (empty_positions != nullptr) {
+        // how spiky the starts are: the host picks the sweep kernel by it (the event-driven form pays
+        // dearly for blocks with an empty start position)
+        empties = wave_sum_u32(empties);
+        if (lane == 0 && empties != 0) atomicAdd(empty_positions, empties);
+    }
     __syncthreads();
     uint32_t run = lo + inc - sum;
     for (uint32_t x = 0; x < w; ++x) run += s_wsum[x];

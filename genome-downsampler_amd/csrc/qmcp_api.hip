@@ -83,6 +83,10 @@ struct qmcp_hip_ctx {
     bool pending = false;
     qmcp_hip_stats pend_stats;
     uint32_t pend_whole_contig_chains = 0;  // mixed spans without cut points: one chain per non-empty contig
+    // positions that start no read, as counted by the last range-ranked solve (picks the sweep kernel of the next)
+    bool spiky_known = false, pend_spiky = false;
+    uint64_t spiky_n = 0, spiky_ltot = 0;
+    uint32_t spiky_empty = 0;
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
     DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
@@ -312,7 +316,7 @@ uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, boo
 }
 
 int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
-                         uint32_t span, uint32_t M, uint32_t* d_iters) {
+                         uint32_t span, uint32_t M, uint32_t* d_iters, uint32_t empty_positions) {
     // mean coverage in units of M: the fast form needs the binding jumps to come from the previous
     // block, which holds while coverage is many times M
     const double depth = (double)n * (double)span / ((double)ltot * (double)(M ? M : 1));
@@ -335,7 +339,16 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     }
     // deep data: the event-driven form (a block is only TESTED unless its counts fall below the kept
     // profile); spans below ev_min_span() would need more scratch than the arena holds for it
-    bool ev = !gen && span >= ev_min_span();
+    // ... and only where few blocks have a start position that holds no read: such a block nearly always
+    // changes the kept profile, and a changed block costs the event-driven chain ~6 x the block-scan
+    // pipeline's chain step (amplicon panels, whose reads start in a few windows: cfg3 took 0.16 ms against
+    // 0.05).  With a fraction z of empty positions about 1 - (1 - z)^span of the blocks have one: more than
+    // half of them from z = ln 2 / span on.  (Unknown on the small-call route: block scan, as in round 1.)
+    // (no read can start in the last span - 1 positions of a contig: those are not holes in the data)
+    const double structural = (double)n_contigs * (double)(span - 1);
+    const double holes = (double)empty_positions > structural ? (double)empty_positions - structural : 0.0;
+    const bool spiky = empty_positions == 0xFFFFFFFFu || holes * (double)span > 0.693 * (double)ltot;
+    bool ev = !gen && !spiky && span >= ev_min_span();
     if (const char* e = std::getenv("QMCP_HIP_SWEEP")) {
         if (std::strcmp(e, "ev") == 0) ev = span >= ev_min_span();
         if (std::strcmp(e, "fast") == 0 || std::strcmp(e, "gen") == 0) ev = false;
@@ -382,7 +395,8 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
                   const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
                   uint32_t M, uint64_t* d_mask) {
     if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
-    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    c->pend_spiky = false;
+    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 5 * sizeof(unsigned long long), hipHostMallocDefault));
     Problem pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n;
@@ -441,6 +455,8 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
     uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
     const bool two_level = qmcp::range_path_two_level(ltot);
     uint32_t max_load = 0;
+    uint32_t empty_positions = 0xFFFFFFFFu;  // unknown unless the range-ranked route counted them
+    bool ranked_counted = false;
     bool have_gstart = true;
     if (!may_rank) {
         HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
@@ -494,16 +510,26 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         }
         HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
         {
-            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan
+            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan; it also
+            // counts the positions that start no read (stats word 3: the host picks the sweep kernel by it)
             KernelSpan sp(c, "k_range_offsets");
             qmcp::launch_range_offsets(s1, (const uint16_t*)c->keys[0].p, d_range_start, range_shift, ltot,
-                                       (uint32_t*)c->boff.p);
+                                       (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         HIP_TRY(hipMemcpyAsync(hs, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
         HIP_TRY(hipMemcpyAsync(&max_load, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
         HIP_TRY(hipStreamSynchronize(c->stream2));
+        // How spiky the starts are only decides WHICH exact sweep kernel runs, so the count of the previous
+        // call of this shape is good enough (and saves waiting for k_range_offsets); a first call waits.
+        if (c->spiky_known && c->spiky_n == n64 && c->spiky_ltot == pr.ltot) {
+            empty_positions = c->spiky_empty;
+        } else {
+            HIP_TRY(hipMemcpyAsync(&empty_positions, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s1));
+            HIP_TRY(hipStreamSynchronize(s1));
+        }
+        ranked_counted = true;
         if (hs[2] != 0) {
             (void)hipStreamSynchronize(s1);  // what was queued stays in bounds; let it drain
             return fail(QMCP_EREAD, "a read has start > end or end >= its contig length");
@@ -569,7 +595,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
-        TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters));
+        TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters, empty_positions));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
         sweep_done = true;
@@ -666,7 +692,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
     if (sweep_done) {
         // done above, from the early counts
     } else if (uniform) {
-        TRY(launch_uniform_sweep(c, c->stream, n, ltot, n_contigs, max_span, M, d_iters));
+        TRY(launch_uniform_sweep(c, c->stream, n, ltot, n_contigs, max_span, M, d_iters, empty_positions));
     } else {
         uint32_t ring = 64;
         while (ring <= max_span) ring <<= 1;
@@ -744,6 +770,12 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));
+    c->pend_spiky = ranked_counted;
+    if (ranked_counted) {
+        HIP_TRY(hipMemcpyAsync(c->h_scalars + 4, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        c->spiky_n = n64;
+        c->spiky_ltot = pr.ltot;
+    }
     c->pend_stats = local;
     c->pend_whole_contig_chains = 0;
     if (mixed_whole_contigs)  // one wave per non-empty contig
@@ -768,6 +800,10 @@ int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
 #endif
     qmcp_hip_stats local = c->pend_stats;
     const unsigned long long* host_scalars = c->h_scalars;
+    if (c->pend_spiky) {
+        c->spiky_empty = (uint32_t)(c->h_scalars[4] & 0xFFFFFFFFull);
+        c->spiky_known = true;
+    }
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);

@@ -143,7 +143,8 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
 void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
-                          uint32_t shift, uint32_t ltot, uint32_t* boff);
+                          uint32_t shift, uint32_t ltot, uint32_t* boff,
+                          uint32_t* empty_positions /* zeroed counter: positions that start no read; or null */);
 size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot, uint32_t n);  // list slots: per position or per read
 bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n);
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,

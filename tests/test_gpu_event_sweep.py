@@ -171,3 +171,28 @@ def test_tiny_genomes_of_one_to_eight_blocks(pkg, oracle, solver, span):
             rng = np.random.default_rng(int(f * 100) + span + M)
             s, e = _reads(rng, 3000, L, span)
             _check(solver, oracle, s, e, L, M)
+
+
+def test_host_picks_the_sweep_by_how_spiky_the_starts_are(pkg, oracle, solver):
+    """deep data whose reads start in a few windows (amplicon panels) leaves most blocks with an empty start
+    position: the event-driven chain would pay for every one of them, so the host -- told the number of empty
+    positions by k_range_offsets (of this call if its shape is new to the context, else of the previous call of
+    the shape) -- takes the block-scan pipeline there and the event-driven form on data that starts reads
+    everywhere; same answers either way"""
+    import workloads
+    s, e, a0, a1, _ = workloads.amplicon_reads(400_000, seed=5, straddle_fraction=0.0)   # 800 k reads: ranked route
+    solver.set_profiling(1)
+    try:
+        got = solver.solve(s, e, 29_903, 200)
+        spiky_kernels = set(solver.kernel_times())
+        rng = np.random.default_rng(2)
+        s2, e2 = _reads(rng, 800_002, 29_903, 150)   # (another shape: the count is taken afresh)
+        solver.set_profiling(1)
+        got2 = solver.solve(s2, e2, 29_903, 200)
+        flat_kernels = set(solver.kernel_times())
+    finally:
+        solver.set_profiling(0)
+    assert "k_sweep_uniform_mw" in spiky_kernels and "k_sweep_uniform_ev" not in spiky_kernels
+    assert "k_sweep_uniform_ev" in flat_kernels and "k_sweep_uniform_mw" not in flat_kernels
+    assert np.array_equal(got, oracle.solve(s, e, 29_903, 200))
+    assert np.array_equal(got2, oracle.solve(s2, e2, 29_903, 200))
