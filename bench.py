@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the host-entry, plugin-entry and CPU-baseline legs (counter passes: every "
+                         "launch of the run is then the workload's own)")
     ap.add_argument("--mode", choices=["per-gpu", "sharded"], default="per-gpu",
                     help="N > 1: the workload per GPU (weak scaling) or one workload sharded by contig (strong)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
@@ -317,7 +320,7 @@ def main():
                                        "every kernel bracketed (solves overlap: the sum exceeds a step)",
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # T_e2e, outside the timed region and never `value`: host arrays in ->
             # host keep mask out through qmcp_hip_solve_host (pageable H2D of 8 B/read, solve, D2H of
             # the mask), best of three
@@ -331,7 +334,7 @@ def main():
                                  "h2d_ms": round(float(solvers[0].last_stats.ms_h2d), 3),
                                  "d2h_ms": round(float(solvers[0].last_stats.ms_d2h), 3),
                                  "note": "PCIe-inclusive; reported beside, never as, value"}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # The plugin boundary itself (SURVEY section 8d T_e2e; the span src/app.cpp:132-139 brackets):
             # BamApi holding SOAPairedReads (size_t columns) -> QuasiMcpHipSolver::solve -> Solution
             # (vector<size_t>), one contig -- the reference is single-contig.  Best of three.
@@ -348,7 +351,7 @@ def main():
                          "note": "one contig of the workload through SolverManager -> Solver::solve(M, BamApi&); "
                                  "pcie_floor_ms = 8 B/read at the pageable-copy rate host_entry measured"})
             out["plugin_entry"] = best
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             base, oracle_mask = cpu_baseline(pkg, args.workload)
             out["cpu_baseline"] = base
             # parity spot check on the sampled contig: GPU bits == oracle bits

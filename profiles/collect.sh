@@ -14,7 +14,7 @@ python3 "$ROOT/bench.py" --workload cfg2 --steps 50 --warmup 5 > "$OUT/bench_cfg
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof/stats" -o run -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/prof/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --in-flight 1 --no-cpu-baseline \
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/prof/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --in-flight 1 --no-extras \
         > "$OUT/prof/pmc_$c.json" 2> "$OUT/prof/pmc_$c.err"
 done
 python3 "$ROOT/profiles/summarize_pmc.py" "$OUT/prof" "$OUT/prof/pmc_traffic_cfg4.json" \

@@ -55,7 +55,7 @@ def test_product_does_not_link_the_oracle(pkg):
                 assert hit is None, f"{os.path.join(dirpath, f)} refers to the oracle: {hit.group(0)!r}"
     # bench.py may use the oracle only in its cpu_baseline leg (and the parity spot check beside it)
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    timed = bench[bench.index("def main():"):bench.index("if world == 1 and not args.no_cpu_baseline:")]
+    timed = bench[bench.index("def main():"):bench.index("if world == 1 and not args.no_cpu_baseline")]
     assert "oracle" not in timed.replace("parity_vs_oracle_on_sample", "")
 
 
