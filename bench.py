@@ -86,7 +86,7 @@ def main():
                          "launch of the run is then the workload's own)")
     ap.add_argument("--mode", choices=["per-gpu", "sharded"], default="per-gpu",
                     help="N > 1: the workload per GPU (weak scaling) or one workload sharded by contig (strong)")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="solves kept in flight per GPU (two solver contexts)")
     # rehearsal knobs (not used by the driver): run several ranks on ONE GPU over gloo to
     # exercise the N > 1 plumbing on a single-GPU box
@@ -151,7 +151,7 @@ def main():
     # Four mask buffers in rotation: solve s writes buffer s % 4; its gather (RCCL, its own stream) is
     # started when the solve is collected one or two steps later and waited for before buffer s % 4
     # is written again.
-    n_buf = 4
+    n_buf = max(4, args.in_flight + 2)
     d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_buf)]
     d_alls = [torch.zeros(words * world, dtype=torch.int64, device=dev) for _ in range(n_buf)] \
         if world > 1 else None

@@ -327,15 +327,25 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
 #else
 #define QMCP_GEN_STAMP_ARG
 #endif
-#define QMCP_GEN_REG(BB)                                                                              \
+#define QMCP_GEN_REG_K(BB, KK)                                                                        \
     if (wide)                                                                                          \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB>), dim3(n_wg), dim3(128), 0, st, boff,       \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
                            max_span, M, selend, seg QMCP_GEN_STAMP_ARG);                               \
     else                                                                                               \
-        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB>), dim3(n_wg), dim3(128), 0, st, boff,       \
+        hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
                            M, selend, seg QMCP_GEN_STAMP_ARG);
+    // loader waves per walker: few workgroups (contigs) -> many loaders, so the walker never waits for an
+    // entering chunk's three trips to memory; many workgroups (stretches) fill the chip by themselves
+    // and extra waves only get in the walkers' way
+    int loaders = n_wg <= 64 ? 4 : 1;  // (769 stretches, cfg3-like mix: 1 loader 2.52 ms, 8 loaders 4.92 ms; one contig: 1.19 vs 1.09 ms)
+    if (const char* e = std::getenv("QMCP_HIP_REG_LOADERS")) loaders = std::atoi(e);  // lab
+#define QMCP_GEN_REG(BB)                                                                              \
+    if (loaders >= 8) { QMCP_GEN_REG_K(BB, 8) }                                                        \
+    else if (loaders >= 4) { QMCP_GEN_REG_K(BB, 4) }                                                   \
+    else if (loaders >= 2) { QMCP_GEN_REG_K(BB, 2) }                                                   \
+    else { QMCP_GEN_REG_K(BB, 1) }
     if (b <= 2) { QMCP_GEN_REG(2) }
     else if (b == 3) { QMCP_GEN_REG(3) }
     else if (b == 4) { QMCP_GEN_REG(4) }
@@ -343,6 +353,7 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
     else if (b <= 8) { QMCP_GEN_REG(8) }
     else return false;
 #undef QMCP_GEN_REG
+#undef QMCP_GEN_REG_K
 #undef QMCP_GEN_STAMP_ARG
     return true;
 }

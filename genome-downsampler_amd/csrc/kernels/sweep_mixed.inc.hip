@@ -334,17 +334,19 @@ __global__ __launch_bounds__(64) void k_sweep_general_cached(
 // serial path.  Only the expiry counts of reads that end beyond the chunk go through an LDS ring
 // (fire-and-forget adds, read back when their chunk enters).  The chunk loop is unrolled B times so
 // that the slot a chunk's buckets enter is a compile-time index.
-// Two waves: the walker above, and a loader that stays one chunk ahead -- bucket bounds, coverage
-// and the first two groups of every entering bucket are three dependent trips to memory (~1.5 us),
-// which the walker would otherwise sit out at every chunk's entry (most of its time on shallow
-// data); the loader hands them over through LDS at one barrier per chunk and also stores the
-// selected counts of the buckets whose slot the chunk recycles.
+// 1 + kRegLoaders waves: the walker above, and loader waves that run ahead of it -- bucket bounds,
+// coverage and the first two groups of every entering bucket are three dependent trips to memory
+// (~3 us on sorted records that miss L2), which the walker would otherwise sit out at every chunk's
+// entry.  Loader wave w takes the chunks c = w (mod kRegLoaders) and hands each over through its
+// own LDS buffer (2 * kRegLoaders buffers in rotation) and a progress word per loader; the walker
+// publishes how many chunks it has taken in.  No barrier after the roles split.  The launcher
+// gives few workgroups four loaders each and many workgroups (stretches) one.
 __device__ __forceinline__ uint32_t reg_sweep_key(uint32_t gx, uint32_t gy, uint32_t qrel, uint32_t pbase) {
     return gy != 0 ? (((gx - pbase) << 16) | (qrel << 7) | min(gy, 127u)) : 0u;
 }
 
-template <typename Sorted, int B>
-__global__ __launch_bounds__(128) void k_sweep_general_reg(
+template <typename Sorted, int B, int kRegLoaders>
+__global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
     uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend,
@@ -357,29 +359,32 @@ __global__ __launch_bounds__(128) void k_sweep_general_reg(
     constexpr uint32_t kRing = 64 * B;  // >= max_span + 64
     constexpr uint32_t kBack = 64u * (uint32_t)(B - 1);  // p0 - pbase
     __shared__ uint32_t s_exp[kRing];
-    // what the loader hands the walker for a chunk: need, bucket end, head group, second group, next
-    // unread group (double-buffered), and what the walker hands back: selected counts of the slot
-    // the chunk recycles
-    enum { kInNeed, kInB1, kInG0x, kInG0y, kInG1x, kInG1y, kInNext, kInWords };
-    __shared__ uint32_t s_in[2][kInWords][64];
-    __shared__ uint32_t s_tk[2][64];
+    // what a loader hands the walker for a chunk: need, bucket start and end, head group, second group,
+    // next unread group
+    enum { kInNeed, kInB0, kInB1, kInG0x, kInG0y, kInG1x, kInG1y, kInNext, kInWords };
+    constexpr uint32_t kBufs = 2u * (uint32_t)kRegLoaders;
+    __shared__ uint32_t s_in[kBufs][kInWords][64];
+    __shared__ uint32_t s_flag_words[kRegLoaders + 1];  // [w] chunks loader w has handed over, [kRegLoaders] chunks the walker has taken in
+    typedef __attribute__((address_space(3))) uint32_t LdsWord;
+    volatile LdsWord* const s_flag = (volatile LdsWord*)s_flag_words;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 walker, 1 loader
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 walker, 1.. loaders
     const uint32_t c_id = blockIdx.x;
     SweepSeg sg;
     if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
     const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
     const uint64_t code_mask = (1ull << span_bits) - 1;
-    for (uint32_t i = threadIdx.x; i < kRing; i += 128) s_exp[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kRing; i += blockDim.x) s_exp[i] = 0;
+    if (threadIdx.x <= (uint32_t)kRegLoaders) s_flag[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t* __restrict__ cb = boff + base;
     const uint32_t* __restrict__ ce = eoff + base;
     uint32_t* __restrict__ csel = selend + base;
     // per owned bucket: head group (end + 1, run), cached second group, next unread group, bucket
-    // end, reads selected so far
-    uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bend1[B], taken[B];
+    // start and end, reads selected so far
+    uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bstart[B], bend1[B], taken[B];
 #pragma unroll
-    for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bend1[b] = taken[b] = 0; }
+    for (int b = 0; b < B; ++b) { g0x[b] = g0y[b] = g1x[b] = g1y[b] = nextj[b] = bstart[b] = bend1[b] = taken[b] = 0; }
     uint32_t cur = 0;  // selected reads covering the chunk's first position, before its own selections
     if (seg != nullptr) {
         if (role == 0) cur = seed_stretch_expiry(skeys, boff, base, span_bits, max_span, s_exp, kRing, lane);
@@ -397,35 +402,33 @@ __global__ __launch_bounds__(128) void k_sweep_general_reg(
         }
     };
 
-    if (role == 1) {
-        // ---- loader: chunk c + 1 while the walker walks chunk c
-        auto enter = [&](uint32_t c) {
-            const uint32_t q = c * 64 + lane, buf = c & 1u;
-            uint32_t need = 0, b1 = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, nj = 0;
+    if (role != 0) {
+        // ---- loader w: chunks w - 1, w - 1 + kRegLoaders, ...; buffer c % kBufs is free once the walker
+        // has taken chunk c - kBufs in
+        uint32_t handed = 0, walker_at = 0;
+        for (uint32_t c = role - 1u; c < n_chunks; c += (uint32_t)kRegLoaders) {
+            const uint32_t q = c * 64 + lane, buf = c % kBufs;
+            uint32_t need = 0, b0 = 0, b1 = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, nj = 0;
             if (q < L) {
-                const uint32_t b0 = cb[q];
+                b0 = cb[q];
                 b1 = cb[q + 1];
                 need = min(b1 - ce[q], M);  // cov(q) = boff[q + 1] - eoff[q]
                 load_group(b0, b1, q, x0, y0);
                 load_group(b0 + y0, b1, q, x1, y1);
                 nj = b0 + y0 + y1;
             }
-            s_in[buf][kInNeed][lane] = need; s_in[buf][kInB1][lane] = b1;
+            while (c >= kBufs && walker_at + kBufs <= c) {
+                walker_at = s_flag[kRegLoaders];
+                if (walker_at + kBufs <= c) __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            s_in[buf][kInNeed][lane] = need; s_in[buf][kInB0][lane] = b0; s_in[buf][kInB1][lane] = b1;
             s_in[buf][kInG0x][lane] = x0; s_in[buf][kInG0y][lane] = y0;
             s_in[buf][kInG1x][lane] = x1; s_in[buf][kInG1y][lane] = y1;
             s_in[buf][kInNext][lane] = nj;
-        };
-        enter(0);
-        __syncthreads();  // chunk 0 handed over
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            // the slot chunk c recycles held the buckets of chunk c - B: their selected counts came in
-            // s_tk before the barrier that handed chunk c over
-            const uint32_t qq = c * 64 + lane - kRing;
-            if (c >= (uint32_t)B && qq < L) csel[qq] = cb[qq] + s_tk[c & 1u][lane];
-            if (c + 1 < n_chunks) {
-                enter(c + 1);
-                __syncthreads();  // chunk c + 1 handed over (the walker arrives when it has walked chunk c)
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            handed += 1;
+            if (lane == 0) s_flag[role - 1u] = handed;
         }
         return;
     }
@@ -443,16 +446,25 @@ __global__ __launch_bounds__(128) void k_sweep_general_reg(
             // buckets hand their selected counts to the loader, which hands this chunk's buckets over
             const uint32_t q = p0 + lane;
             uint32_t need = 0, exp_c = 0;
-            if (c >= (uint32_t)B) s_tk[c & 1u][lane] = taken[e];
-            __syncthreads();
             {
-                const uint32_t buf = c & 1u;
+                const uint32_t qq = q - kRing;
+                if (c >= (uint32_t)B && qq < L) csel[qq] = bstart[e] + taken[e];
+            }
+            {
+                // chunk c is the (c / kRegLoaders + 1)-th of loader c % kRegLoaders
+                const uint32_t w = c % (uint32_t)kRegLoaders, want = c / (uint32_t)kRegLoaders + 1u;
+                while (s_flag[w] < want) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t buf = c % kBufs;
                 need = s_in[buf][kInNeed][lane];
+                bstart[e] = s_in[buf][kInB0][lane];
                 bend1[e] = s_in[buf][kInB1][lane];
                 g0x[e] = s_in[buf][kInG0x][lane]; g0y[e] = s_in[buf][kInG0y][lane];
                 g1x[e] = s_in[buf][kInG1x][lane]; g1y[e] = s_in[buf][kInG1y][lane];
                 nextj[e] = s_in[buf][kInNext][lane];
                 taken[e] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) s_flag[kRegLoaders] = c + 1u;
             }
             if (q < L) {
                 exp_c = s_exp[q % kRing];
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(128) void k_sweep_general_reg(
         if (last_c >= (uint32_t)b) {
             const uint32_t cc = last_c - ((last_c - (uint32_t)b) % (uint32_t)B);
             const uint32_t qq = cc * 64 + lane;
-            if (qq < L) csel[qq] = cb[qq] + taken[b];
+            if (qq < L) csel[qq] = bstart[b] + taken[b];
         }
     }
 }
