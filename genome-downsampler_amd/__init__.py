@@ -33,10 +33,21 @@ PATH_UNIFORM, PATH_GENERAL = 1, 2
 KIND_UNIFORM, KIND_LOW_BOTH_SIDES, KIND_HOLE, KIND_ZERO_BOTH_SIDES = 0, 1, 2, 3
 
 
+# status codes of include/qmcp_hip.h
+QMCP_OK, QMCP_EINVAL, QMCP_EREAD, QMCP_ERANGE, QMCP_ENODEVICE, QMCP_EHIP, QMCP_ENOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
 class QmcpError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"qmcp_hip error {code}: {message}")
         self.code = code
+
+
+class HostBreakdown(C.Structure):
+    """qmcp_hip_host_breakdown (include/qmcp_hip.h)"""
+    _fields_ = [("ms_total", C.c_float), ("ms_narrow_h2d", C.c_float), ("ms_solve", C.c_float),
+                ("ms_d2h", C.c_float), ("host_threads", C.c_uint32), ("chunks", C.c_uint32),
+                ("columns_sent", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -46,7 +57,7 @@ class Stats(C.Structure):
         ("max_span", C.c_uint32), ("sort_passes", C.c_uint32), ("sweep_stretches", C.c_uint32),
         ("ms_total", C.c_float), ("ms_prepare", C.c_float), ("ms_scan", C.c_float),
         ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_mark", C.c_float),
-        ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
+        ("ms_h2d", C.c_float), ("ms_d2h", C.c_float), ("columns_sent", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -75,6 +86,8 @@ _hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 _hip.qmcp_hip_solve_device_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 _hip.qmcp_hip_solve_end.argtypes = [C.c_void_p, C.POINTER(Stats)]
+_hip.qmcp_hip_solve_host64.argtypes = [C.c_void_p, _u64p, _u64p, C.c_uint64, _u64p, _u32p, C.c_uint32,
+                                       C.c_uint32, _u64p, C.POINTER(Stats), C.POINTER(HostBreakdown)]
 _hip.qmcp_hip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
 _hip.qmcp_hip_multi_destroy.argtypes = [C.c_void_p]
 _hip.qmcp_hip_multi_destroy.restype = None
@@ -233,6 +246,20 @@ class Solver:
                                         _p32(lengths), lengths.size, int(max_coverage), _p64(mask),
                                         C.byref(st)))
         self.last_stats = st
+        return mask[:mask_words(n)]
+
+    def solve64(self, start_inds, end_inds, contig_lengths, max_coverage, contig_read_offsets=None):
+        """the reference's own size_t columns in (qmcp_hip_solve_host64: narrowed inside the library),
+        host keep bitmask out; self.last_breakdown tells how (threads, chunks, columns sent)"""
+        s64 = np.ascontiguousarray(start_inds, dtype=np.uint64)
+        e64 = np.ascontiguousarray(end_inds, dtype=np.uint64)
+        n = s64.size
+        offs, lengths = _contig_tables(n, contig_read_offsets, contig_lengths)
+        mask = np.zeros(max(mask_words(n), 1), dtype=np.uint64)
+        st, bd = Stats(), HostBreakdown()
+        _check(_hip.qmcp_hip_solve_host64(self._ctx, _p64(s64), _p64(e64), n, _p64(offs), _p32(lengths),
+                                          lengths.size, int(max_coverage), _p64(mask), C.byref(st), C.byref(bd)))
+        self.last_stats, self.last_breakdown = st, bd
         return mask[:mask_words(n)]
 
     def solve_device(self, d_starts, d_ends, n_reads, contig_lengths, max_coverage, d_mask,
@@ -451,14 +478,14 @@ def plugin_solve_timed(solver_name, starts, ends, ref_genome_length, max_coverag
     _need_host()
     starts, ends = _u32(starts), _u32(ends)
     kept = np.empty(max(starts.size, 1), dtype=np.uint64)
-    t = (C.c_float * 8)()
+    t = (C.c_float * 9)()
     n = _host.qmcp_host_plugin_solve_timed(solver_name.encode(), _p32(starts), _p32(ends), starts.size,
                                            int(ref_genome_length), int(max_coverage), _p64(kept), t)
     if n < 0:
         raise KeyError(solver_name)
     names = ("solve_call_ms", "library_ms", "narrow_h2d_ms", "device_solve_ms", "d2h_ms", "expand_ms")
     out = {k: round(float(t[i]), 3) for i, k in enumerate(names)}
-    out["host_threads"], out["chunks"] = int(t[6]), int(t[7])
+    out["host_threads"], out["chunks"], out["columns_sent"] = int(t[6]), int(t[7]), int(t[8])
     return kept[:n].copy(), out
 
 

@@ -517,6 +517,16 @@ void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uin
     hipLaunchKernelGGL(k_gstart, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, n, d_roff, d_poff,
                        n_contigs, gstart);
 }
+// ends of reads that all have one span (the 64-bit host entry then sends the starts only)
+__global__ __launch_bounds__(256) void k_fill_ends(const uint32_t* __restrict__ starts, uint32_t n,
+                                                  uint32_t span_minus_1, uint32_t* __restrict__ ends) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ends[i] = starts[i] + span_minus_1;
+}
+void launch_fill_ends(hipStream_t st, const uint32_t* starts, uint32_t n, uint32_t span_minus_1, uint32_t* ends) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill_ends, dim3(grid_for(n, 256 * 4)), dim3(256), 0, st, starts, n, span_minus_1, ends);
+}
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot

@@ -1035,11 +1035,49 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
     HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
     HIP_TRY(hipEventCreate(&t2)); HIP_TRY(hipEventCreate(&t3));
     int rc = QMCP_OK;
+    uint32_t sent_columns = 2;
     do {
         if (hipEventRecord(t0, c->stream) != hipSuccess) { rc = fail(QMCP_EHIP, "event record"); break; }
         if (nb) {
-            if (hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            // Large calls whose first reads all have one span: host threads check that every read has it
+            // while the starts are copied; if so the ends never cross the link -- the device rebuilds
+            // them (bit for bit: ends[i] == starts[i] + span mod 2^32 is what was checked).
+            bool ends_on_device = false;
+            const uint32_t span0 = ends[0] - starts[0];
+            bool speculate = n_reads >= (1u << 20) && std::getenv("QMCP_HIP_HOST_BOTH_COLUMNS") == nullptr;
+            for (size_t i = 0; speculate && i < 4096; ++i) speculate = ends[i] - starts[i] == span0;
+            if (speculate) {
+                unsigned T = 8;
+                if (const char* e = std::getenv("QMCP_HIP_HOST_THREADS")) T = (unsigned)std::strtoul(e, nullptr, 10);
+                const unsigned hw = std::thread::hardware_concurrency();
+                if (T < 1) T = 1;
+                if (hw != 0 && T > hw) T = hw;
+                std::atomic<uint32_t> differs{0};
+                const size_t n = (size_t)n_reads;
+                auto check = [&](unsigned t) {
+                    // interleaved 64 Ki-read pieces, so that all threads walk the columns front to back together
+                    constexpr size_t kPiece = 1u << 16;
+                    uint32_t d = 0;
+                    for (size_t lo = (size_t)t * kPiece; lo < n && differs.load(std::memory_order_relaxed) == 0; lo += (size_t)T * kPiece) {
+                        const size_t hi = lo + kPiece < n ? lo + kPiece : n;
+                        for (size_t i = lo; i < hi; ++i) d |= (ends[i] - starts[i]) ^ span0;
+                        if (d) differs.fetch_or(d, std::memory_order_relaxed);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < T; ++t) pool.emplace_back(check, t);
+                const bool copied = hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+                for (auto& th : pool) th.join();
+                if (!copied) { rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError())); break; }
+                ends_on_device = differs.load() == 0;
+                if (ends_on_device) sent_columns = 1;
+                if (ends_on_device)
+                    qmcp::launch_fill_ends(c->stream, (const uint32_t*)c->in_starts.p, (uint32_t)n_reads, span0, (uint32_t*)c->in_ends.p);
+            } else if (hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            if (!ends_on_device && hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
                 rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
                 break;
             }
@@ -1064,6 +1102,7 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
         if (stats) {
             stats->ms_h2d = elapsed(t0, t1);
             stats->ms_d2h = elapsed(t2, t3);
+            stats->columns_sent = sent_columns;
         }
     } while (0);
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
@@ -1132,11 +1171,25 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
         c->stage_done.push_back(e);
     }
     const clock::time_point t_copy = clock::now();
-    std::atomic<uint64_t> high_bits{0};
+    // One span for every read (all of reads-gen's inputs): only the starts cross the link and the device
+    // rebuilds the ends.  Taken on the evidence of the first reads, checked on all of them while they are
+    // narrowed; a call that turns out mixed after all sends its ends in a second pass.
+    uint64_t span0 = 0;
+    bool send_starts_only = n != 0 && end_inds[0] >= start_inds[0] && end_inds[0] - start_inds[0] < (1ull << 24) &&
+                            std::getenv("QMCP_HIP_HOST_BOTH_COLUMNS") == nullptr;
+    if (send_starts_only) {
+        span0 = end_inds[0] - start_inds[0];
+        const size_t probe = n < 4096 ? n : 4096;
+        uint64_t differs = 0;
+        for (size_t i = 0; i < probe; ++i) differs |= (end_inds[i] - start_inds[i]) ^ span0;
+        send_starts_only = differs == 0;
+    }
+    std::atomic<uint64_t> high_bits{0}, span_differs{0};
     std::atomic<int> hip_failed{0};
-    auto worker = [&](unsigned t) {
+    enum Pass { kBothColumns, kStartsChecked, kEndsOnly };
+    auto worker = [&](unsigned t, Pass pass) {
         if (hipSetDevice(c->device) != hipSuccess) { hip_failed = 1; return; }
-        uint64_t hi = 0;
+        uint64_t hi = 0, differs = 0;
         unsigned use = 0;
         hipStream_t cs = c->stage_streams[t % n_streams];
         for (size_t k = t; k < n_chunks; k += T, ++use) {
@@ -1148,23 +1201,46 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
             const size_t lo = k * kChunk, cnt = (lo + kChunk <= n ? kChunk : n - lo);
             const uint64_t* s64 = start_inds + lo;
             const uint64_t* e64 = end_inds + lo;
-            for (size_t i = 0; i < cnt; ++i) {  // (branch-free: the range check is one OR per element)
-                const uint64_t a = s64[i], b = e64[i];
-                hi |= a | b;
-                ss[i] = (uint32_t)a;
-                ee[i] = (uint32_t)b;
+            bool ok = true;
+            if (pass == kBothColumns) {
+                for (size_t i = 0; i < cnt; ++i) {  // (branch-free: the range check is one OR per element)
+                    const uint64_t a = s64[i], b = e64[i];
+                    hi |= a | b;
+                    ss[i] = (uint32_t)a;
+                    ee[i] = (uint32_t)b;
+                }
+                ok = hipMemcpyAsync((uint32_t*)c->in_starts.p + lo, ss, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) == hipSuccess &&
+                     hipMemcpyAsync((uint32_t*)c->in_ends.p + lo, ee, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) == hipSuccess;
+            } else if (pass == kStartsChecked) {
+                for (size_t i = 0; i < cnt; ++i) {
+                    const uint64_t a = s64[i], b = e64[i];
+                    hi |= a | b;
+                    differs |= (b - a) ^ span0;
+                    ss[i] = (uint32_t)a;
+                }
+                ok = hipMemcpyAsync((uint32_t*)c->in_starts.p + lo, ss, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) == hipSuccess;
+            } else {
+                for (size_t i = 0; i < cnt; ++i) ee[i] = (uint32_t)e64[i];  // (range-checked in the first pass)
+                ok = hipMemcpyAsync((uint32_t*)c->in_ends.p + lo, ee, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) == hipSuccess;
             }
-            if (hipMemcpyAsync((uint32_t*)c->in_starts.p + lo, ss, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
-                hipMemcpyAsync((uint32_t*)c->in_ends.p + lo, ee, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
-                hipEventRecord(ev, cs) != hipSuccess) { hip_failed = 1; return; }
+            if (!ok || hipEventRecord(ev, cs) != hipSuccess) { hip_failed = 1; return; }
         }
+        // the staging slots are this thread's own in every pass: drain its last two copies before another pass reuses them
+        for (unsigned u = 0; u < 2 && u < use; ++u)
+            if (pass != kBothColumns && hipEventSynchronize(c->stage_ev[(size_t)t * 2 + u]) != hipSuccess) { hip_failed = 1; return; }
         high_bits.fetch_or(hi >> 32);
+        span_differs.fetch_or(differs);
     };
-    {
+    auto run_pass = [&](Pass pass) {
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(worker, t);
-        worker(0);
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(worker, t, pass);
+        worker(0, pass);
         for (auto& th : pool) th.join();
+    };
+    run_pass(send_starts_only ? kStartsChecked : kBothColumns);
+    if (send_starts_only && span_differs.load() != 0 && !hip_failed.load() && high_bits.load() == 0) {
+        send_starts_only = false;
+        run_pass(kEndsOnly);
     }
     if (hip_failed.load()) return fail(QMCP_EHIP, "staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     if (high_bits.load() != 0) {
@@ -1176,6 +1252,8 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
         HIP_TRY(hipEventRecord(c->stage_done[i], c->stage_streams[i]));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->stage_done[i], 0));
     }
+    if (send_starts_only) qmcp::launch_fill_ends(c->stream, (const uint32_t*)c->in_starts.p, (uint32_t)n, (uint32_t)span0,
+                                                 (uint32_t*)c->in_ends.p);
     for (unsigned i = 0; i < n_streams; ++i) HIP_TRY(hipStreamSynchronize(c->stage_streams[i]));  // (for the breakdown)
     const float ms_copy = ms_since(t_copy);
     const clock::time_point t_solve = clock::now();
@@ -1190,7 +1268,7 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
         std::memcpy(keep_mask_out, c->h_mask, words * sizeof(uint64_t));
     }
     const float ms_d2h = ms_since(t_d2h);
-    if (stats) { stats->ms_h2d = ms_copy; stats->ms_d2h = ms_d2h; }
+    if (stats) { stats->ms_h2d = ms_copy; stats->ms_d2h = ms_d2h; stats->columns_sent = send_starts_only ? 1u : 2u; }
     if (breakdown) {
         breakdown->ms_total = ms_since(t_begin);
         breakdown->ms_narrow_h2d = ms_copy;
@@ -1198,6 +1276,7 @@ int qmcp_hip_solve_host64(qmcp_hip_ctx* c, const uint64_t* start_inds, const uin
         breakdown->ms_d2h = ms_d2h;
         breakdown->host_threads = T;
         breakdown->chunks = (uint32_t)n_chunks;
+        breakdown->columns_sent = send_starts_only ? 1u : 2u;
     }
     return QMCP_OK;
 }

@@ -142,6 +142,7 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
                             uint32_t* idx_out, uint32_t* range_start /* [257] */, uint32_t* max_load);
 void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
+void launch_fill_ends(hipStream_t st, const uint32_t* starts, uint32_t n, uint32_t span_minus_1, uint32_t* ends);
 void launch_range_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* range_start,
                           uint32_t shift, uint32_t ltot, uint32_t* boff,
                           uint32_t* empty_positions /* zeroed counter: positions that start no read; or null */);

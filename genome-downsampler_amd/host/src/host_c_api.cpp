@@ -233,7 +233,8 @@ std::int64_t qmcp_host_downsample_bam(const char* solver_name, const char* in_pa
 // The span the reference times as "solve took" (src/app.cpp:132-139) at the plugin boundary: a BamApi
 // that already holds the reads as SOAPairedReads (size_t columns) -> solver.solve(M, api) -> Solution.
 // Building the BamApi is outside the span, as parsing the BAM is in the reference.  `times` receives
-// {wall of solve(), library total, narrow + H2D, device solve, D2H, mask expansion, threads, chunks};
+// {wall of solve(), library total, narrow + H2D, device solve, D2H, mask expansion, threads, chunks,
+// columns sent};
 // returns the number of kept reads (kept_out may be NULL), negative on an unknown solver.
 std::int64_t qmcp_host_plugin_solve_timed(const char* solver_name, const std::uint32_t* starts,
                                           const std::uint32_t* ends, std::uint64_t n,
@@ -251,12 +252,13 @@ std::int64_t qmcp_host_plugin_solve_timed(const char* solver_name, const std::ui
     auto solution = solver.solve(max_coverage, api);
     const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (times) {
-        for (int i = 0; i < 8; ++i) times[i] = 0.f;
+        for (int i = 0; i < 9; ++i) times[i] = 0.f;
         times[0] = wall;
         if (auto* hip = dynamic_cast<qmcp::QuasiMcpHipSolver*>(&solver)) {
             const qmcp_hip_host_breakdown& b = hip->last_breakdown();
             times[1] = b.ms_total; times[2] = b.ms_narrow_h2d; times[3] = b.ms_solve; times[4] = b.ms_d2h;
             times[5] = hip->last_expand_ms(); times[6] = (float)b.host_threads; times[7] = (float)b.chunks;
+            times[8] = (float)b.columns_sent;
         }
     }
     if (kept_out) for (std::size_t i = 0; i < solution->size(); ++i) kept_out[i] = (*solution)[i];

@@ -88,6 +88,8 @@ typedef struct qmcp_hip_stats {
     float ms_mark;            /* keep-mask emission                                               */
     float ms_h2d;             /* host entry point only                                            */
     float ms_d2h;             /* host entry point only                                            */
+    uint32_t columns_sent;    /* host entry points only: 1 = every read has one span, only the starts
+                                 crossed the link and the device rebuilt the ends; 2 = both columns  */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);
@@ -136,6 +138,8 @@ typedef struct qmcp_hip_host_breakdown {
     float ms_d2h;          /* keep mask to the host                                                 */
     uint32_t host_threads; /* threads that narrowed                                                 */
     uint32_t chunks;
+    uint32_t columns_sent; /* 1: every read has one span, only the starts crossed the link (the device
+                              rebuilt the ends); 2: starts and ends                                   */
 } qmcp_hip_host_breakdown;
 int qmcp_hip_solve_host64(qmcp_hip_ctx* ctx,
                           const uint64_t* start_inds, const uint64_t* end_inds, uint64_t n_reads,
