@@ -129,8 +129,11 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* ctx,
  * quasi_mcp_cuda_max_flow_solver.hpp:19) runs here, chunk by chunk on several host threads into pinned
  * staging owned by the context, each chunk's host-to-device copy issued as soon as it is narrowed, so
  * the span the reference times as "solve took" (src/app.cpp:132-139) is the PCIe transfer plus little.
- * A coordinate above 2^32 - 1 fails with QMCP_ERANGE.  `breakdown` (may be NULL) receives host
- * wall-clock milliseconds of the call's parts. */
+ * A coordinate above 2^32 - 1 fails with QMCP_ERANGE.  When every read of the call has one span (checked
+ * on all of them while they are narrowed) only the starts cross the link and the device rebuilds the
+ * ends; qmcp_hip_solve_host does the same for calls of 2^20 reads or more (host threads check while
+ * the starts are copied).  `breakdown` (may be NULL) receives host wall-clock milliseconds of the
+ * call's parts. */
 typedef struct qmcp_hip_host_breakdown {
     float ms_total;        /* the whole call                                                        */
     float ms_narrow_h2d;   /* narrowing + host-to-device copies (overlapped with each other)        */
