@@ -896,6 +896,55 @@ int coverage_common(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* end
     return QMCP_OK;
 }
 
+// Host uint32 columns -> c->in_starts / c->in_ends on the solver stream.  Large calls whose first reads
+// all have one span: host threads check that every read has it while the starts are copied; if so the
+// ends never cross the link -- the device rebuilds them (bit for bit: ends[i] == starts[i] + span mod
+// 2^32 is what was checked, so invalid reads stay invalid).  *columns_sent: 1 or 2.
+int upload_columns(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t* ends, uint64_t n_reads,
+                   uint32_t* columns_sent) {
+    const size_t nb = (size_t)n_reads * sizeof(uint32_t);
+    *columns_sent = 2;
+    if (nb == 0) return QMCP_OK;
+    bool ends_on_device = false;
+    const uint32_t span0 = ends[0] - starts[0];
+    bool speculate = n_reads >= (1u << 20) && std::getenv("QMCP_HIP_HOST_BOTH_COLUMNS") == nullptr;
+    for (size_t i = 0; speculate && i < 4096; ++i) speculate = ends[i] - starts[i] == span0;
+    if (speculate) {
+        unsigned T = 8;
+        if (const char* e = std::getenv("QMCP_HIP_HOST_THREADS")) T = (unsigned)std::strtoul(e, nullptr, 10);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (T < 1) T = 1;
+        if (hw != 0 && T > hw) T = hw;
+        std::atomic<uint32_t> differs{0};
+        const size_t n = (size_t)n_reads;
+        auto check = [&](unsigned t) {
+            // interleaved 64 Ki-read pieces, so that all threads walk the columns front to back together
+            constexpr size_t kPiece = 1u << 16;
+            uint32_t d = 0;
+            for (size_t lo = (size_t)t * kPiece; lo < n && differs.load(std::memory_order_relaxed) == 0; lo += (size_t)T * kPiece) {
+                const size_t hi = lo + kPiece < n ? lo + kPiece : n;
+                for (size_t i = lo; i < hi; ++i) d |= (ends[i] - starts[i]) ^ span0;
+                if (d) differs.fetch_or(d, std::memory_order_relaxed);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t) pool.emplace_back(check, t);
+        const bool copied = hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        for (auto& th : pool) th.join();
+        if (!copied) return fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+        ends_on_device = differs.load() == 0;
+        if (ends_on_device) {
+            *columns_sent = 1;
+            qmcp::launch_fill_ends(c->stream, (const uint32_t*)c->in_starts.p, (uint32_t)n_reads, span0, (uint32_t*)c->in_ends.p);
+        }
+    } else if (hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        return fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (!ends_on_device && hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return QMCP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1039,48 +1088,8 @@ int qmcp_hip_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const uint32_t*
     do {
         if (hipEventRecord(t0, c->stream) != hipSuccess) { rc = fail(QMCP_EHIP, "event record"); break; }
         if (nb) {
-            // Large calls whose first reads all have one span: host threads check that every read has it
-            // while the starts are copied; if so the ends never cross the link -- the device rebuilds
-            // them (bit for bit: ends[i] == starts[i] + span mod 2^32 is what was checked).
-            bool ends_on_device = false;
-            const uint32_t span0 = ends[0] - starts[0];
-            bool speculate = n_reads >= (1u << 20) && std::getenv("QMCP_HIP_HOST_BOTH_COLUMNS") == nullptr;
-            for (size_t i = 0; speculate && i < 4096; ++i) speculate = ends[i] - starts[i] == span0;
-            if (speculate) {
-                unsigned T = 8;
-                if (const char* e = std::getenv("QMCP_HIP_HOST_THREADS")) T = (unsigned)std::strtoul(e, nullptr, 10);
-                const unsigned hw = std::thread::hardware_concurrency();
-                if (T < 1) T = 1;
-                if (hw != 0 && T > hw) T = hw;
-                std::atomic<uint32_t> differs{0};
-                const size_t n = (size_t)n_reads;
-                auto check = [&](unsigned t) {
-                    // interleaved 64 Ki-read pieces, so that all threads walk the columns front to back together
-                    constexpr size_t kPiece = 1u << 16;
-                    uint32_t d = 0;
-                    for (size_t lo = (size_t)t * kPiece; lo < n && differs.load(std::memory_order_relaxed) == 0; lo += (size_t)T * kPiece) {
-                        const size_t hi = lo + kPiece < n ? lo + kPiece : n;
-                        for (size_t i = lo; i < hi; ++i) d |= (ends[i] - starts[i]) ^ span0;
-                        if (d) differs.fetch_or(d, std::memory_order_relaxed);
-                    }
-                };
-                std::vector<std::thread> pool;
-                for (unsigned t = 0; t < T; ++t) pool.emplace_back(check, t);
-                const bool copied = hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-                for (auto& th : pool) th.join();
-                if (!copied) { rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError())); break; }
-                ends_on_device = differs.load() == 0;
-                if (ends_on_device) sent_columns = 1;
-                if (ends_on_device)
-                    qmcp::launch_fill_ends(c->stream, (const uint32_t*)c->in_starts.p, (uint32_t)n_reads, span0, (uint32_t*)c->in_ends.p);
-            } else if (hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-                rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
-                break;
-            }
-            if (!ends_on_device && hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-                rc = fail(QMCP_EHIP, "H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
-                break;
-            }
+            rc = upload_columns(c, starts, ends, n_reads, &sent_columns);
+            if (rc != QMCP_OK) break;
         }
         (void)hipEventRecord(t1, c->stream);
         c->mask_reads = 0;
@@ -1453,8 +1462,8 @@ int qmcp_hip_filter_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const ui
     TRY(ensure(c, c->mask, words * 8));
     TRY(ensure(c, c->cov, words * 8 + 16));  // compact-index keep mask
     TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries((uint32_t)pwords + 1) + 1) * 4 + 16));
-    HIP_TRY(hipMemcpyAsync(c->in_starts.p, starts, nb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->in_ends.p, ends, nb, hipMemcpyHostToDevice, st));
+    uint32_t sent_columns = 2;
+    TRY(upload_columns(c, starts, ends, n_reads, &sent_columns));
     const uint32_t* d_len = nullptr;
     const uint32_t* d_q = nullptr;
     if (seq_lengths) {
@@ -1519,6 +1528,7 @@ int qmcp_hip_filter_solve_host(qmcp_hip_ctx* c, const uint32_t* starts, const ui
     HIP_TRY(hipMemcpyAsync(keep_mask_out, c->mask.p, words * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     c->mask_reads = n_reads;
+    if (stats) stats->columns_sent = sent_columns;
     return QMCP_OK;
 }
 
