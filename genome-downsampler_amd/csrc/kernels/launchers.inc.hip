@@ -106,7 +106,9 @@ uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs) 
     return (uint32_t)(w < 2 ? 0 : (w > cap ? cap : w));
 }
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
-    return (size_t)n_windows + 1 + 3 * ((size_t)n_contigs + n_windows);
+    // the windows' cuts, then two tables (with speculative boundaries, and the exact one): count,
+    // {start, end, contig end} and the owned-from position per stretch
+    return (size_t)n_windows + 2 * (1 + 4 * ((size_t)n_contigs + n_windows));
 }
 // fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
@@ -117,8 +119,28 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
     hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, eoff, d_poff, n_contigs, ltot, ell, M, win, cut);
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
-                       ltot, seg);
+                       ltot, win, 0u, 1u, seg, (uint32_t*)nullptr);
     return seg;
+}
+// the same windows' second table: speculative boundaries where a window has no cut (behind the exact
+// table in seg_words; launch_sweep_segments comes first)
+const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
+                                                  uint32_t ltot, uint32_t n_windows, uint32_t burn,
+                                                  uint32_t* seg_words, uint32_t* n_speculative) {
+    // candidates four run-ins apart at least
+    const uint32_t win0 = (ltot + n_windows - 1) / n_windows;
+    const uint32_t stride = (uint32_t)((4ull * burn + win0 - 1) / win0);
+    const uint32_t* cut = seg_words;
+    uint32_t* seg = seg_words + n_windows + 1 + 4 * ((size_t)n_contigs + n_windows);
+    const uint32_t win = (ltot + n_windows - 1) / n_windows;
+    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
+                       ltot, win, burn, stride < 1 ? 1u : stride, seg, n_speculative);
+    return seg;
+}
+void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
+                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches) {
+    hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, out_even, out_odd, mismatches);
+    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, mismatches);
 }
 
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
@@ -149,7 +171,8 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
-                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max) {
+                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
+                              uint32_t* selend_odd, const uint32_t* run_if_nonzero) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_GEN(EE)                                                                             \
@@ -158,7 +181,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,      \
-                           ell, M, ltot, selend, iter_stats, seg);                                           \
+                           ell, M, ltot, selend, iter_stats, seg, selend_odd, run_if_nonzero);               \
     }
     switch (e) {
         case 1: QMCP_SWEEP_GEN(1); break;

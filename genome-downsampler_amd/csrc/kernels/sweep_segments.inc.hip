@@ -48,31 +48,67 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
     if (threadIdx.x == 0) cut[w] = s_first;
 }
 
+// Speculative boundaries (burn != 0).  On data a few times deeper than M cut points are rare, but the
+// greedy FORGETS where it started: two sweeps of the same positions from different states select the
+// same reads from some point on (measured: within 25-60 blocks at a depth of 2 x M, hundreds at 4 x M,
+// never on deep data), because the state is only the kept counts of the last ell start positions and the
+// sparse counts keep forcing it.  So a window without a cut still gets a boundary at its first position b:
+// its stretch starts `burn` positions earlier from the state of a cut point (every read over the start
+// kept) and OWNS the positions from b on (only every stride-th window is a candidate, so that stretches stay
+// several run-ins long); the stretch before it runs up to b as before.  The two have
+// then both computed [b - burn, b), into separate outputs (stretches alternate between two), and
+// k_spec_verify compares the last ell positions before b: equal kept counts there are equal states, so
+// everything the speculative stretch selected from b on is what the serial sweep selects.  One mismatch
+// anywhere and the whole sweep is redone on the exact table (k_spec_verify's counter gates both).
+// Table: [count, {start, end, contig end} per stretch, then the position each stretch owns from].
 __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint32_t* __restrict__ cut,
                                                                       uint32_t n_windows,
                                                                       const uint64_t* __restrict__ contig_pos_off,
                                                                       uint32_t n_contigs, uint32_t ltot,
-                                                                      uint32_t* __restrict__ seg) {
+                                                                      uint32_t win, uint32_t burn, uint32_t stride,
+                                                                      uint32_t* __restrict__ seg,
+                                                                      uint32_t* __restrict__ n_speculative /* += ; or null */) {
     __shared__ uint32_t s_pos[kSegMaxCandidates];
     __shared__ uint32_t s_sorted[kSegMaxCandidates];
-    __shared__ uint32_t s_count;
+    __shared__ uint32_t s_count, s_spec;
     const uint32_t t = threadIdx.x;
+    const uint32_t n_cand = n_contigs + n_windows;
     uint32_t mine = kNoCut;
+    bool spec = false;
     if (t < n_contigs) {
         if (contig_pos_off[t + 1] > contig_pos_off[t]) mine = (uint32_t)contig_pos_off[t];  // empty contigs: no work
     } else if (t - n_contigs < n_windows) {
-        mine = cut[t - n_contigs];
+        const uint32_t w = t - n_contigs;
+        mine = cut[w];
+        if (mine == kNoCut && burn != 0 && w >= 1 && w % stride == 0 && (uint64_t)w * win < ltot) {
+            mine = w * win;
+            spec = true;
+        }
     }
+    s_pos[t] = spec ? kNoCut : mine;  // the exact boundaries first
+    if (t == 0) { s_count = 0; s_spec = 0; }
+    __syncthreads();
+    if (spec) {
+        // the run-in must lie inside one stretch: no exact boundary in (mine - burn, mine]
+        bool ok = mine >= burn;
+        for (uint32_t k = 0; k < n_cand; ++k) {
+            const uint32_t q = s_pos[k];
+            if (q != kNoCut && q <= mine && q + burn > mine) ok = false;
+        }
+        if (!ok) { mine = kNoCut; spec = false; }
+    }
+    __syncthreads();
     s_pos[t] = mine;
-    if (t == 0) s_count = 0;
     __syncthreads();
     uint32_t rank = 0;
     if (mine != kNoCut) {
         // candidates are distinct: non-empty contigs start at distinct positions, windows are
-        // disjoint, and a cut is never a contig's first position
-        for (uint32_t k = 0; k < n_contigs + n_windows; ++k) rank += s_pos[k] < mine ? 1u : 0u;
+        // disjoint, a cut is never a contig's first position, and a speculative boundary has no exact one
+        // within `burn` before it
+        for (uint32_t k = 0; k < n_cand; ++k) rank += s_pos[k] < mine ? 1u : 0u;
         s_sorted[rank] = mine;
         atomicAdd(&s_count, 1u);
+        if (spec) atomicAdd(&s_spec, 1u);
     }
     __syncthreads();
     if (mine != kNoCut) {
@@ -83,9 +119,40 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
             if (a <= mine && mine < b) cend = b;
         }
         const uint32_t next = rank + 1 < count ? s_sorted[rank + 1] : ltot;
-        seg[1 + 3 * rank + 0] = mine;
+        seg[1 + 3 * rank + 0] = spec ? mine - burn : mine;
         seg[1 + 3 * rank + 1] = min(next, cend);
         seg[1 + 3 * rank + 2] = cend;
+        seg[1 + 3 * n_cand + rank] = mine;
         if (rank == 0) seg[0] = count;
     }
+    if (t == 0 && n_speculative != nullptr) *n_speculative = s_spec;
+}
+
+// one workgroup per stretch: a speculative one compares its own last ell positions before the position it
+// owns from with what the stretch before it (the other output) holds there
+__global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t ell,
+                                                     const uint32_t* __restrict__ out_even,
+                                                     const uint32_t* __restrict__ out_odd,
+                                                     uint32_t* __restrict__ mismatches) {
+    const uint32_t r = blockIdx.x;
+    if (r >= seg[0]) return;
+    const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
+    if (own == start) return;  // an exact boundary
+    const uint32_t* mine = (r & 1u) ? out_odd : out_even;
+    const uint32_t* prev = (r & 1u) ? out_even : out_odd;
+    bool differs = false;
+    for (uint32_t i = threadIdx.x; i < ell; i += blockDim.x) differs |= mine[own - ell + i] != prev[own - ell + i];
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+}
+
+// the odd stretches' own positions move to the even output (which the ranking reads), unless the
+// speculation failed (then the exact sweep that follows writes all of it)
+__global__ __launch_bounds__(256) void k_spec_merge(const uint32_t* __restrict__ seg, uint32_t n_cand,
+                                                    uint32_t* __restrict__ out_even,
+                                                    const uint32_t* __restrict__ out_odd,
+                                                    const uint32_t* __restrict__ mismatches) {
+    const uint32_t r = blockIdx.x;
+    if ((r & 1u) == 0 || r >= seg[0] || *mismatches != 0) return;
+    const uint32_t own = seg[1 + 3 * n_cand + r], end = seg[1 + 3 * r + 1];
+    for (uint32_t p = own + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
 }

@@ -540,8 +540,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                            uint32_t ell, uint32_t M, uint32_t ltot,
                                                            uint32_t* __restrict__ selend,
                                                            uint32_t* __restrict__ iter_stats,
-                                                           const uint32_t* __restrict__ seg) {
+                                                           const uint32_t* __restrict__ seg,
+                                                           uint32_t* __restrict__ selend_odd /* odd stretches' output; or null */,
+                                                           const uint32_t* __restrict__ run_if_nonzero /* or null */) {
     using Ly = MgLayout<E>;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;  // (the exact sweep behind a speculation that held)
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
     const uint32_t lane = threadIdx.x & 63;
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     const uint32_t n_blocks = (Lrun + ell - 1) / ell;
     const uint32_t n_groups = n_blocks / kG;
     const uint32_t* __restrict__ cb = boff + base;
-    uint32_t* __restrict__ csel = selend + base;
+    uint32_t* __restrict__ csel = (selend_odd != nullptr && (c_id & 1u) ? selend_odd : selend) + base;
     const uint32_t trash = ltot - base;
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
     __builtin_amdgcn_s_setprio(3);

@@ -315,6 +315,16 @@ uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, boo
     return on ? qmcp::sweep_segment_windows(ltot, span, n_contigs) : 0u;
 }
 
+// Speculative stretch boundaries: below this mean coverage (in units of M), with a run-in (in blocks)
+// that grows with the depth.  lab/spec_burn_study.py, cfg5's shape at 1/32 scale, boundaries that
+// disagreed at a run-in of 128 / 256 / 512 / 1024 blocks: depth 2.0: 2 of 364 / 0 / 0 / 0; 2.5: 67 of 364 /
+// 1 of 240 / 0 / 0; 3.0: 157 / 28 / 0 of 118 / 0; 4.0: 273 / 86 / 6 of 118 / 0 of 56 -- about twice
+// the run-in per half unit of depth; the table keeps a factor of two to three above the longest seen.
+constexpr double kSpecDepth = 4.1;
+uint32_t spec_burn_blocks(double depth) {
+    return depth < 2.1 ? 384u : depth < 2.6 ? 768u : depth < 3.1 ? 1280u : 2560u;
+}
+
 int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
                          uint32_t span, uint32_t M, uint32_t* d_iters, uint32_t empty_positions) {
     // mean coverage in units of M: the fast form needs the binding jumps to come from the previous
@@ -332,6 +342,17 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     const uint32_t* seg = nullptr;
     uint32_t n_seg_max = 0;
     const uint32_t windows = sweep_cut_windows(ltot, span, n_contigs, gen);
+    // Data a few times deeper than M: hardly any cut points, but the sweep forgets its start within tens
+    // of blocks (kernels/sweep_segments.inc.hip), so windows without a cut get a speculative boundary with a
+    // run-in (every few windows, so that stretches stay several run-ins long); the stretches' outputs are compared where they
+    // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
+    // returns at once when all agreed).
+    bool speculate = depth < kSpecDepth;
+    if (const char* e = std::getenv("QMCP_HIP_SPEC")) speculate = e[0] == '1';  // (0 / 1: never / at any depth the general form sweeps)
+    speculate = speculate && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span);
+    uint32_t burn_blocks = spec_burn_blocks(depth);
+    if (const char* e = std::getenv("QMCP_HIP_SPEC_BURN")) burn_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (speculate && (burn_blocks < 2 || (uint64_t)ltot < 8ull * burn_blocks * span)) speculate = false;
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);
         seg = qmcp::launch_sweep_segments(st, boff, nullptr, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
@@ -376,6 +397,32 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, sev, lastns, selend);
         return QMCP_OK;
     }
+    if (speculate && seg != nullptr) {
+        {
+            uint32_t* mismatches = (uint32_t*)((char*)c->scalars.p + 32);
+            uint32_t* n_spec = mismatches + 1;
+            uint32_t* out_odd = (uint32_t*)c->cstart.p;
+            const uint32_t* seg_spec;
+            {
+                KernelSpan sp(c, "k_find_cuts", st);
+                seg_spec = qmcp::launch_sweep_segments_speculative(st, poff, n_contigs, ltot, windows, burn_blocks * span,
+                                                                   (uint32_t*)c->segs.p, n_spec);
+            }
+            {
+                KernelSpan sp(c, "k_sweep_uniform_gen", st);
+                (void)qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg_spec,
+                                                     n_seg_max, out_odd, nullptr);
+            }
+            {
+                KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
+                qmcp::launch_spec_verify_merge(st, seg_spec, n_seg_max, span, selend, out_odd, mismatches);
+            }
+            KernelSpan sp(c, "k_sweep_uniform_gen (exact, if the speculation failed)", st);
+            (void)qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max,
+                                                 nullptr, mismatches);
+            return QMCP_OK;
+        }
+    }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
         const bool ok = gen ? qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max)
@@ -396,7 +443,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
                   uint32_t M, uint64_t* d_mask) {
     if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
     c->pend_spiky = false;
-    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 6 * sizeof(unsigned long long), hipHostMallocDefault));
     Problem pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n;
@@ -412,7 +459,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
         HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
         for (int i = EV_PREP; i <= EV_MARK; ++i) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
-        c->h_scalars[0] = c->h_scalars[1] = c->h_scalars[2] = c->h_scalars[3] = 0;
+        c->h_scalars[0] = c->h_scalars[1] = c->h_scalars[2] = c->h_scalars[3] = c->h_scalars[4] = 0;
         c->pend_stats = local;
         c->pend_whole_contig_chains = 0;
         c->pending = true;
@@ -768,11 +815,11 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));
     c->pend_spiky = ranked_counted;
     if (ranked_counted) {
-        HIP_TRY(hipMemcpyAsync(c->h_scalars + 4, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_scalars + 5, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         c->spiky_n = n64;
         c->spiky_ltot = pr.ltot;
     }
@@ -801,13 +848,15 @@ int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     qmcp_hip_stats local = c->pend_stats;
     const unsigned long long* host_scalars = c->h_scalars;
     if (c->pend_spiky) {
-        c->spiky_empty = (uint32_t)(c->h_scalars[4] & 0xFFFFFFFFull);
+        c->spiky_empty = (uint32_t)(c->h_scalars[5] & 0xFFFFFFFFull);
         c->spiky_known = true;
     }
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
     local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu) + c->pend_whole_contig_chains;
+    local.spec_mismatches = (uint32_t)(host_scalars[4] & 0xFFFFFFFFu);
+    local.spec_boundaries = (uint32_t)(host_scalars[4] >> 32);
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);

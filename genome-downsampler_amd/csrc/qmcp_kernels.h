@@ -51,10 +51,21 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
 // seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
+// selend_odd (or null): odd stretches write there instead (speculative tables: neighbours overlap);
+// run_if_nonzero (or null): the launch does nothing unless that device word is non-zero
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
-                              uint32_t n_seg_max);
+                              uint32_t n_seg_max, uint32_t* selend_odd = nullptr,
+                              const uint32_t* run_if_nonzero = nullptr);
+// Speculative boundaries (kernels/sweep_segments.inc.hip): the second table of the same windows, with a
+// boundary `burn` positions of run-in wide wherever a window has no cut (call launch_sweep_segments
+// first; *n_speculative receives how many), and the check + merge of the two outputs behind the sweep.
+const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
+                                                  uint32_t ltot, uint32_t n_windows, uint32_t burn,
+                                                  uint32_t* seg_words, uint32_t* n_speculative);
+void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
+                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,

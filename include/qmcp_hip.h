@@ -90,6 +90,10 @@ typedef struct qmcp_hip_stats {
     float ms_d2h;             /* host entry point only                                            */
     uint32_t columns_sent;    /* host entry points only: 1 = every read has one span, only the starts
                                  crossed the link and the device rebuilt the ends; 2 = both columns  */
+    uint32_t spec_boundaries; /* stretches that started at a speculative boundary (data a few times
+                                 deeper than M: no cut point, but the sweep forgets its start)      */
+    uint32_t spec_mismatches; /* of those, how many disagreed with the stretch before them; non-zero:
+                                 the exact sweep was run after the speculative one                  */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);

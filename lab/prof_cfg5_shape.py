@@ -16,6 +16,6 @@ for _ in range(3):
     sol.solve(s, e, lengths, 50, contig_read_offsets=offs)
 st = sol.last_stats
 print(f"N = {s.size}, Ltot = {int(lengths.sum())}, contigs = {lengths.size}, device ms = {st.ms_total:.2f}, "
-      f"sweep ms = {st.ms_sweep:.2f}, kept = {st.n_kept}, sort passes = {st.sort_passes}, stretches = {st.sweep_stretches}")
+      f"sweep ms = {st.ms_sweep:.2f}, kept = {st.n_kept}, sort passes = {st.sort_passes}, stretches = {st.sweep_stretches} (speculative {st.spec_boundaries}, mismatching {st.spec_mismatches})")
 for name, (launches, ms) in sorted(sol.kernel_times().items(), key=lambda kv: -kv[1][1])[:8]:
     print(f"  {name:36s} {ms / launches:.3f} ms avg")

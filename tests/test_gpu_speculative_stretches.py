@@ -1,0 +1,103 @@
+"""Speculative stretch boundaries (csrc/kernels/sweep_segments.inc.hip): on data a few times deeper than M
+there are hardly any cut points, but two sweeps of the same positions from different states agree from
+some point on.  Windows without a cut therefore start a stretch with a run-in from the state of a cut
+point; where it meets the stretch before it the two outputs are compared, and one disagreement anywhere
+re-runs the exact sweep.  Whatever happens the kept set must be the oracle's, bit for bit."""
+import os
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@contextmanager
+def _env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    try:
+        for k, v in kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _uniform_contigs(rng, lengths, depth_in_m, M, span):
+    """reads of one span, uniformly placed, mean coverage depth_in_m * M on every contig"""
+    ss, ee, offs = [], [], [0]
+    for L in lengths:
+        n = int(depth_in_m * M * L / span)
+        s = rng.integers(0, L - span + 1, size=n, dtype=np.uint32)
+        ss.append(s)
+        ee.append(s + np.uint32(span - 1))
+        offs.append(offs[-1] + n)
+    return np.concatenate(ss), np.concatenate(ee), np.asarray(offs, np.uint64), np.asarray(lengths, np.uint32)
+
+
+@pytest.mark.parametrize("span,M,depth", [(150, 50, 2.0), (150, 30, 1.6), (100, 40, 2.4), (250, 60, 2.0), (40, 20, 2.0)])
+def test_speculative_boundaries_hold_and_change_nothing(pkg, oracle, solver, span, M, depth):
+    rng = np.random.default_rng(span + M)
+    s, e, offs, lengths = _uniform_contigs(rng, [2_400_000, 700_000, 1_300_000], depth, M, span)
+    with _env(QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.path == pkg.PATH_UNIFORM and st.spec_mismatches == 0, st.as_dict()
+    if depth >= 2.0:   # (shallower: nearly every window has a real cut point)
+        assert st.spec_boundaries >= 2, st.as_dict()
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want)
+    with _env(QMCP_HIP_SPEC="0"):
+        plain = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        assert solver.last_stats.spec_boundaries == 0
+    assert np.array_equal(plain, want)
+
+
+def test_a_run_in_that_is_too_short_is_noticed_and_the_exact_sweep_takes_over(pkg, oracle, solver):
+    rng = np.random.default_rng(8)
+    s, e, offs, lengths = _uniform_contigs(rng, [3_000_000], 2.0, 50, 150)
+    want = oracle.solve(s, e, lengths, 50, contig_read_offsets=offs)
+    with _env(QMCP_HIP_SPEC_BURN="4"):
+        got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.spec_boundaries > 0 and st.spec_mismatches > 0, st.as_dict()
+    assert np.array_equal(got, want)
+    with _env(QMCP_HIP_SPEC_BURN="2"):
+        assert np.array_equal(solver.solve(s, e, lengths, 50, contig_read_offsets=offs), want)
+
+
+def test_speculation_beside_real_cut_points_and_gaps(pkg, oracle, solver):
+    """stretches of 2 x M separated by shallow runs and holes: exact and speculative boundaries in one table"""
+    rng = np.random.default_rng(99)
+    L, M, span = 4_000_000, 40, 150
+    parts = []
+    for lo, hi, depth in ((0, 900_000, 2.0), (900_000, 1_000_000, 0.5), (1_000_000, 2_600_000, 2.2),
+                          (2_700_000, 3_999_000, 1.9)):
+        n = int(depth * M * (hi - lo) / span)
+        parts.append(rng.integers(lo, hi - span + 1, size=n, dtype=np.uint32))
+    s = np.concatenate(parts)
+    s = s[rng.permutation(s.size)]
+    e = s + np.uint32(span - 1)
+    with _env(QMCP_HIP_SPEC="1"):
+        got = solver.solve(s, e, L, M)
+        st = solver.last_stats
+    assert st.spec_boundaries > 0
+    assert np.array_equal(got, oracle.solve(s, e, L, M))
+
+
+def test_deeper_data_forced_to_speculate_falls_back_exactly(pkg, oracle, solver):
+    """at 6 x M the sweep does not forget its start within the run-in: every boundary disagrees"""
+    rng = np.random.default_rng(5)
+    s, e, offs, lengths = _uniform_contigs(rng, [1_500_000], 6.0, 20, 150)
+    with _env(QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="64"):
+        got = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.spec_boundaries > 0 and st.spec_mismatches > 0
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 20, contig_read_offsets=offs))
