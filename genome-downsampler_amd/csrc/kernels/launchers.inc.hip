@@ -126,16 +126,25 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
 // table in seg_words; launch_sweep_segments comes first)
 const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
                                                   uint32_t ltot, uint32_t n_windows, uint32_t burn,
-                                                  uint32_t* seg_words, uint32_t* n_speculative) {
-    // candidates four run-ins apart at least
+                                                  uint32_t* seg_words, uint32_t* n_speculative, uint32_t run_ins_apart) {
+    // candidates this many run-ins apart at least (>= 2)
     const uint32_t win0 = (ltot + n_windows - 1) / n_windows;
-    const uint32_t stride = (uint32_t)((4ull * burn + win0 - 1) / win0);
+    const uint32_t stride = (uint32_t)(((uint64_t)run_ins_apart * burn + win0 - 1) / win0);
     const uint32_t* cut = seg_words;
     uint32_t* seg = seg_words + n_windows + 1 + 4 * ((size_t)n_contigs + n_windows);
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, burn, stride < 1 ? 1u : stride, seg, n_speculative);
     return seg;
+}
+size_t spec_snap_bytes(uint32_t n_cand) { return (size_t)n_cand * kSpecSnapWords * sizeof(uint32_t); }
+void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t max_span,
+                                    uint32_t* out_even, const uint32_t* out_odd, const uint32_t* snap,
+                                    uint32_t* mismatches) {
+    hipLaunchKernelGGL(k_spec_verify_mixed, dim3(n_cand), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd, snap,
+                       kSpecSnapWords, mismatches);
+    hipLaunchKernelGGL(k_spec_merge_mixed, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd,
+                       mismatches);
 }
 void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                               uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches) {
@@ -342,7 +351,8 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
 bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
-                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max) {
+                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max,
+                              uint32_t* selend_odd, const uint32_t* run_if_nonzero, uint32_t* snap) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t b = (max_span + 64 + 63) / 64;
 #ifdef QMCP_GEN_STAMP
@@ -354,11 +364,11 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
     if (wide)                                                                                          \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
-                           max_span, M, selend, seg QMCP_GEN_STAMP_ARG);                               \
+                           max_span, M, selend, seg, selend_odd, run_if_nonzero, n_seg_max, snap QMCP_GEN_STAMP_ARG); \
     else                                                                                               \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
-                           M, selend, seg QMCP_GEN_STAMP_ARG);
+                           M, selend, seg, selend_odd, run_if_nonzero, n_seg_max, snap QMCP_GEN_STAMP_ARG);
     // loader waves per walker: few workgroups (contigs) -> many loaders, so the walker never waits for an
     // entering chunk's three trips to memory; many workgroups (stretches) fill the chip by themselves
     // and extra waves only get in the walkers' way

@@ -345,12 +345,18 @@ __device__ __forceinline__ uint32_t reg_sweep_key(uint32_t gx, uint32_t gy, uint
     return gy != 0 ? (((gx - pbase) << 16) | (qrel << 7) | min(gy, 127u)) : 0u;
 }
 
+static constexpr uint32_t kSpecSnapWords = 512;  // >= the register sweep's window of live buckets
+
 template <typename Sorted, int B, int kRegLoaders>
 __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     const uint32_t* __restrict__ boff, const uint32_t* __restrict__ eoff, Sorted skeys,
     const uint32_t* __restrict__ next_head, const uint64_t* __restrict__ contig_pos_off,
     uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend,
-    const uint32_t* __restrict__ seg
+    const uint32_t* __restrict__ seg,
+    uint32_t* __restrict__ selend_odd /* odd stretches' output (speculative tables); or null */,
+    const uint32_t* __restrict__ run_if_nonzero /* or null */,
+    uint32_t n_cand /* speculative tables: entries per column of seg */,
+    uint32_t* __restrict__ snap /* speculative tables: kSpecSnapWords per stretch */
 #ifdef QMCP_GEN_STAMP
     , unsigned long long* __restrict__ stamps  // lab builds: [0] entry cycles [1] events [2] event cycles [3] fetches [4] fetch cycles [5] walk cycles
 #endif
@@ -370,6 +376,7 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 walker, 1.. loaders
     const uint32_t c_id = blockIdx.x;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;  // (the exact sweep behind a speculation that held)
     SweepSeg sg;
     if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
     const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     __syncthreads();
     const uint32_t* __restrict__ cb = boff + base;
     const uint32_t* __restrict__ ce = eoff + base;
-    uint32_t* __restrict__ csel = selend + base;
+    uint32_t* __restrict__ csel = (selend_odd != nullptr && (c_id & 1u) ? selend_odd : selend) + base;
     // per owned bucket: head group (end + 1, run), cached second group, next unread group, bucket
     // start and end, reads selected so far
     uint32_t g0x[B], g0y[B], g1x[B], g1y[B], nextj[B], bstart[B], bend1[B], taken[B];
@@ -391,6 +398,16 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
         __syncthreads();
     }
     const uint32_t n_chunks = (L + 63) / 64;
+    // A speculative stretch owns the positions from `own` on and runs in from `base` (a multiple of 64
+    // positions earlier).  When it reaches `own` it records, for the buckets still alive, how many reads
+    // each has given so far: the whole state of the walk at that point, which k_spec_verify_mixed compares
+    // with what the stretch before it -- which ends there -- left behind.
+    uint32_t snap_chunk = 0xFFFFFFFFu;
+    if (selend_odd != nullptr && seg != nullptr) {
+        const uint32_t own = seg[1 + 3 * n_cand + c_id];
+        if (own != base) snap_chunk = (own - base) / 64u;
+    }
+    uint32_t* const my_snap = snap + (size_t)c_id * kSpecSnapWords;
 
     auto load_group = [&](uint32_t j, uint32_t b1, uint32_t q, uint32_t& gx, uint32_t& gy) {
         // group starting at sorted index j of the bucket of position q ending at b1 (gy = 0: none)
@@ -449,6 +466,15 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
             {
                 const uint32_t qq = q - kRing;
                 if (c >= (uint32_t)B && qq < L) csel[qq] = bstart[e] + taken[e];
+            }
+            if (c == snap_chunk) {
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (b != e) {
+                        const uint32_t back = 64u * (uint32_t)((e - b + B) % B);  // chunks ago, in positions
+                        if (p0 >= back) my_snap[(base + p0 - back + lane) % kSpecSnapWords] = bstart[b] + taken[b];
+                    }
+                }
             }
             {
                 // chunk c is the (c / kRegLoaders + 1)-th of loader c % kRegLoaders

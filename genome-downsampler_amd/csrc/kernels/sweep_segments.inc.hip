@@ -156,3 +156,46 @@ __global__ __launch_bounds__(256) void k_spec_merge(const uint32_t* __restrict__
     const uint32_t own = seg[1 + 3 * n_cand + r], end = seg[1 + 3 * r + 1];
     for (uint32_t p = own + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
 }
+
+// Mixed spans (the register-resident event sweep): a bucket keeps giving reads while any of them is alive,
+// so what the stretch before a speculative boundary left in its output for the last W = max_span start
+// positions is the count "so far", and the speculative stretch recorded its own counts so far when it
+// reached the boundary (k_sweep_general_reg, `snap`): equal counts are equal states of the walk.
+__global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t W,
+                                                           const uint32_t* __restrict__ out_even,
+                                                           const uint32_t* __restrict__ out_odd,
+                                                           const uint32_t* __restrict__ snap, uint32_t snap_words,
+                                                           uint32_t* __restrict__ mismatches) {
+    const uint32_t r = blockIdx.x;
+    if (r >= seg[0]) return;
+    const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
+    if (own == start) return;  // an exact boundary
+    const uint32_t* prev = (r & 1u) ? out_even : out_odd;
+    const uint32_t* mine = snap + (size_t)r * snap_words;
+    bool differs = false;
+    for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
+        const uint32_t p = own - W + i;
+        differs |= mine[p % snap_words] != prev[p];
+    }
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+}
+
+// ... and the final counts of those W positions are the speculative stretch's: an odd stretch's range
+// moves to the even output from W before the position it owns from (if it is speculative) up to W
+// before its end (if the next one is)
+__global__ __launch_bounds__(256) void k_spec_merge_mixed(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t W,
+                                                          uint32_t* __restrict__ out_even,
+                                                          const uint32_t* __restrict__ out_odd,
+                                                          const uint32_t* __restrict__ mismatches) {
+    const uint32_t r = blockIdx.x;
+    const uint32_t count = seg[0];
+    if ((r & 1u) == 0 || r >= count || *mismatches != 0) return;
+    const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
+    uint32_t from = own != start ? own - W : own;
+    uint32_t end = seg[1 + 3 * r + 1];
+    if (r + 1 < count) {
+        const uint32_t nstart = seg[1 + 3 * (r + 1)], nown = seg[1 + 3 * n_cand + r + 1];
+        if (nown != nstart && nown == end) end -= W;
+    }
+    for (uint32_t p = from + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
+}

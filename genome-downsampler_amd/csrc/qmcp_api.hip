@@ -62,7 +62,7 @@ struct qmcp_hip_ctx {
     hipStream_t stream2 = nullptr;  // side stream: small read-backs beside the work queued on `stream`
     hipEvent_t ev_fork = nullptr;   // main stream -> side stream: statistics and heaviest load are final
     // arena (grow-only, reused across solves like a reference solver instance's members)
-    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2;
+    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2, specsnap;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
@@ -776,8 +776,55 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
             }
             // spans up to 448: the window of live buckets fits the wave's registers (8 per lane)
             const bool in_regs = max_span + 64 <= 512 && std::getenv("QMCP_HIP_GENERAL_LDS") == nullptr;
+            // speculative stretch boundaries, as for one span (launch_uniform_sweep): the state is the
+            // selected reads still alive, i.e. the kept counts of the last max_span start positions, which
+            // k_spec_verify compares (selend = bucket start + kept count); the run-in is counted in
+            // windows of max_span positions
+            bool speculate = depth < kSpecDepth;
+            if (const char* e = std::getenv("QMCP_HIP_SPEC")) speculate = e[0] == '1';
+            uint32_t burn_blocks = spec_burn_blocks(depth);
+            if (const char* e = std::getenv("QMCP_HIP_SPEC_BURN")) burn_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
+            speculate = speculate && in_regs && seg != nullptr && burn_blocks >= 2 &&
+                        (uint64_t)ltot >= 4ull * burn_blocks * max_span;
+            if (speculate) {
+                TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(n_seg_max)));
+                uint32_t* mismatches = (uint32_t*)((char*)c->scalars.p + 32);
+                const uint32_t* seg_spec;
+                const uint32_t burn = (burn_blocks * max_span + 63u) / 64u * 64u;  // whole chunks of the walk
+                {
+                    KernelSpan sp(c, "k_find_cuts");
+                    seg_spec = qmcp::launch_sweep_segments_speculative(c->stream, (const uint64_t*)c->poff.p, n_contigs, ltot,
+                                                                       windows, burn, (uint32_t*)c->segs.p,
+                                                                       mismatches + 1, 2);  // (a walk is one light workgroup:
+                                                                                            //  many short stretches beat few long ones)
+                    HIP_TRY(hipMemcpyAsync(d_iters + 2, seg_spec, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+                }
+                {
+                    KernelSpan sp(c, "k_sweep_general_reg");
+                    speculate = qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
+                                                               c->keys[kin].p, (const uint32_t*)c->next_head.p,
+                                                               (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
+                                                               (uint32_t*)c->selend.p, seg_spec, n_seg_max,
+                                                               (uint32_t*)c->cstart.p, nullptr, (uint32_t*)c->specsnap.p);
+                }
+                if (speculate) {
+                    {
+                        KernelSpan sp(c, "k_spec_verify + k_spec_merge");
+                        qmcp::launch_spec_verify_merge_mixed(c->stream, seg_spec, n_seg_max, max_span, (uint32_t*)c->selend.p,
+                                                             (const uint32_t*)c->cstart.p, (const uint32_t*)c->specsnap.p,
+                                                             mismatches);
+                    }
+                    KernelSpan sp(c, "k_sweep_general_reg (exact, if the speculation failed)");
+                    (void)qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
+                                                         c->keys[kin].p, (const uint32_t*)c->next_head.p,
+                                                         (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
+                                                         (uint32_t*)c->selend.p, seg, n_seg_max, nullptr, mismatches);
+                }
+            }
             KernelSpan sp(c, in_regs ? "k_sweep_general_reg" : "k_sweep_general_cached");
-            if (!in_regs ||
+            if (speculate) {
+                // swept above
+            } else if (!in_regs ||
                 !qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p,
                                                 (const uint32_t*)c->eoff.p, c->keys[kin].p,
                                                 (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
@@ -1049,7 +1096,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->specsnap, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -63,7 +63,8 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
 // first; *n_speculative receives how many), and the check + merge of the two outputs behind the sweep.
 const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
                                                   uint32_t ltot, uint32_t n_windows, uint32_t burn,
-                                                  uint32_t* seg_words, uint32_t* n_speculative);
+                                                  uint32_t* seg_words, uint32_t* n_speculative,
+                                                  uint32_t run_ins_apart = 4);
 void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                               uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
@@ -104,7 +105,13 @@ void launch_sweep_general_cached(hipStream_t st, bool wide, const uint32_t* boff
 bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, const uint32_t* eoff,
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
-                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max);
+                              uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max,
+                              uint32_t* selend_odd = nullptr, const uint32_t* run_if_nonzero = nullptr,
+                              uint32_t* snap = nullptr /* speculative tables: spec_snap_bytes(n_seg_max) */);
+size_t spec_snap_bytes(uint32_t n_cand);
+void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t max_span,
+                                    uint32_t* out_even, const uint32_t* out_odd, const uint32_t* snap,
+                                    uint32_t* mismatches);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
                  unsigned long long* n_kept);

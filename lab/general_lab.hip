@@ -51,7 +51,7 @@ int main() {
         hipMemset(d_st, 0, 64);
         hipEventRecord(a);
         hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, 4, 1>), dim3(1), dim3(128), 0, 0, d_boff, d_eoff,
-                           SortedK64{d_keys}, d_nh, d_poff, span_bits, max_span, M, d_sel, nullptr, d_st);
+                           SortedK64{d_keys}, d_nh, d_poff, span_bits, max_span, M, d_sel, nullptr, nullptr, nullptr, 0u, nullptr, d_st);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         unsigned long long st[8]; hipMemcpy(st, d_st, 64, hipMemcpyDeviceToHost);

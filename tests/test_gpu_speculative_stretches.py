@@ -101,3 +101,44 @@ def test_deeper_data_forced_to_speculate_falls_back_exactly(pkg, oracle, solver)
         st = solver.last_stats
     assert st.spec_boundaries > 0 and st.spec_mismatches > 0
     assert np.array_equal(got, oracle.solve(s, e, lengths, 20, contig_read_offsets=offs))
+
+
+def _mixed_contigs(rng, lengths, depth_in_m, M, lo, hi):
+    ss, ee, offs = [], [], [0]
+    for L in lengths:
+        n = int(depth_in_m * M * L / ((lo + hi) / 2))
+        span = rng.integers(lo, hi + 1, size=n).astype(np.uint32)
+        s = (rng.random(n) * (L - span + 1)).astype(np.uint32)
+        ss.append(s)
+        ee.append(s + span - 1)
+        offs.append(offs[-1] + n)
+    return np.concatenate(ss), np.concatenate(ee), np.asarray(offs, np.uint64), np.asarray(lengths, np.uint32)
+
+
+@pytest.mark.parametrize("lo,hi,M,depth", [(100, 150, 40, 2.0), (140, 151, 30, 1.8), (200, 250, 50, 1.9), (30, 60, 25, 2.0)])
+def test_mixed_spans_speculate_too(pkg, oracle, solver, lo, hi, M, depth):
+    """the register-resident event sweep: the state compared at a boundary is how many reads every bucket
+    that is still alive has given so far"""
+    rng = np.random.default_rng(lo * 1000 + hi)
+    s, e, offs, lengths = _mixed_contigs(rng, [2_600_000, 900_000], depth, M, lo, hi)
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_GENERAL and st.spec_boundaries >= 2 and st.spec_mismatches == 0, st.as_dict()
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want)
+    with _env(QMCP_HIP_SPEC="0"):
+        assert np.array_equal(solver.solve(s, e, lengths, M, contig_read_offsets=offs), want)
+        assert solver.last_stats.spec_boundaries == 0
+
+
+def test_mixed_spans_with_a_run_in_that_is_too_short(pkg, oracle, solver):
+    rng = np.random.default_rng(17)
+    s, e, offs, lengths = _mixed_contigs(rng, [2_000_000], 2.0, 40, 100, 150)
+    want = oracle.solve(s, e, lengths, 40, contig_read_offsets=offs)
+    for burn in ("3", "16"):
+        with _env(QMCP_HIP_SPEC_BURN=burn):
+            got = solver.solve(s, e, lengths, 40, contig_read_offsets=offs)
+            st = solver.last_stats
+        assert st.spec_boundaries > 0
+        assert np.array_equal(got, want), (burn, st.as_dict())
+
