@@ -106,9 +106,9 @@ uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs) 
     return (uint32_t)(w < 2 ? 0 : (w > cap ? cap : w));
 }
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
-    // the windows' cuts, then two tables (with speculative boundaries, and the exact one): count,
+    // the windows' cuts, then three tables (the exact one, and two with speculative boundaries): count,
     // {start, end, contig end} and the owned-from position per stretch
-    return (size_t)n_windows + 2 * (1 + 4 * ((size_t)n_contigs + n_windows));
+    return (size_t)n_windows + 3 * (1 + 4 * ((size_t)n_contigs + n_windows));
 }
 // fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
@@ -122,16 +122,17 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
                        ltot, win, 0u, 1u, seg, (uint32_t*)nullptr);
     return seg;
 }
-// the same windows' second table: speculative boundaries where a window has no cut (behind the exact
-// table in seg_words; launch_sweep_segments comes first)
+// the same windows' further tables (tier 1 or 2): speculative boundaries where a window has no cut (behind
+// the exact table in seg_words; launch_sweep_segments comes first); burn == 0 gives the exact table again
 const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
                                                   uint32_t ltot, uint32_t n_windows, uint32_t burn,
-                                                  uint32_t* seg_words, uint32_t* n_speculative, uint32_t run_ins_apart) {
+                                                  uint32_t* seg_words, uint32_t* n_speculative, uint32_t run_ins_apart,
+                                                  uint32_t tier) {
     // candidates this many run-ins apart at least (>= 2)
     const uint32_t win0 = (ltot + n_windows - 1) / n_windows;
     const uint32_t stride = (uint32_t)(((uint64_t)run_ins_apart * burn + win0 - 1) / win0);
     const uint32_t* cut = seg_words;
-    uint32_t* seg = seg_words + n_windows + 1 + 4 * ((size_t)n_contigs + n_windows);
+    uint32_t* seg = seg_words + n_windows + (size_t)tier * (1 + 4 * ((size_t)n_contigs + n_windows));
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, burn, stride < 1 ? 1u : stride, seg, n_speculative);
@@ -140,16 +141,22 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
 size_t spec_snap_bytes(uint32_t n_cand) { return (size_t)n_cand * kSpecSnapWords * sizeof(uint32_t); }
 void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t max_span,
                                     uint32_t* out_even, const uint32_t* out_odd, const uint32_t* snap,
-                                    uint32_t* mismatches) {
+                                    uint32_t* mismatches, const uint32_t* run_if_nonzero) {
     hipLaunchKernelGGL(k_spec_verify_mixed, dim3(n_cand), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd, snap,
-                       kSpecSnapWords, mismatches);
+                       kSpecSnapWords, mismatches, run_if_nonzero);
     hipLaunchKernelGGL(k_spec_merge_mixed, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd,
-                       mismatches);
+                       mismatches, run_if_nonzero);
 }
 void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
-                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches) {
-    hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, out_even, out_odd, mismatches);
-    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, mismatches);
+                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches,
+                              const uint32_t* run_if_nonzero) {
+    hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, out_even, out_odd, mismatches,
+                       run_if_nonzero);
+    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, mismatches,
+                       run_if_nonzero);
+}
+void launch_spec_gate(hipStream_t st, const uint32_t* a, const uint32_t* b_or_null, uint32_t* out) {
+    hipLaunchKernelGGL(k_spec_gate, dim3(1), dim3(1), 0, st, a, b_or_null, out);
 }
 
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }

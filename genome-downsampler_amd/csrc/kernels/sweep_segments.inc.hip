@@ -133,8 +133,10 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
 __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t ell,
                                                      const uint32_t* __restrict__ out_even,
                                                      const uint32_t* __restrict__ out_odd,
-                                                     uint32_t* __restrict__ mismatches) {
+                                                     uint32_t* __restrict__ mismatches,
+                                                     const uint32_t* __restrict__ run_if_nonzero /* or null */) {
     const uint32_t r = blockIdx.x;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     if (r >= seg[0]) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
@@ -150,8 +152,10 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_spec_merge(const uint32_t* __restrict__ seg, uint32_t n_cand,
                                                     uint32_t* __restrict__ out_even,
                                                     const uint32_t* __restrict__ out_odd,
-                                                    const uint32_t* __restrict__ mismatches) {
+                                                    const uint32_t* __restrict__ mismatches,
+                                                    const uint32_t* __restrict__ run_if_nonzero /* or null */) {
     const uint32_t r = blockIdx.x;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     if ((r & 1u) == 0 || r >= seg[0] || *mismatches != 0) return;
     const uint32_t own = seg[1 + 3 * n_cand + r], end = seg[1 + 3 * r + 1];
     for (uint32_t p = own + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
@@ -165,8 +169,10 @@ __global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __res
                                                            const uint32_t* __restrict__ out_even,
                                                            const uint32_t* __restrict__ out_odd,
                                                            const uint32_t* __restrict__ snap, uint32_t snap_words,
-                                                           uint32_t* __restrict__ mismatches) {
+                                                           uint32_t* __restrict__ mismatches,
+                                                           const uint32_t* __restrict__ run_if_nonzero /* or null */) {
     const uint32_t r = blockIdx.x;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     if (r >= seg[0]) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
@@ -186,8 +192,10 @@ __global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __res
 __global__ __launch_bounds__(256) void k_spec_merge_mixed(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t W,
                                                           uint32_t* __restrict__ out_even,
                                                           const uint32_t* __restrict__ out_odd,
-                                                          const uint32_t* __restrict__ mismatches) {
+                                                          const uint32_t* __restrict__ mismatches,
+                                                          const uint32_t* __restrict__ run_if_nonzero /* or null */) {
     const uint32_t r = blockIdx.x;
+    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     const uint32_t count = seg[0];
     if ((r & 1u) == 0 || r >= count || *mismatches != 0) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
@@ -198,4 +206,9 @@ __global__ __launch_bounds__(256) void k_spec_merge_mixed(const uint32_t* __rest
         if (nown != nstart && nown == end) end -= W;
     }
     for (uint32_t p = from + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
+}
+
+// gates between the tiers of a speculative sweep: *out = (*a != 0) and (b == null or *b != 0)
+__global__ void k_spec_gate(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out) {
+    *out = (*a != 0 && (b == nullptr || *b != 0)) ? 1u : 0u;
 }

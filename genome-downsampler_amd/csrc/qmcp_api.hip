@@ -319,10 +319,80 @@ uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, boo
 // that grows with the depth.  lab/spec_burn_study.py, cfg5's shape at 1/32 scale, boundaries that
 // disagreed at a run-in of 128 / 256 / 512 / 1024 blocks: depth 2.0: 2 of 364 / 0 / 0 / 0; 2.5: 67 of 364 /
 // 1 of 240 / 0 / 0; 3.0: 157 / 28 / 0 of 118 / 0; 4.0: 273 / 86 / 6 of 118 / 0 of 56 -- about twice
-// the run-in per half unit of depth; the table keeps a factor of two to three above the longest seen.
+// the run-in per half unit of depth.  Two tiers: the first with the run-in of this table, and -- only
+// if some boundary disagreed -- a second with three times that (or, where the genome is too short for it,
+// none: the exact table); the exact sweep runs only if the second tier disagrees somewhere too.  Every
+// tier's launches are queued at once and gated by device words, so nothing waits for the host.
 constexpr double kSpecDepth = 4.1;
 uint32_t spec_burn_blocks(double depth) {
-    return depth < 2.1 ? 384u : depth < 2.6 ? 768u : depth < 3.1 ? 1280u : 2560u;
+    return depth < 2.1 ? 320u : depth < 2.6 ? 640u : depth < 3.1 ? 1152u : 2304u;
+}
+bool spec_wanted(double depth) {
+    bool on = depth < kSpecDepth;
+    if (const char* e = std::getenv("QMCP_HIP_SPEC")) on = e[0] == '1';  // (0 / 1: never / at any depth)
+    return on;
+}
+uint32_t spec_first_run_in(double depth) {
+    if (const char* e = std::getenv("QMCP_HIP_SPEC_BURN")) return (uint32_t)std::strtoul(e, nullptr, 10);
+    return spec_burn_blocks(depth);
+}
+
+// device words of a speculative sweep, behind the solve's other scalars
+struct SpecWords {
+    uint32_t* mismatches1;  // tier 1: boundaries that disagreed
+    uint32_t* n_spec1;      //         speculative boundaries
+    uint32_t* mismatches2;  // tier 2
+    uint32_t* go2;          // tier 2 runs
+    uint32_t* go_exact;     // the exact sweep runs
+    uint32_t* n_spec2;
+};
+SpecWords spec_words(qmcp_hip_ctx* c) {
+    uint32_t* w = (uint32_t*)((char*)c->scalars.p + 32);
+    return SpecWords{w, w + 1, w + 2, w + 3, w + 4, w + 5};
+}
+
+// The tiers of a speculative sweep.  `unit`: positions per block of run-in (the span; the largest span of a
+// mix), `round_to`: the run-in is made a multiple of this many positions.  sweep(table, odd stretches' output
+// or null, gate or null) launches the sweep kernel; check(table, mismatch counter, gate) the comparison and
+// the merge behind it.
+template <class Sweep, class Check>
+int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint32_t ltot, uint32_t windows,
+                      uint32_t unit, uint32_t round_to, uint32_t burn_blocks, uint32_t run_ins_apart,
+                      const uint32_t* seg_exact, const char* sweep_name, Sweep sweep, Check check) {
+    const SpecWords w = spec_words(c);
+    const uint64_t* poff = (const uint64_t*)c->poff.p;
+    auto positions = [&](uint64_t blocks) { return (uint32_t)((blocks * unit + round_to - 1) / round_to * round_to); };
+    const uint32_t burn1 = positions(burn_blocks);
+    uint32_t burn2 = positions(3ull * burn_blocks);
+    if ((uint64_t)ltot < 2ull * run_ins_apart * burn2) burn2 = 0;  // too short a genome: tier 2 is the exact table
+    const uint32_t *seg1, *seg2;
+    {
+        KernelSpan sp(c, "k_find_cuts", st);
+        seg1 = qmcp::launch_sweep_segments_speculative(st, poff, n_contigs, ltot, windows, burn1, (uint32_t*)c->segs.p,
+                                                       w.n_spec1, run_ins_apart, 1);
+        seg2 = qmcp::launch_sweep_segments_speculative(st, poff, n_contigs, ltot, windows, burn2, (uint32_t*)c->segs.p,
+                                                       w.n_spec2, run_ins_apart, 2);
+    }
+    uint32_t* out_odd = (uint32_t*)c->cstart.p;
+    {
+        KernelSpan sp(c, sweep_name, st);
+        if (!sweep(seg1, out_odd, nullptr)) return fail(QMCP_ERANGE, "speculative sweep: span not supported");
+    }
+    {
+        KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
+        check(seg1, w.mismatches1, nullptr);
+        qmcp::launch_spec_gate(st, w.mismatches1, nullptr, w.go2);
+    }
+    {
+        KernelSpan sp(c, "second tier, if the first disagreed", st);
+        (void)sweep(seg2, out_odd, w.go2);
+        check(seg2, w.mismatches2, w.go2);
+        qmcp::launch_spec_gate(st, w.go2, w.mismatches2, w.go_exact);
+    }
+    KernelSpan sp(c, "exact sweep, if the second tier disagreed", st);
+    (void)sweep(seg_exact, nullptr, w.go_exact);
+    HIP_TRY(hipGetLastError());
+    return QMCP_OK;
 }
 
 int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
@@ -347,12 +417,9 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // run-in (every few windows, so that stretches stay several run-ins long); the stretches' outputs are compared where they
     // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
     // returns at once when all agreed).
-    bool speculate = depth < kSpecDepth;
-    if (const char* e = std::getenv("QMCP_HIP_SPEC")) speculate = e[0] == '1';  // (0 / 1: never / at any depth the general form sweeps)
-    speculate = speculate && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span);
-    uint32_t burn_blocks = spec_burn_blocks(depth);
-    if (const char* e = std::getenv("QMCP_HIP_SPEC_BURN")) burn_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (speculate && (burn_blocks < 2 || (uint64_t)ltot < 8ull * burn_blocks * span)) speculate = false;
+    const uint32_t burn_blocks = spec_first_run_in(depth);
+    const bool speculate = spec_wanted(depth) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
+                           burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);
         seg = qmcp::launch_sweep_segments(st, boff, nullptr, poff, n_contigs, ltot, span, M, windows, (uint32_t*)c->segs.p);
@@ -398,30 +465,15 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         return QMCP_OK;
     }
     if (speculate && seg != nullptr) {
-        {
-            uint32_t* mismatches = (uint32_t*)((char*)c->scalars.p + 32);
-            uint32_t* n_spec = mismatches + 1;
-            uint32_t* out_odd = (uint32_t*)c->cstart.p;
-            const uint32_t* seg_spec;
-            {
-                KernelSpan sp(c, "k_find_cuts", st);
-                seg_spec = qmcp::launch_sweep_segments_speculative(st, poff, n_contigs, ltot, windows, burn_blocks * span,
-                                                                   (uint32_t*)c->segs.p, n_spec);
-            }
-            {
-                KernelSpan sp(c, "k_sweep_uniform_gen", st);
-                (void)qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg_spec,
-                                                     n_seg_max, out_odd, nullptr);
-            }
-            {
-                KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
-                qmcp::launch_spec_verify_merge(st, seg_spec, n_seg_max, span, selend, out_odd, mismatches);
-            }
-            KernelSpan sp(c, "k_sweep_uniform_gen (exact, if the speculation failed)", st);
-            (void)qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, seg, n_seg_max,
-                                                 nullptr, mismatches);
-            return QMCP_OK;
-        }
+        return speculative_sweep(
+            c, st, n_contigs, ltot, windows, span, span, burn_blocks, 4, seg, "k_sweep_uniform_gen",
+            [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* gate) {
+                return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, table, n_seg_max,
+                                                      out_odd, gate);
+            },
+            [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* gate) {
+                qmcp::launch_spec_verify_merge(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches, gate);
+            });
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
         KernelSpan sp(c, gen ? "k_sweep_uniform_gen" : "k_sweep_uniform_mw", st);
@@ -443,7 +495,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
                   uint32_t M, uint64_t* d_mask) {
     if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
     c->pend_spiky = false;
-    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 6 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     Problem pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n;
@@ -459,7 +511,7 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
         HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
         for (int i = EV_PREP; i <= EV_MARK; ++i) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
-        c->h_scalars[0] = c->h_scalars[1] = c->h_scalars[2] = c->h_scalars[3] = c->h_scalars[4] = 0;
+        for (int i = 0; i < 8; ++i) c->h_scalars[i] = 0;
         c->pend_stats = local;
         c->pend_whole_contig_chains = 0;
         c->pending = true;
@@ -780,61 +832,44 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
             // selected reads still alive, i.e. the kept counts of the last max_span start positions, which
             // k_spec_verify compares (selend = bucket start + kept count); the run-in is counted in
             // windows of max_span positions
-            bool speculate = depth < kSpecDepth;
-            if (const char* e = std::getenv("QMCP_HIP_SPEC")) speculate = e[0] == '1';
-            uint32_t burn_blocks = spec_burn_blocks(depth);
-            if (const char* e = std::getenv("QMCP_HIP_SPEC_BURN")) burn_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
-            speculate = speculate && in_regs && seg != nullptr && burn_blocks >= 2 &&
-                        (uint64_t)ltot >= 4ull * burn_blocks * max_span;
+            const uint32_t burn_blocks = spec_first_run_in(depth);
+            const bool speculate = spec_wanted(depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
+                                   (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {
                 TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(n_seg_max)));
-                uint32_t* mismatches = (uint32_t*)((char*)c->scalars.p + 32);
-                const uint32_t* seg_spec;
-                const uint32_t burn = (burn_blocks * max_span + 63u) / 64u * 64u;  // whole chunks of the walk
-                {
-                    KernelSpan sp(c, "k_find_cuts");
-                    seg_spec = qmcp::launch_sweep_segments_speculative(c->stream, (const uint64_t*)c->poff.p, n_contigs, ltot,
-                                                                       windows, burn, (uint32_t*)c->segs.p,
-                                                                       mismatches + 1, 2);  // (a walk is one light workgroup:
-                                                                                            //  many short stretches beat few long ones)
-                    HIP_TRY(hipMemcpyAsync(d_iters + 2, seg_spec, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-                }
-                {
-                    KernelSpan sp(c, "k_sweep_general_reg");
-                    speculate = qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
-                                                               c->keys[kin].p, (const uint32_t*)c->next_head.p,
-                                                               (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
-                                                               (uint32_t*)c->selend.p, seg_spec, n_seg_max,
-                                                               (uint32_t*)c->cstart.p, nullptr, (uint32_t*)c->specsnap.p);
-                }
-                if (speculate) {
-                    {
-                        KernelSpan sp(c, "k_spec_verify + k_spec_merge");
-                        qmcp::launch_spec_verify_merge_mixed(c->stream, seg_spec, n_seg_max, max_span, (uint32_t*)c->selend.p,
+                const void* sorted = c->keys[kin].p;
+                // (a walk is one light workgroup: many short stretches beat few long ones -- two run-ins apart)
+                TRY(speculative_sweep(
+                    c, c->stream, n_contigs, ltot, windows, max_span, 64, burn_blocks, 2, seg, "k_sweep_general_reg",
+                    [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* gate) {
+                        return qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
+                                                              sorted, (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
+                                                              n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p, table,
+                                                              n_seg_max, out_odd, gate, (uint32_t*)c->specsnap.p);
+                    },
+                    [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* gate) {
+                        qmcp::launch_spec_verify_merge_mixed(c->stream, table, n_seg_max, max_span, (uint32_t*)c->selend.p,
                                                              (const uint32_t*)c->cstart.p, (const uint32_t*)c->specsnap.p,
-                                                             mismatches);
-                    }
-                    KernelSpan sp(c, "k_sweep_general_reg (exact, if the speculation failed)");
-                    (void)qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
-                                                         c->keys[kin].p, (const uint32_t*)c->next_head.p,
-                                                         (const uint64_t*)c->poff.p, n_contigs, span_bits, max_span, M,
-                                                         (uint32_t*)c->selend.p, seg, n_seg_max, nullptr, mismatches);
-                }
+                                                             mismatches, gate);
+                    }));
+                // stats.sweep_stretches: the first tier's table
+                HIP_TRY(hipMemcpyAsync(d_iters + 2, (uint32_t*)c->segs.p + windows + (1 + 4 * (size_t)n_seg_max), sizeof(uint32_t),
+                                       hipMemcpyDeviceToDevice, c->stream));
             }
-            KernelSpan sp(c, in_regs ? "k_sweep_general_reg" : "k_sweep_general_cached");
-            if (speculate) {
-                // swept above
-            } else if (!in_regs ||
-                !qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p,
-                                                (const uint32_t*)c->eoff.p, c->keys[kin].p,
-                                                (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
-                                                n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p, seg,
-                                                n_seg_max))
-            qmcp::launch_sweep_general_cached(c->stream, wide, (const uint32_t*)c->boff.p,
-                                              (const uint32_t*)c->eoff.p, c->keys[kin].p,
-                                              (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
-                                              n_contigs, span_bits, max_span, M,
-                                              (uint32_t*)c->selend.p, ring, seg, n_seg_max);
+            if (!speculate) {  // (else: swept above)
+                KernelSpan sp(c, in_regs ? "k_sweep_general_reg" : "k_sweep_general_cached");
+                if (!in_regs ||
+                    !qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p,
+                                                    (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                                    (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
+                                                    n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p, seg,
+                                                    n_seg_max))
+                    qmcp::launch_sweep_general_cached(c->stream, wide, (const uint32_t*)c->boff.p,
+                                                      (const uint32_t*)c->eoff.p, c->keys[kin].p,
+                                                      (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
+                                                      n_contigs, span_bits, max_span, M,
+                                                      (uint32_t*)c->selend.p, ring, seg, n_seg_max);
+            }
         } else {
             uint32_t* g_rings = nullptr;
             if (max_span > qmcp::kMaxLdsRingSpan) {
@@ -862,11 +897,11 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));
     c->pend_spiky = ranked_counted;
     if (ranked_counted) {
-        HIP_TRY(hipMemcpyAsync(c->h_scalars + 5, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_scalars + 7, (uint32_t*)c->stats.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         c->spiky_n = n64;
         c->spiky_ltot = pr.ltot;
     }
@@ -895,7 +930,7 @@ int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     qmcp_hip_stats local = c->pend_stats;
     const unsigned long long* host_scalars = c->h_scalars;
     if (c->pend_spiky) {
-        c->spiky_empty = (uint32_t)(c->h_scalars[5] & 0xFFFFFFFFull);
+        c->spiky_empty = (uint32_t)(c->h_scalars[7] & 0xFFFFFFFFull);
         c->spiky_known = true;
     }
     local.n_kept = host_scalars[0];
@@ -904,6 +939,7 @@ int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu) + c->pend_whole_contig_chains;
     local.spec_mismatches = (uint32_t)(host_scalars[4] & 0xFFFFFFFFu);
     local.spec_boundaries = (uint32_t)(host_scalars[4] >> 32);
+    local.spec_retry_mismatches = local.spec_mismatches ? (uint32_t)(host_scalars[5] & 0xFFFFFFFFu) : 0u;
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);

@@ -93,7 +93,9 @@ typedef struct qmcp_hip_stats {
     uint32_t spec_boundaries; /* stretches that started at a speculative boundary (data a few times
                                  deeper than M: no cut point, but the sweep forgets its start)      */
     uint32_t spec_mismatches; /* of those, how many disagreed with the stretch before them; non-zero:
-                                 the exact sweep was run after the speculative one                  */
+                                 a second speculative sweep with three times the run-in was run     */
+    uint32_t spec_retry_mismatches; /* ... and how many disagreed in that one; non-zero: the exact
+                                 sweep was run after all                                            */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);

@@ -69,8 +69,15 @@ def test_a_run_in_that_is_too_short_is_noticed_and_the_exact_sweep_takes_over(pk
         st = solver.last_stats
     assert st.spec_boundaries > 0 and st.spec_mismatches > 0, st.as_dict()
     assert np.array_equal(got, want)
+    assert st.spec_retry_mismatches > 0          # three times four blocks is not enough either: the exact sweep ran
     with _env(QMCP_HIP_SPEC_BURN="2"):
         assert np.array_equal(solver.solve(s, e, lengths, 50, contig_read_offsets=offs), want)
+    # 64 blocks: a good part of the boundaries disagree; the second tier (192 blocks) settles it
+    with _env(QMCP_HIP_SPEC_BURN="64"):
+        got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.spec_mismatches > 0 and st.spec_retry_mismatches == 0, st.as_dict()
+    assert np.array_equal(got, want)
 
 
 def test_speculation_beside_real_cut_points_and_gaps(pkg, oracle, solver):
