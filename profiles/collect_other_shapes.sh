@@ -14,4 +14,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shallow" -o run --
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shallow_mixed" -o run -- python3 "$ROOT/lab/prof_cut_segments.py" 2e7 30 1.0 0 100 > "$OUT/shallow_mixed.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mixed_amplicon" -o run -- python3 "$ROOT/lab/prof_mixed_amplicon.py" > "$OUT/mixed_amplicon.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5share" -o run -- python3 "$ROOT/lab/check_cfg5_share.py" 0.125 0 > "$OUT/cfg5share.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mixed_wgs" -o run -- python3 "$ROOT/lab/prof_mixed_wgs.py" > "$OUT/mixed_wgs.log" 2>&1
 find "$OUT" -name "run_kernel_stats.csv"
