@@ -323,12 +323,12 @@ uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, boo
 // if some boundary disagreed -- a second with three times that (or, where the genome is too short for it,
 // none: the exact table); the exact sweep runs only if the second tier disagrees somewhere too.  Every
 // tier's launches are queued at once and gated by device words, so nothing waits for the host.
-constexpr double kSpecDepth = 4.1;
+constexpr double kSpecDepth = 4.1, kSpecMinDepth = 1.3;
 uint32_t spec_burn_blocks(double depth) {
     return depth < 2.1 ? 320u : depth < 2.6 ? 640u : depth < 3.1 ? 1152u : 2304u;
 }
 bool spec_wanted(double depth) {
-    bool on = depth < kSpecDepth;
+    bool on = depth < kSpecDepth && depth > kSpecMinDepth;  // (shallower: nearly every window has a real cut point)
     if (const char* e = std::getenv("QMCP_HIP_SPEC")) on = e[0] == '1';  // (0 / 1: never / at any depth)
     return on;
 }
@@ -832,7 +832,9 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
             // selected reads still alive, i.e. the kept counts of the last max_span start positions, which
             // k_spec_verify compares (selend = bucket start + kept count); the run-in is counted in
             // windows of max_span positions
-            const uint32_t burn_blocks = spec_first_run_in(depth);
+            // (the first tier starts lower than for one span: a walk is slow per position, so short stretches
+            //  matter more, and the second tier is there)
+            const uint32_t burn_blocks = std::getenv("QMCP_HIP_SPEC_BURN") ? spec_first_run_in(depth) : spec_first_run_in(depth) * 3u / 5u;
             const bool speculate = spec_wanted(depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
                                    (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {

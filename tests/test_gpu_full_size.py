@@ -45,11 +45,15 @@ def test_cfg3_full_size_through_bed_and_tsv_files(pkg, oracle, solver, tmp_path)
 
 def test_cfg5_one_gpus_share_contig_by_contig(pkg, oracle, solver):
     """one GPU's share of configs[4]: 24 contigs ~ GRCh38 proportions at 1/8 of the genome-scale
-    configuration (187.5 M positions, 125 M reads, M = 50): two partition levels, general-form sweep"""
+    configuration (187.5 M positions, 125 M reads, M = 50): two partition levels, general-form sweep in
+    speculative stretches"""
     s, e, offs, lengths = workloads.wgs_contigs(int(1.5e9 / 8), int(0.5e9 / 8))
     got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
     st = solver.last_stats
     assert st.path == pkg.PATH_UNIFORM and st.sort_passes == 1 and st.n_contigs == 24
+    # coverage 2 x M, a few dozen cut points in 187.5 M positions: the sweep runs as several hundred stretches
+    # from speculative boundaries (csrc/kernels/sweep_segments.inc.hip), all of which must have held
+    assert st.spec_boundaries > 500 and st.spec_mismatches == 0 and st.sweep_stretches > 500, st.as_dict()
     bits = np.unpackbits(got.view(np.uint8), bitorder="little")
     for c in range(lengths.size):   # contig by contig: bounded memory on the oracle side
         a, b = int(offs[c]), int(offs[c + 1])
