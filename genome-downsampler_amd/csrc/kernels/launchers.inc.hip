@@ -107,8 +107,8 @@ uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs) 
 }
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
     // the windows' cuts, then three tables (the exact one, and two with speculative boundaries): count,
-    // {start, end, contig end} and the owned-from position per stretch
-    return (size_t)n_windows + 3 * (1 + 4 * ((size_t)n_contigs + n_windows));
+    // {start, end, contig end}, the owned-from position and the exact table's stretch per stretch
+    return (size_t)n_windows + 3 * (1 + 5 * ((size_t)n_contigs + n_windows));
 }
 // fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
@@ -132,7 +132,7 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
     const uint32_t win0 = (ltot + n_windows - 1) / n_windows;
     const uint32_t stride = (uint32_t)(((uint64_t)run_ins_apart * burn + win0 - 1) / win0);
     const uint32_t* cut = seg_words;
-    uint32_t* seg = seg_words + n_windows + (size_t)tier * (1 + 4 * ((size_t)n_contigs + n_windows));
+    uint32_t* seg = seg_words + n_windows + (size_t)tier * (1 + 5 * ((size_t)n_contigs + n_windows));
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, burn, stride < 1 ? 1u : stride, seg, n_speculative);
@@ -141,22 +141,18 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
 size_t spec_snap_bytes(uint32_t n_cand) { return (size_t)n_cand * kSpecSnapWords * sizeof(uint32_t); }
 void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t max_span,
                                     uint32_t* out_even, const uint32_t* out_odd, const uint32_t* snap,
-                                    uint32_t* mismatches, const uint32_t* run_if_nonzero) {
+                                    uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
     hipLaunchKernelGGL(k_spec_verify_mixed, dim3(n_cand), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd, snap,
-                       kSpecSnapWords, mismatches, run_if_nonzero);
+                       kSpecSnapWords, mismatches, redo_in, redo_out);
     hipLaunchKernelGGL(k_spec_merge_mixed, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd,
-                       mismatches, run_if_nonzero);
+                       redo_in);
 }
 void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                               uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches,
-                              const uint32_t* run_if_nonzero) {
+                              const uint32_t* redo_in, uint32_t* redo_out) {
     hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, out_even, out_odd, mismatches,
-                       run_if_nonzero);
-    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, mismatches,
-                       run_if_nonzero);
-}
-void launch_spec_gate(hipStream_t st, const uint32_t* a, const uint32_t* b_or_null, uint32_t* out) {
-    hipLaunchKernelGGL(k_spec_gate, dim3(1), dim3(1), 0, st, a, b_or_null, out);
+                       redo_in, redo_out);
+    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, redo_in);
 }
 
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
@@ -188,7 +184,7 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_odd, const uint32_t* run_if_nonzero) {
+                              uint32_t* selend_odd, const uint32_t* redo_in) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_GEN(EE)                                                                             \
@@ -197,7 +193,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,      \
-                           ell, M, ltot, selend, iter_stats, seg, selend_odd, run_if_nonzero);               \
+                           ell, M, ltot, selend, iter_stats, seg, selend_odd, redo_in, n_seg_max);           \
     }
     switch (e) {
         case 1: QMCP_SWEEP_GEN(1); break;
@@ -359,7 +355,7 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
                               uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_odd, const uint32_t* run_if_nonzero, uint32_t* snap) {
+                              uint32_t* selend_odd, const uint32_t* redo_in, uint32_t* snap) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t b = (max_span + 64 + 63) / 64;
 #ifdef QMCP_GEN_STAMP
@@ -371,11 +367,11 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
     if (wide)                                                                                          \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedK64, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedK64{(const uint64_t*)sorted}, next_head, d_poff, span_bits,    \
-                           max_span, M, selend, seg, selend_odd, run_if_nonzero, n_seg_max, snap QMCP_GEN_STAMP_ARG); \
+                           max_span, M, selend, seg, selend_odd, redo_in, n_seg_max, snap QMCP_GEN_STAMP_ARG); \
     else                                                                                               \
         hipLaunchKernelGGL((k_sweep_general_reg<SortedRec, BB, KK>), dim3(n_wg), dim3(64 * (1 + KK)), 0, st, boff, \
                            eoff, SortedRec{(const Rec*)sorted}, next_head, d_poff, span_bits, max_span, \
-                           M, selend, seg, selend_odd, run_if_nonzero, n_seg_max, snap QMCP_GEN_STAMP_ARG);
+                           M, selend, seg, selend_odd, redo_in, n_seg_max, snap QMCP_GEN_STAMP_ARG);
     // loader waves per walker: few workgroups (contigs) -> many loaders, so the walker never waits for an
     // entering chunk's three trips to memory; many workgroups (stretches) fill the chip by themselves
     // and extra waves only get in the walkers' way

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     uint32_t span_bits, uint32_t max_span, uint32_t M, uint32_t* __restrict__ selend,
     const uint32_t* __restrict__ seg,
     uint32_t* __restrict__ selend_odd /* odd stretches' output (speculative tables); or null */,
-    const uint32_t* __restrict__ run_if_nonzero /* or null */,
+    const uint32_t* __restrict__ redo_in /* or null: every stretch (else: a later tier of a speculative sweep) */,
     uint32_t n_cand /* speculative tables: entries per column of seg */,
     uint32_t* __restrict__ snap /* speculative tables: kSpecSnapWords per stretch */
 #ifdef QMCP_GEN_STAMP
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * (1 + kRegLoaders)) void k_sweep_general_reg(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 walker, 1.. loaders
     const uint32_t c_id = blockIdx.x;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;  // (the exact sweep behind a speculation that held)
+    if (redo_in != nullptr && (c_id >= seg[0] || spec_stretch_idle(seg, n_cand, c_id, redo_in))) return;
     SweepSeg sg;
     if (!sweep_segment(contig_pos_off, seg, c_id, sg)) return;
     const uint32_t base = sg.base, L = sg.Lrun;  // a stretch never looks past its own end

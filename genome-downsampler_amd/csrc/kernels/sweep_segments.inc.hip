@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
 // several run-ins long); the stretch before it runs up to b as before.  The two have
 // then both computed [b - burn, b), into separate outputs (stretches alternate between two), and
 // k_spec_verify compares the last ell positions before b: equal kept counts there are equal states, so
-// everything the speculative stretch selected from b on is what the serial sweep selects.  One mismatch
-// anywhere and the whole sweep is redone on the exact table (k_spec_verify's counter gates both).
-// Table: [count, {start, end, contig end} per stretch, then the position each stretch owns from].
+// everything the speculative stretch selected from b on is what the serial sweep selects.  A mismatch
+// marks the part of the genome it lies in for another go (see "Tiers" below).
+// Table: [count, {start, end, contig end} per stretch, then the position each stretch owns from, then the
+// index of the exact table's stretch it lies in].
 __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint32_t* __restrict__ cut,
                                                                       uint32_t n_windows,
                                                                       const uint64_t* __restrict__ contig_pos_off,
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
                                                                       uint32_t* __restrict__ seg,
                                                                       uint32_t* __restrict__ n_speculative /* += ; or null */) {
     __shared__ uint32_t s_pos[kSegMaxCandidates];
+    __shared__ uint32_t s_exact[kSegMaxCandidates];
     __shared__ uint32_t s_sorted[kSegMaxCandidates];
     __shared__ uint32_t s_count, s_spec;
     const uint32_t t = threadIdx.x;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
         }
     }
     s_pos[t] = spec ? kNoCut : mine;  // the exact boundaries first
+    s_exact[t] = spec ? kNoCut : mine;
     if (t == 0) { s_count = 0; s_spec = 0; }
     __syncthreads();
     if (spec) {
@@ -123,9 +126,23 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
         seg[1 + 3 * rank + 1] = min(next, cend);
         seg[1 + 3 * rank + 2] = cend;
         seg[1 + 3 * n_cand + rank] = mine;
+        // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
+        // disagreement marks for another go, and what the later tiers look up to see whether they have work
+        uint32_t exact_before = 0;
+        for (uint32_t k = 0; k < n_cand; ++k) exact_before += (s_exact[k] != kNoCut && s_exact[k] <= mine) ? 1u : 0u;
+        seg[1 + 4 * n_cand + rank] = exact_before - 1u;  // (>= 1: every position lies behind its contig's start)
         if (rank == 0) seg[0] = count;
     }
     if (t == 0 && n_speculative != nullptr) *n_speculative = s_spec;
+}
+
+// Tiers.  A disagreement marks the EXACT stretch (between two cut points / contig starts) it lies in:
+// `redo_out[x] = 1`.  The next tier's kernels -- sweep, check, merge -- look their stretch's exact stretch up
+// in `redo_in` and return at once when it is not marked, so only the marked parts of the genome are swept
+// again (first speculatively with a longer run-in, at last exactly), and everything is queued at once.
+__device__ __forceinline__ bool spec_stretch_idle(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t r,
+                                                  const uint32_t* __restrict__ redo_in) {
+    return redo_in != nullptr && redo_in[seg[1 + 4 * n_cand + r]] == 0;
 }
 
 // one workgroup per stretch: a speculative one compares its own last ell positions before the position it
@@ -134,29 +151,30 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ out_even,
                                                      const uint32_t* __restrict__ out_odd,
                                                      uint32_t* __restrict__ mismatches,
-                                                     const uint32_t* __restrict__ run_if_nonzero /* or null */) {
+                                                     const uint32_t* __restrict__ redo_in /* or null: every stretch */,
+                                                     uint32_t* __restrict__ redo_out) {
     const uint32_t r = blockIdx.x;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
-    if (r >= seg[0]) return;
+    if (r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
     const uint32_t* mine = (r & 1u) ? out_odd : out_even;
     const uint32_t* prev = (r & 1u) ? out_even : out_odd;
     bool differs = false;
     for (uint32_t i = threadIdx.x; i < ell; i += blockDim.x) differs |= mine[own - ell + i] != prev[own - ell + i];
-    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) {
+        atomicAdd(mismatches, 1u);
+        redo_out[seg[1 + 4 * n_cand + r]] = 1u;
+    }
 }
 
-// the odd stretches' own positions move to the even output (which the ranking reads), unless the
-// speculation failed (then the exact sweep that follows writes all of it)
+// the odd stretches' own positions move to the even output (which the ranking reads); a marked part's
+// values are overwritten by the tier that sweeps it again
 __global__ __launch_bounds__(256) void k_spec_merge(const uint32_t* __restrict__ seg, uint32_t n_cand,
                                                     uint32_t* __restrict__ out_even,
                                                     const uint32_t* __restrict__ out_odd,
-                                                    const uint32_t* __restrict__ mismatches,
-                                                    const uint32_t* __restrict__ run_if_nonzero /* or null */) {
+                                                    const uint32_t* __restrict__ redo_in) {
     const uint32_t r = blockIdx.x;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
-    if ((r & 1u) == 0 || r >= seg[0] || *mismatches != 0) return;
+    if ((r & 1u) == 0 || r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
     const uint32_t own = seg[1 + 3 * n_cand + r], end = seg[1 + 3 * r + 1];
     for (uint32_t p = own + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
 }
@@ -170,10 +188,10 @@ __global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __res
                                                            const uint32_t* __restrict__ out_odd,
                                                            const uint32_t* __restrict__ snap, uint32_t snap_words,
                                                            uint32_t* __restrict__ mismatches,
-                                                           const uint32_t* __restrict__ run_if_nonzero /* or null */) {
+                                                           const uint32_t* __restrict__ redo_in,
+                                                           uint32_t* __restrict__ redo_out) {
     const uint32_t r = blockIdx.x;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
-    if (r >= seg[0]) return;
+    if (r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
     const uint32_t* prev = (r & 1u) ? out_even : out_odd;
@@ -183,7 +201,10 @@ __global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __res
         const uint32_t p = own - W + i;
         differs |= mine[p % snap_words] != prev[p];
     }
-    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) {
+        atomicAdd(mismatches, 1u);
+        redo_out[seg[1 + 4 * n_cand + r]] = 1u;
+    }
 }
 
 // ... and the final counts of those W positions are the speculative stretch's: an odd stretch's range
@@ -192,12 +213,10 @@ __global__ __launch_bounds__(256) void k_spec_verify_mixed(const uint32_t* __res
 __global__ __launch_bounds__(256) void k_spec_merge_mixed(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t W,
                                                           uint32_t* __restrict__ out_even,
                                                           const uint32_t* __restrict__ out_odd,
-                                                          const uint32_t* __restrict__ mismatches,
-                                                          const uint32_t* __restrict__ run_if_nonzero /* or null */) {
+                                                          const uint32_t* __restrict__ redo_in) {
     const uint32_t r = blockIdx.x;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;
     const uint32_t count = seg[0];
-    if ((r & 1u) == 0 || r >= count || *mismatches != 0) return;
+    if ((r & 1u) == 0 || r >= count || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     uint32_t from = own != start ? own - W : own;
     uint32_t end = seg[1 + 3 * r + 1];
@@ -206,9 +225,4 @@ __global__ __launch_bounds__(256) void k_spec_merge_mixed(const uint32_t* __rest
         if (nown != nstart && nown == end) end -= W;
     }
     for (uint32_t p = from + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
-}
-
-// gates between the tiers of a speculative sweep: *out = (*a != 0) and (b == null or *b != 0)
-__global__ void k_spec_gate(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out) {
-    *out = (*a != 0 && (b == nullptr || *b != 0)) ? 1u : 0u;
 }

@@ -542,9 +542,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                            uint32_t* __restrict__ iter_stats,
                                                            const uint32_t* __restrict__ seg,
                                                            uint32_t* __restrict__ selend_odd /* odd stretches' output; or null */,
-                                                           const uint32_t* __restrict__ run_if_nonzero /* or null */) {
+                                                           const uint32_t* __restrict__ redo_in /* or null: every stretch */,
+                                                           uint32_t n_cand /* entries per column of seg (redo_in != null) */) {
     using Ly = MgLayout<E>;
-    if (run_if_nonzero != nullptr && *run_if_nonzero == 0) return;  // (the exact sweep behind a speculation that held)
+    // (a later tier of a speculative sweep: only the parts of the genome a disagreement marked)
+    if (redo_in != nullptr && (blockIdx.x >= seg[0] || spec_stretch_idle(seg, n_cand, blockIdx.x, redo_in))) return;
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
     const uint32_t lane = threadIdx.x & 63;

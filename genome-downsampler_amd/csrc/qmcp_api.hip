@@ -62,7 +62,7 @@ struct qmcp_hip_ctx {
     hipStream_t stream2 = nullptr;  // side stream: small read-backs beside the work queued on `stream`
     hipEvent_t ev_fork = nullptr;   // main stream -> side stream: statistics and heaviest load are final
     // arena (grow-only, reused across solves like a reference solver instance's members)
-    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2, specsnap;
+    DevBuf roff, poff, stats, cstart, boff, ecnt, eoff, selend, spine, hist, spine2, hist2, specsnap, specflags;
     DevBuf keys[2], vals[2];
     DevBuf in_starts, in_ends, in_aux0, in_aux1, mask, cov, amp, next_head;
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
@@ -342,25 +342,29 @@ struct SpecWords {
     uint32_t* mismatches1;  // tier 1: boundaries that disagreed
     uint32_t* n_spec1;      //         speculative boundaries
     uint32_t* mismatches2;  // tier 2
-    uint32_t* go2;          // tier 2 runs
-    uint32_t* go_exact;     // the exact sweep runs
     uint32_t* n_spec2;
 };
 SpecWords spec_words(qmcp_hip_ctx* c) {
     uint32_t* w = (uint32_t*)((char*)c->scalars.p + 32);
-    return SpecWords{w, w + 1, w + 2, w + 3, w + 4, w + 5};
+    return SpecWords{w, w + 1, w + 2, w + 3};
 }
 
 // The tiers of a speculative sweep.  `unit`: positions per block of run-in (the span; the largest span of a
 // mix), `round_to`: the run-in is made a multiple of this many positions.  sweep(table, odd stretches' output
-// or null, gate or null) launches the sweep kernel; check(table, mismatch counter, gate) the comparison and
-// the merge behind it.
+// or null, marks to obey or null) launches the sweep kernel; check(table, mismatch counter, marks to obey or
+// null, marks to set) the comparison and the merge behind it.  A disagreement marks the exact stretch it
+// lies in; tier 2 (three times the run-in) sweeps only marked parts, the exact sweep only what tier 2 marked.
 template <class Sweep, class Check>
 int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint32_t ltot, uint32_t windows,
                       uint32_t unit, uint32_t round_to, uint32_t burn_blocks, uint32_t run_ins_apart,
                       const uint32_t* seg_exact, const char* sweep_name, Sweep sweep, Check check) {
     const SpecWords w = spec_words(c);
     const uint64_t* poff = (const uint64_t*)c->poff.p;
+    const uint32_t n_cand = n_contigs + windows;
+    TRY(ensure(c, c->specflags, 2 * (size_t)n_cand * sizeof(uint32_t)));
+    uint32_t* redo1 = (uint32_t*)c->specflags.p;
+    uint32_t* redo2 = redo1 + n_cand;
+    HIP_TRY(hipMemsetAsync(redo1, 0, 2 * (size_t)n_cand * sizeof(uint32_t), st));
     auto positions = [&](uint64_t blocks) { return (uint32_t)((blocks * unit + round_to - 1) / round_to * round_to); };
     const uint32_t burn1 = positions(burn_blocks);
     uint32_t burn2 = positions(3ull * burn_blocks);
@@ -380,17 +384,15 @@ int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint3
     }
     {
         KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
-        check(seg1, w.mismatches1, nullptr);
-        qmcp::launch_spec_gate(st, w.mismatches1, nullptr, w.go2);
+        check(seg1, w.mismatches1, nullptr, redo1);
     }
     {
-        KernelSpan sp(c, "second tier, if the first disagreed", st);
-        (void)sweep(seg2, out_odd, w.go2);
-        check(seg2, w.mismatches2, w.go2);
-        qmcp::launch_spec_gate(st, w.go2, w.mismatches2, w.go_exact);
+        KernelSpan sp(c, "second tier, where the first disagreed", st);
+        (void)sweep(seg2, out_odd, redo1);
+        check(seg2, w.mismatches2, redo1, redo2);
     }
-    KernelSpan sp(c, "exact sweep, if the second tier disagreed", st);
-    (void)sweep(seg_exact, nullptr, w.go_exact);
+    KernelSpan sp(c, "exact sweep, where the second tier disagreed", st);
+    (void)sweep(seg_exact, nullptr, redo2);
     HIP_TRY(hipGetLastError());
     return QMCP_OK;
 }
@@ -467,12 +469,13 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     if (speculate && seg != nullptr) {
         return speculative_sweep(
             c, st, n_contigs, ltot, windows, span, span, burn_blocks, 4, seg, "k_sweep_uniform_gen",
-            [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* gate) {
+            [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* redo_in) {
                 return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, table, n_seg_max,
-                                                      out_odd, gate);
+                                                      out_odd, redo_in);
             },
-            [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* gate) {
-                qmcp::launch_spec_verify_merge(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches, gate);
+            [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
+                qmcp::launch_spec_verify_merge(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches,
+                                               redo_in, redo_out);
             });
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {
@@ -536,6 +539,8 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
         TRY(ensure(c, c->segs, qmcp::sweep_segment_words(n_contigs < 256 ? n_contigs : 0, 768) * sizeof(uint32_t)));
+        TRY(ensure(c, c->specflags, 2 * 1024 * sizeof(uint32_t)));           // speculative sweeps: marks per exact stretch, two tiers
+        TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(1024)));            // ... and the mixed-span walk's states at boundaries
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
@@ -843,19 +848,19 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
                 // (a walk is one light workgroup: many short stretches beat few long ones -- two run-ins apart)
                 TRY(speculative_sweep(
                     c, c->stream, n_contigs, ltot, windows, max_span, 64, burn_blocks, 2, seg, "k_sweep_general_reg",
-                    [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* gate) {
+                    [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* redo_in) {
                         return qmcp::launch_sweep_general_reg(c->stream, wide, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
                                                               sorted, (const uint32_t*)c->next_head.p, (const uint64_t*)c->poff.p,
                                                               n_contigs, span_bits, max_span, M, (uint32_t*)c->selend.p, table,
-                                                              n_seg_max, out_odd, gate, (uint32_t*)c->specsnap.p);
+                                                              n_seg_max, out_odd, redo_in, (uint32_t*)c->specsnap.p);
                     },
-                    [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* gate) {
+                    [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
                         qmcp::launch_spec_verify_merge_mixed(c->stream, table, n_seg_max, max_span, (uint32_t*)c->selend.p,
                                                              (const uint32_t*)c->cstart.p, (const uint32_t*)c->specsnap.p,
-                                                             mismatches, gate);
+                                                             mismatches, redo_in, redo_out);
                     }));
                 // stats.sweep_stretches: the first tier's table
-                HIP_TRY(hipMemcpyAsync(d_iters + 2, (uint32_t*)c->segs.p + windows + (1 + 4 * (size_t)n_seg_max), sizeof(uint32_t),
+                HIP_TRY(hipMemcpyAsync(d_iters + 2, (uint32_t*)c->segs.p + windows + (1 + 5 * (size_t)n_seg_max), sizeof(uint32_t),
                                        hipMemcpyDeviceToDevice, c->stream));
             }
             if (!speculate) {  // (else: swept above)
@@ -1134,7 +1139,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->specsnap, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

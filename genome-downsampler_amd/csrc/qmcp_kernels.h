@@ -52,24 +52,24 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
 // selend_odd (or null): odd stretches write there instead (speculative tables: neighbours overlap);
-// run_if_nonzero (or null): the launch does nothing unless that device word is non-zero
+// redo_in (or null): a later tier -- only stretches whose exact stretch is marked there do anything
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
                               uint32_t n_seg_max, uint32_t* selend_odd = nullptr,
-                              const uint32_t* run_if_nonzero = nullptr);
+                              const uint32_t* redo_in = nullptr);
 // Speculative boundaries (kernels/sweep_segments.inc.hip): further tables of the same windows (tier 1, 2
 // behind the exact one in seg_words), with a boundary `burn` positions of run-in wide wherever a window has no
 // cut (call launch_sweep_segments first; *n_speculative receives how many; burn == 0: the exact table again),
-// the check + merge of the two outputs behind a sweep, and the gate words between tiers.
+// and the check + merge of the two outputs behind a sweep (a disagreement marks its exact stretch in
+// redo_out; a later tier passes the previous tier's marks as redo_in).
 const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t* d_poff, uint32_t n_contigs,
                                                   uint32_t ltot, uint32_t n_windows, uint32_t burn,
                                                   uint32_t* seg_words, uint32_t* n_speculative,
                                                   uint32_t run_ins_apart, uint32_t tier);
 void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                               uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches,
-                              const uint32_t* run_if_nonzero);
-void launch_spec_gate(hipStream_t st, const uint32_t* a, const uint32_t* b_or_null, uint32_t* out);
+                              const uint32_t* redo_in, uint32_t* redo_out);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
@@ -109,12 +109,12 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
                               const void* sorted, const uint32_t* next_head, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t span_bits, uint32_t max_span, uint32_t M,
                               uint32_t* selend, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_odd = nullptr, const uint32_t* run_if_nonzero = nullptr,
+                              uint32_t* selend_odd = nullptr, const uint32_t* redo_in = nullptr,
                               uint32_t* snap = nullptr /* speculative tables: spec_snap_bytes(n_seg_max) */);
 size_t spec_snap_bytes(uint32_t n_cand);
 void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t max_span,
                                     uint32_t* out_even, const uint32_t* out_odd, const uint32_t* snap,
-                                    uint32_t* mismatches, const uint32_t* run_if_nonzero);
+                                    uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
                  unsigned long long* n_kept);

@@ -92,10 +92,11 @@ typedef struct qmcp_hip_stats {
                                  crossed the link and the device rebuilt the ends; 2 = both columns  */
     uint32_t spec_boundaries; /* stretches that started at a speculative boundary (data a few times
                                  deeper than M: no cut point, but the sweep forgets its start)      */
-    uint32_t spec_mismatches; /* of those, how many disagreed with the stretch before them; non-zero:
-                                 a second speculative sweep with three times the run-in was run     */
-    uint32_t spec_retry_mismatches; /* ... and how many disagreed in that one; non-zero: the exact
-                                 sweep was run after all                                            */
+    uint32_t spec_mismatches; /* of those, how many disagreed with the stretch before them: the parts
+                                 of the genome they lie in were swept again with three times the
+                                 run-in                                                              */
+    uint32_t spec_retry_mismatches; /* ... and how many disagreed in that sweep: those parts were
+                                 swept exactly                                                       */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);

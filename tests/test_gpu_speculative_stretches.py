@@ -149,3 +149,23 @@ def test_mixed_spans_with_a_run_in_that_is_too_short(pkg, oracle, solver):
         assert st.spec_boundaries > 0
         assert np.array_equal(got, want), (burn, st.as_dict())
 
+
+
+def test_a_deep_island_in_a_shallow_genome_is_swept_again_alone(pkg, oracle, solver):
+    """depth 2.2 x M, but one long region is 12 x M deep: the boundaries inside it disagree (the sweep
+    does not forget its start there), which marks that part -- between the cut points around it -- for the
+    later tiers, and only that part; the rest keeps its speculative stretches"""
+    rng = np.random.default_rng(123)
+    L, M, span = 6_000_000, 30, 150
+    parts = [rng.integers(0, L - span + 1, size=int(2.2 * M * L / span), dtype=np.uint32)]            # 2.2 x M everywhere
+    lo, hi = 2_000_000, 3_200_000
+    parts.append(rng.integers(lo, hi - span + 1, size=int(10.0 * M * (hi - lo) / span), dtype=np.uint32))  # + 10 x M there
+    s = np.concatenate(parts)
+    s = s[rng.permutation(s.size)]
+    e = s + np.uint32(span - 1)
+    with _env(QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="160"):
+        got = solver.solve(s, e, L, M)
+        st = solver.last_stats
+    # boundaries outside the island hold, those inside disagree in both speculative tiers
+    assert st.spec_boundaries > 20 and 0 < st.spec_mismatches < st.spec_boundaries and st.spec_retry_mismatches > 0, st.as_dict()
+    assert np.array_equal(got, oracle.solve(s, e, L, M))
