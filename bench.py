@@ -85,6 +85,30 @@ def cfg5_share(pkg, torch, dev, solver, stream):
     return best
 
 
+def cfg3_full(pkg, solver):
+    """configs[2] at full size (15 M amplicon pairs on a 29 903-base genome, a tenth of the pairs straddling two
+    amplicons, M = 200) through the fused host entry -- FILTER, pair compaction, solve, mate completion, keep
+    mask over the original read indices -- outside the timed region and never `value`: wall clock of the
+    call (PCIe included), best of three.  Parity: tests/test_gpu_full_size.py (== composed oracle)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import workloads   # (the synthetic-input generators the tests use; nothing of the oracle)
+    s, e, a0, a1, straddle = workloads.amplicon_reads(15_000_000)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        solver.filter_solve(s, e, 29_903, 200, amp_starts=a0, amp_ends=a1, complete_pairs=True)
+        wall = time.perf_counter() - t0
+        st = solver.last_stats
+        if best is None or wall * 1e3 < best["host_call_ms"]:
+            best = {"host_call_ms": round(wall * 1e3, 3), "solve_device_ms": round(float(st.ms_total), 3),
+                    "reads_solved": int(st.n_reads), "kept_before_mates": int(st.n_kept),
+                    "columns_sent": int(st.columns_sent)}
+    best.update({"reads": int(s.size), "pairs_straddling": int(straddle.sum()), "max_coverage": 200,
+                 "Mreads_per_s_host_call": round(s.size / best["host_call_ms"] / 1e3, 1),
+                 "note": "host arrays in -> host keep mask out; not the headline workload"})
+    return best
+
+
 def cpu_baseline(pkg, workload):
     """oracle (single thread) on a bounded sample of the same workload: one contig"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -390,7 +414,8 @@ def main():
                                  "pcie_floor_ms = 8 B/read at the pageable-copy rate host_entry measured"})
             out["plugin_entry"] = best
         if world == 1 and not args.no_extras and args.workload == "cfg4":
-            out["other_configs"] = {"cfg5_share_one_gpu": cfg5_share(pkg, torch, dev, solvers[0], stream)}
+            out["other_configs"] = {"cfg3_full_size": cfg3_full(pkg, solvers[1 % depth]),
+                                    "cfg5_share_one_gpu": cfg5_share(pkg, torch, dev, solvers[0], stream)}
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             base, oracle_mask = cpu_baseline(pkg, args.workload)
             out["cpu_baseline"] = base
