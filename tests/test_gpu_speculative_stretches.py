@@ -169,3 +169,27 @@ def test_a_deep_island_in_a_shallow_genome_is_swept_again_alone(pkg, oracle, sol
     # boundaries outside the island hold, those inside disagree in both speculative tiers
     assert st.spec_boundaries > 20 and 0 < st.spec_mismatches < st.spec_boundaries and st.spec_retry_mismatches > 0, st.as_dict()
     assert np.array_equal(got, oracle.solve(s, e, L, M))
+
+
+def test_two_speculative_solves_in_flight_on_two_contexts(pkg, oracle):
+    """the two-phase entry (qmcp_hip_solve_device_begin / _end) with every tier's launches queued and gated on
+    the device: two contexts, two different problems, collected in the other order"""
+    import torch
+    rng = np.random.default_rng(4)
+    probs = []
+    for M in (50, 35):
+        s, e, offs, lengths = _uniform_contigs(rng, [1_900_000, 800_000], 2.0, M, 150)
+        probs.append((s, e, offs, lengths, M))
+    with pkg.Solver(0) as a, pkg.Solver(0) as b:
+        dev, masks = [], []
+        for sv, (s, e, offs, lengths, M) in zip((a, b), probs):
+            d_s = torch.from_numpy(s.view(np.int32)).cuda()
+            d_e = torch.from_numpy(e.view(np.int32)).cuda()
+            d_m = torch.zeros(pkg.mask_words(s.size), dtype=torch.int64, device="cuda")
+            dev.append((d_s, d_e))
+            masks.append(d_m)
+            sv.solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, lengths, M, d_m.data_ptr(), contig_read_offsets=offs)
+        st_b, st_a = b.solve_end(), a.solve_end()
+        for st, d_m, (s, e, offs, lengths, M) in zip((st_a, st_b), masks, probs):
+            assert st.spec_boundaries >= 2 and st.spec_mismatches == 0, st.as_dict()
+            assert np.array_equal(d_m.cpu().numpy().view(np.uint64), oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
