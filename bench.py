@@ -184,7 +184,8 @@ def main():
     sharded = args.mode == "sharded" and world > 1
     if sharded:
         # one workload for the whole job: contigs dealt by cost (reads + the longest chain of a rank)
-        owned = sharding.assign_contigs([2 * pairs] * n_contigs_job, world, contig_lengths=[L] * n_contigs_job)
+        owned = sharding.assign_contigs([2 * pairs] * n_contigs_job, world, contig_lengths=[L] * n_contigs_job,
+                                        read_length=rl, max_coverage=M)
         my_contigs = owned[rank]
         seeds = [12345 + c for c in my_contigs]
     else:

@@ -1684,27 +1684,41 @@ namespace {
 // cost model of a device's share (measured; the same numbers as
 // genome-downsampler_amd/sharding.py): per read for the bandwidth-bound stages, per position of the
 // LONGEST contig for the sweep (a device's chains run side by side)
-constexpr double kNsPerRead = 0.008, kNsPerPosition = 1.5;
+constexpr double kNsPerRead = 0.008, kNsPerPosition = 1.5, kNsPerPositionStretches = 0.012;
+
+// (sharding.py: _chain_free) a contig shallow and long enough for its sweep to run as stretches
+bool chain_free(double reads, double length, uint32_t span, uint32_t M) {
+    if (span == 0 || M == 0 || length <= 0) return false;
+    const double depth = reads * (double)span / (length * (double)M);
+    return depth < 4.1 && length >= 8.0 * 320.0 * (double)span;
+}
 
 void assign_contigs_by_cost(const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, int n_dev,
-                            std::vector<std::vector<uint32_t>>& owned) {
+                            uint32_t span, uint32_t M, std::vector<std::vector<uint32_t>>& owned) {
     owned.assign((size_t)n_dev, {});
     std::vector<uint32_t> order(n_contigs);
     for (uint32_t c = 0; c < n_contigs; ++c) order[c] = c;
-    auto alone = [&](uint32_t c) { return kNsPerRead * (double)(roff[c + 1] - roff[c]) + kNsPerPosition * (double)lengths[c]; };
+    auto n_reads_of = [&](uint32_t c) { return (double)(roff[c + 1] - roff[c]); };
+    auto stretched = [&](uint32_t c) { return chain_free(n_reads_of(c), (double)lengths[c], span, M); };
+    auto alone = [&](uint32_t c) {
+        return kNsPerRead * n_reads_of(c) + (stretched(c) ? kNsPerPositionStretches : kNsPerPosition) * (double)lengths[c];
+    };
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return alone(a) > alone(b); });
-    std::vector<double> reads((size_t)n_dev, 0.0), longest((size_t)n_dev, 0.0);
+    std::vector<double> reads((size_t)n_dev, 0.0), longest((size_t)n_dev, 0.0), positions((size_t)n_dev, 0.0);
     for (uint32_t c : order) {
         int best = 0;
         double best_cost = 0;
+        const bool st = stretched(c);
         for (int d = 0; d < n_dev; ++d) {
-            const double cost = kNsPerRead * (reads[d] + (double)(roff[c + 1] - roff[c])) +
-                                kNsPerPosition * std::max(longest[d], (double)lengths[c]);
+            const double cost = kNsPerRead * (reads[d] + n_reads_of(c)) +
+                                kNsPerPosition * (st ? longest[d] : std::max(longest[d], (double)lengths[c])) +
+                                kNsPerPositionStretches * (positions[d] + (st ? (double)lengths[c] : 0.0));
             if (d == 0 || cost < best_cost) { best = d; best_cost = cost; }
         }
         owned[best].push_back(c);
-        reads[best] += (double)(roff[c + 1] - roff[c]);
-        longest[best] = std::max(longest[best], (double)lengths[c]);
+        reads[best] += n_reads_of(c);
+        if (st) positions[best] += (double)lengths[c];
+        else longest[best] = std::max(longest[best], (double)lengths[c]);
     }
     for (auto& o : owned) std::sort(o.begin(), o.end());
 }
@@ -1759,7 +1773,9 @@ int qmcp_hip_multi_solve_host(qmcp_hip_multi* m, const uint32_t* starts, const u
     TRY(check_problem(contig_read_offsets, contig_lengths, n_contigs, n_reads, pr));
     const int n_dev = (int)m->ctx.size();
     std::vector<std::vector<uint32_t>> owned;
-    assign_contigs_by_cost(contig_read_offsets, contig_lengths, n_contigs, n_dev, owned);
+    // (the first read's span stands for the read length in the cost model; a mix of lengths only shifts balance)
+    const uint32_t span0 = n_reads != 0 && ends[0] >= starts[0] ? ends[0] - starts[0] + 1 : 0u;
+    assign_contigs_by_cost(contig_read_offsets, contig_lengths, n_contigs, n_dev, span0, max_coverage, owned);
     if (contig_device_out)
         for (int d = 0; d < n_dev; ++d)
             for (uint32_t c : owned[d]) contig_device_out[c] = d;

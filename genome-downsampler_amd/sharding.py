@@ -10,32 +10,51 @@ import numpy as np
 
 # Cost model of one rank's share (measured on MI355X): the bandwidth-bound stages
 # cost time per READ and add up over a rank's contigs; the selection sweep is one serial chain per
-# contig, all of a rank's chains side by side, so it costs the LONGEST contig's length.
+# contig, all of a rank's chains side by side, so it costs the LONGEST contig's length -- unless the contig
+# is shallow enough (mean coverage below 4.1 x M) and long enough for its sweep to run as hundreds of
+# stretches from cut points and speculative boundaries: then the sweep is throughput too, per position.
 NS_PER_READ = 0.008        # prepare + partition + offsets + ranking: ~0.8 ms per 1e8 reads
 NS_PER_POSITION = 1.5      # block-scan sweep on shallow data; deep data (event sweep) is ~0.5
+NS_PER_POSITION_STRETCHES = 0.012   # the same sweep cut into stretches (2.0 ms per 187.5 M positions)
+STRETCH_DEPTH = 4.1        # mean coverage in units of M below which a contig's sweep is cut into stretches
+STRETCH_MIN_BLOCKS = 8 * 320   # ... if it is at least this many read lengths long
 
 
-def rank_cost(read_counts, contig_lengths, contigs):
+def _chain_free(reads, length, read_length, max_coverage):
+    if not read_length or not max_coverage or length <= 0:
+        return False
+    depth = float(reads) * float(read_length) / (float(length) * float(max_coverage))
+    return depth < STRETCH_DEPTH and length >= STRETCH_MIN_BLOCKS * read_length
+
+
+def rank_cost(read_counts, contig_lengths, contigs, read_length=None, max_coverage=None):
     reads = sum(int(read_counts[c]) for c in contigs)
-    longest = max((int(contig_lengths[c]) for c in contigs), default=0)
-    return NS_PER_READ * reads + NS_PER_POSITION * longest
+    longest, stretched = 0, 0
+    for c in contigs:
+        if _chain_free(int(read_counts[c]), int(contig_lengths[c]), read_length, max_coverage):
+            stretched += int(contig_lengths[c])
+        else:
+            longest = max(longest, int(contig_lengths[c]))
+    return NS_PER_READ * reads + NS_PER_POSITION * longest + NS_PER_POSITION_STRETCHES * stretched
 
 
-def assign_contigs(read_counts, world_size, contig_lengths=None):
+def assign_contigs(read_counts, world_size, contig_lengths=None, read_length=None, max_coverage=None):
     """deterministic longest-processing-time assignment of contigs to ranks.  With contig_lengths the
     cost of a rank is reads * NS_PER_READ + (its longest contig) * NS_PER_POSITION -- the sweep's
-    chains run side by side, so a rank pays for its longest one --, without it the read count alone.
-    Returns a list (per rank) of ascending contig ids."""
+    chains run side by side, so a rank pays for its longest one --, without it the read count alone;
+    with read_length and max_coverage as well, contigs whose sweep is cut into stretches (see above)
+    pay per position instead.  Returns a list (per rank) of ascending contig ids."""
     n = len(read_counts)
     if contig_lengths is None:
         contig_lengths = [0] * n
     def alone(c):
-        return NS_PER_READ * int(read_counts[c]) + NS_PER_POSITION * int(contig_lengths[c])
+        return rank_cost(read_counts, contig_lengths, [c], read_length, max_coverage)
     order = sorted(range(n), key=lambda c: (-alone(c), c))
     owned = [[] for _ in range(world_size)]
     for c in order:
         # the rank whose cost AFTER taking c is smallest
-        r = min(range(world_size), key=lambda k: (rank_cost(read_counts, contig_lengths, owned[k] + [c]), k))
+        r = min(range(world_size), key=lambda k: (rank_cost(read_counts, contig_lengths, owned[k] + [c],
+                                                            read_length, max_coverage), k))
         owned[r].append(c)
     return [sorted(o) for o in owned]
 

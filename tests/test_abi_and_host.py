@@ -135,3 +135,22 @@ def test_host_bamapi_mirror_matches_oracle(pkg, layout):
     assert np.array_equal(np.sort(paired), want)
     # reference order: each id followed by its mate, first occurrence only (bam_api.cpp:251-263)
     assert paired[0] == ids[0] and paired[1] == (ids[0] ^ 1)
+
+
+def test_assignment_knows_which_contigs_sweep_as_stretches():
+    """cfg5's shape on 8 ranks: at 2 x M every contig's sweep is cut into stretches, so a rank's cost is its
+    reads (and positions), not its longest contig -- the shares come out even in reads; the same contigs at
+    20 x M are chains, and the longest contig decides"""
+    import importlib
+    sh = importlib.import_module("genome-downsampler_amd.sharding")
+    mb = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+    lengths = [int(1.5e9 * m / sum(mb)) for m in mb]
+    reads = [int(1.0e9 * m / sum(mb)) for m in mb]                      # 100 x coverage at 150 bases
+    shallow = sh.assign_contigs(reads, 8, contig_lengths=lengths, read_length=150, max_coverage=50)
+    share = [sum(reads[c] for c in o) for o in shallow]
+    assert max(share) < 1.08 * (sum(reads) / 8), share
+    blind = sh.assign_contigs(reads, 8, contig_lengths=lengths)        # no depth: every contig counted as a chain
+    assert max(sum(reads[c] for c in o) for o in blind) > max(share)
+    deep = sh.assign_contigs(reads, 8, contig_lengths=lengths, read_length=150, max_coverage=5)
+    assert deep == blind
+    assert sh.rank_cost(reads, lengths, [0], 150, 50) < 0.1 * sh.rank_cost(reads, lengths, [0])

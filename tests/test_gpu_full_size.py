@@ -114,5 +114,5 @@ def test_multi_device_entry_with_contexts_on_one_device(pkg, oracle, solver, n_c
     assert np.array_equal(one, oracle.solve(s, e, lengths, 25, contig_read_offsets=offs))
     assert kept == int(np.unpackbits(one.view(np.uint8)).sum())
     # the C side deals the contigs exactly as sharding.assign_contigs does
-    owned = sh.assign_contigs(counts, n_ctx, contig_lengths=lengths)
+    owned = sh.assign_contigs(counts, n_ctx, contig_lengths=lengths, read_length=150, max_coverage=25)
     assert [where[c] for c in range(len(counts))] == [next(r for r, o in enumerate(owned) if c in o) for c in range(len(counts))]
