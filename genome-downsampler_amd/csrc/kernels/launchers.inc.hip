@@ -460,11 +460,20 @@ void launch_radix_scatter_rec(hipStream_t st, bool first, const uint32_t* keys, 
 
 
 // range-ranked uniform path: geometry, partition table, counts, rank + mark
+static constexpr uint32_t kTwoLevelRangeShift = 15;
 uint32_t range_shift_for(uint32_t ltot) {
     // smallest shift whose ranges (positions 0..ltot inclusive) fit the 256 digits of one pass; beyond
     // 256 ranges of 32 Ki positions a second partition level supplies eight more digit bits
     uint32_t shift = 0;
     while (shift < kMaxRangeShift && (ltot >> shift) >= 256u) ++shift;
+    if ((ltot >> kMaxRangeShift) >= 256u) {
+        // two levels: any shift with <= 65 536 ranges (and so <= 256 super-ranges) will do
+        uint32_t lowest = 0;
+        while ((ltot >> lowest) >= 65536u) ++lowest;
+        uint32_t want = kTwoLevelRangeShift;
+        if (const char* e = std::getenv("QMCP_HIP_RANGE_SHIFT")) want = (uint32_t)std::atoi(e);  // lab
+        shift = want < lowest ? lowest : (want > kMaxRangeShift ? kMaxRangeShift : want);
+    }
     return shift;
 }
 bool range_path_two_level(uint32_t ltot) { return (ltot >> kMaxRangeShift) >= 256u; }

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
     // sit in 32 different banks during the scan
     extern __shared__ uint32_t s_cnt32[];
 #define PADDED(i) ((i) + ((i) >> 5))
-    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_wsum[16], s_esum[16];
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t lo = range_start[range], hi = range_start[range + 1];  // (asked for before the clearing)
     for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[PADDED(i)] = 0;
@@ -360,11 +360,17 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
     if (lane == 63) s_wsum[w] = inc;
     if (empty_positions != nullptr) {
         // how spiky the starts are: the host picks the sweep kernel by it (the event-driven form pays
-        // dearly for blocks with an empty start position)
+        // dearly for blocks with an empty start position).  One global add per workgroup: a long genome has
+        // tens of thousands of ranges, and sixteen same-address atomics from each queue up behind one another.
         empties = wave_sum_u32(empties);
-        if (lane == 0 && empties != 0) atomicAdd(empty_positions, empties);
+        if (lane == 0) s_esum[w] = empties;
     }
     __syncthreads();
+    if (empty_positions != nullptr && threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t x = 0; x < (blockDim.x >> 6); ++x) total += s_esum[x];
+        if (total != 0) atomicAdd(empty_positions, total);
+    }
     uint32_t run = lo + inc - sum;
     for (uint32_t x = 0; x < w; ++x) run += s_wsum[x];
     if (first < width)

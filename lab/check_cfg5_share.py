@@ -20,7 +20,7 @@ got = sol.solve(s, e, lengths, 50, contig_read_offsets=offs)
 st = sol.last_stats
 print(f"device ms = {st.ms_total:.1f} (sweep {st.ms_sweep:.1f}), kept = {st.n_kept}, sort passes = {st.sort_passes}, "
       f"stretches = {st.sweep_stretches} (speculative {st.spec_boundaries}, mismatching {st.spec_mismatches}), {s.size / st.ms_total / 1e3:.0f} Mreads/s", flush=True)
-for name, (launches, ms) in sorted(sol.kernel_times().items(), key=lambda kv: -kv[1][1])[:8]:
+for name, (launches, ms) in sorted(sol.kernel_times().items(), key=lambda kv: -kv[1][1])[:14]:
     print(f"  {name:44s} {ms / launches:.3f} ms", flush=True)
 if with_oracle:
     import oracle_py
