@@ -21,22 +21,26 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
                                                    uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
                                                    uint32_t win, uint32_t* __restrict__ cut) {
     __shared__ uint32_t s_first;
+    __shared__ uint32_t s_cstart[256];  // contig starts (fewer than 256 contigs when this runs)
     const uint32_t w = blockIdx.x;
     const uint32_t lo = max(w * win, 1u);
     const uint32_t hi = (uint32_t)min((uint64_t)(w + 1) * win, (uint64_t)ltot);
     if (threadIdx.x == 0) s_first = kNoCut;
+    if (threadIdx.x < n_contigs) s_cstart[threadIdx.x] = (uint32_t)contig_pos_off[threadIdx.x];
     __syncthreads();
-    // four strips of 256 positions per round: the first position wins, whichever strip it is in
-    for (uint32_t q0 = lo; q0 < hi; q0 += 1024) {
+    // sixteen strips of blockDim.x positions per round (all their loads in flight before the round's barrier: a
+    // window without a cut is scanned to its end, 244 k positions on a genome-sized share): the first
+    // position wins, whichever strip it is in
+    for (uint32_t q0 = lo; q0 < hi; q0 += 16 * blockDim.x) {
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t q = q0 + k * 256 + threadIdx.x;
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t q = q0 + k * blockDim.x + threadIdx.x;
             if (q < hi) {
                 // coverage of position q - 1: starts up to it minus ends before it
                 const uint32_t cov = boff[q] - (eoff != nullptr ? eoff[q - 1] : boff[q >= ell ? q - ell : 0u]);
                 if (cov <= M) {
                     bool contig_start = false;
-                    for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= (uint32_t)contig_pos_off[c] == q;
+                    for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= s_cstart[c] == q;
                     if (!contig_start) atomicMin(&s_first, q);
                 }
             }
@@ -69,16 +73,19 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
                                                                       uint32_t win, uint32_t burn, uint32_t stride,
                                                                       uint32_t* __restrict__ seg,
                                                                       uint32_t* __restrict__ n_speculative /* += ; or null */) {
-    __shared__ uint32_t s_pos[kSegMaxCandidates];
-    __shared__ uint32_t s_exact[kSegMaxCandidates];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[kSegMaxCandidates];
+    __shared__ __attribute__((aligned(16))) uint32_t s_exact[kSegMaxCandidates];
     __shared__ uint32_t s_sorted[kSegMaxCandidates];
     __shared__ uint32_t s_count, s_spec;
+    __shared__ uint32_t s_cpos[257];  // contig starts (+ the end of the last): read once, not in every thread's loops
     const uint32_t t = threadIdx.x;
     const uint32_t n_cand = n_contigs + n_windows;
+    if (t <= n_contigs && t < 257) s_cpos[t] = (uint32_t)contig_pos_off[t];
+    __syncthreads();
     uint32_t mine = kNoCut;
     bool spec = false;
     if (t < n_contigs) {
-        if (contig_pos_off[t + 1] > contig_pos_off[t]) mine = (uint32_t)contig_pos_off[t];  // empty contigs: no work
+        if (s_cpos[t + 1] > s_cpos[t]) mine = s_cpos[t];  // empty contigs: no work
     } else if (t - n_contigs < n_windows) {
         const uint32_t w = t - n_contigs;
         mine = cut[w];
@@ -94,9 +101,12 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
     if (spec) {
         // the run-in must lie inside one stretch: no exact boundary in (mine - burn, mine]
         bool ok = mine >= burn;
-        for (uint32_t k = 0; k < n_cand; ++k) {
-            const uint32_t q = s_pos[k];
-            if (q != kNoCut && q <= mine && q + burn > mine) ok = false;
+        for (uint32_t k = 0; k < n_cand; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
+            const uint32_t q4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q4[j] != kNoCut && q4[j] <= mine && q4[j] + burn > mine) ok = false;
         }
         if (!ok) { mine = kNoCut; spec = false; }
     }
@@ -108,7 +118,12 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
         // candidates are distinct: non-empty contigs start at distinct positions, windows are
         // disjoint, a cut is never a contig's first position, and a speculative boundary has no exact one
         // within `burn` before it
-        for (uint32_t k = 0; k < n_cand; ++k) rank += s_pos[k] < mine ? 1u : 0u;
+        // (four candidates per LDS read: entries from n_cand on hold kNoCut, which is below nothing)
+#pragma unroll 4
+        for (uint32_t k = 0; k < n_cand; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
+            rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+        }
         s_sorted[rank] = mine;
         atomicAdd(&s_count, 1u);
         if (spec) atomicAdd(&s_spec, 1u);
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
         const uint32_t count = s_count;
         uint32_t cend = ltot;
         for (uint32_t c = 0; c < n_contigs; ++c) {
-            const uint32_t a = (uint32_t)contig_pos_off[c], b = (uint32_t)contig_pos_off[c + 1];
+            const uint32_t a = s_cpos[c], b = s_cpos[c + 1];
             if (a <= mine && mine < b) cend = b;
         }
         const uint32_t next = rank + 1 < count ? s_sorted[rank + 1] : ltot;
@@ -129,7 +144,11 @@ __global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint
         // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
         // disagreement marks for another go, and what the later tiers look up to see whether they have work
         uint32_t exact_before = 0;
-        for (uint32_t k = 0; k < n_cand; ++k) exact_before += (s_exact[k] != kNoCut && s_exact[k] <= mine) ? 1u : 0u;
+#pragma unroll 4
+        for (uint32_t k = 0; k < n_cand; k += 4) {  // (kNoCut is the largest value: never <= a position)
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
+            exact_before += (v.x <= mine ? 1u : 0u) + (v.y <= mine ? 1u : 0u) + (v.z <= mine ? 1u : 0u) + (v.w <= mine ? 1u : 0u);
+        }
         seg[1 + 4 * n_cand + rank] = exact_before - 1u;  // (>= 1: every position lies behind its contig's start)
         if (rank == 0) seg[0] = count;
     }
