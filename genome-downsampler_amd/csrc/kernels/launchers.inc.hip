@@ -147,12 +147,11 @@ void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_
     hipLaunchKernelGGL(k_spec_merge_mixed, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, max_span, out_even, out_odd,
                        redo_in);
 }
-void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
-                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches,
-                              const uint32_t* redo_in, uint32_t* redo_out) {
-    hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, out_even, out_odd, mismatches,
+void launch_spec_verify(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
+                        const uint32_t* owned, const uint32_t* run_in, uint32_t* mismatches,
+                        const uint32_t* redo_in, uint32_t* redo_out) {
+    hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, owned, run_in, mismatches,
                        redo_in, redo_out);
-    hipLaunchKernelGGL(k_spec_merge, dim3(n_cand, 32), dim3(256), 0, st, seg, n_cand, out_even, out_odd, redo_in);
 }
 
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
@@ -184,7 +183,7 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_odd, const uint32_t* redo_in) {
+                              uint32_t* selend_run_in, const uint32_t* redo_in) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_GEN(EE)                                                                             \
@@ -193,7 +192,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,      \
-                           ell, M, ltot, selend, iter_stats, seg, selend_odd, redo_in, n_seg_max);           \
+                           ell, M, ltot, selend, iter_stats, seg, selend_run_in, redo_in, n_seg_max);        \
     }
     switch (e) {
         case 1: QMCP_SWEEP_GEN(1); break;

@@ -164,11 +164,11 @@ __device__ __forceinline__ bool spec_stretch_idle(const uint32_t* __restrict__ s
     return redo_in != nullptr && redo_in[seg[1 + 4 * n_cand + r]] == 0;
 }
 
-// one workgroup per stretch: a speculative one compares its own last ell positions before the position it
-// owns from with what the stretch before it (the other output) holds there
+// one workgroup per stretch: a speculative one compares the last ell positions of its run-in (`run_in`: where
+// the sweep stored them) with what the stretch that owns those positions stored in `owned`
 __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict__ seg, uint32_t n_cand, uint32_t ell,
-                                                     const uint32_t* __restrict__ out_even,
-                                                     const uint32_t* __restrict__ out_odd,
+                                                     const uint32_t* __restrict__ owned,
+                                                     const uint32_t* __restrict__ run_in,
                                                      uint32_t* __restrict__ mismatches,
                                                      const uint32_t* __restrict__ redo_in /* or null: every stretch */,
                                                      uint32_t* __restrict__ redo_out) {
@@ -176,26 +176,12 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict_
     if (r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
-    const uint32_t* mine = (r & 1u) ? out_odd : out_even;
-    const uint32_t* prev = (r & 1u) ? out_even : out_odd;
     bool differs = false;
-    for (uint32_t i = threadIdx.x; i < ell; i += blockDim.x) differs |= mine[own - ell + i] != prev[own - ell + i];
+    for (uint32_t i = threadIdx.x; i < ell; i += blockDim.x) differs |= run_in[own - ell + i] != owned[own - ell + i];
     if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) {
         atomicAdd(mismatches, 1u);
         redo_out[seg[1 + 4 * n_cand + r]] = 1u;
     }
-}
-
-// the odd stretches' own positions move to the even output (which the ranking reads); a marked part's
-// values are overwritten by the tier that sweeps it again
-__global__ __launch_bounds__(256) void k_spec_merge(const uint32_t* __restrict__ seg, uint32_t n_cand,
-                                                    uint32_t* __restrict__ out_even,
-                                                    const uint32_t* __restrict__ out_odd,
-                                                    const uint32_t* __restrict__ redo_in) {
-    const uint32_t r = blockIdx.x;
-    if ((r & 1u) == 0 || r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
-    const uint32_t own = seg[1 + 3 * n_cand + r], end = seg[1 + 3 * r + 1];
-    for (uint32_t p = own + blockIdx.y * blockDim.x + threadIdx.x; p < end; p += gridDim.y * blockDim.x) out_even[p] = out_odd[p];
 }
 
 // Mixed spans (the register-resident event sweep): a bucket keeps giving reads while any of them is alive,

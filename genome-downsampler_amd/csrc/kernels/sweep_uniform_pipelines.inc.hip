@@ -541,7 +541,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                            uint32_t* __restrict__ selend,
                                                            uint32_t* __restrict__ iter_stats,
                                                            const uint32_t* __restrict__ seg,
-                                                           uint32_t* __restrict__ selend_odd /* odd stretches' output; or null */,
+                                                           uint32_t* __restrict__ selend_run_in /* speculative tables: where a stretch's
+                                                               run-in (the positions before the one it owns from) goes; or null */,
                                                            const uint32_t* __restrict__ redo_in /* or null: every stretch */,
                                                            uint32_t n_cand /* entries per column of seg (redo_in != null) */) {
     using Ly = MgLayout<E>;
@@ -562,7 +563,15 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     const uint32_t n_blocks = (Lrun + ell - 1) / ell;
     const uint32_t n_groups = n_blocks / kG;
     const uint32_t* __restrict__ cb = boff + base;
-    uint32_t* __restrict__ csel = (selend_odd != nullptr && (c_id & 1u) ? selend_odd : selend) + base;
+    uint32_t* __restrict__ csel = selend + base;
+    // a speculative stretch's run-in (a whole number of blocks) is stored apart: the stretch before it owns
+    // those positions, and only the last block of it is looked at again (k_spec_verify)
+    uint32_t* __restrict__ csel_run_in = csel;
+    uint32_t own_blk = 0;
+    if (selend_run_in != nullptr && seg != nullptr) {
+        csel_run_in = selend_run_in + base;
+        own_blk = (seg[1 + 3 * n_cand + c_id] - base) / ell;
+    }
     const uint32_t trash = ltot - base;
     const uint32_t last_lane = (ell - 1) / E, last_r = (ell - 1) % E;
     __builtin_amdgcn_s_setprio(3);
@@ -773,19 +782,20 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                         const uint32_t blk_first = (g * kG + k) * ell;
                         const uint32_t p0 = blk_first + lane * E;
                         const bool full = lane * E + E <= ell && p0 + E <= Lrun;
+                        uint32_t* __restrict__ const out = g * kG + k < own_blk ? csel_run_in : csel;
                         if constexpr (E == 1) {
-                            csel[full ? p0 : trash] = sel[0];
+                            out[full ? p0 : trash] = sel[0];
                         } else {
                             typedef typename RowVec<E>::type V;
                             V vv;
 #pragma unroll
                             for (int r = 0; r < E; ++r) vv[r] = sel[r];
-                            *reinterpret_cast<V*>(csel + (full ? p0 : trash)) = vv;
+                            *reinterpret_cast<V*>(out + (full ? p0 : trash)) = vv;
                             if (ell % E != 0 || blk_first + ell > Lrun) {
 #pragma unroll
                                 for (int r = 0; r < E; ++r) {
                                     const uint32_t i = lane * E + r;
-                                    if (!full && i < ell && blk_first + i < Lrun) csel[blk_first + i] = sel[r];
+                                    if (!full && i < ell && blk_first + i < Lrun) out[blk_first + i] = sel[r];
                                 }
                             }
                         }
@@ -800,9 +810,15 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
 #undef MG_SLOT
 #undef MG_SLOT0
     if (role == 1) {
-        if (n_groups * kG < n_blocks)
-            sweep_full_run<E>(cb, n_groups * kG, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last,
-                              csel);
+        if (n_groups * kG < n_blocks) {
+            // (the blocks behind the last whole group; those of them that are run-in go to the other output)
+            const uint32_t t0 = n_groups * kG;
+            const uint32_t mid = min(max(own_blk, t0), n_blocks);
+            if (t0 < mid)
+                sweep_full_run<E>(cb, t0, mid, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel_run_in);
+            if (mid < n_blocks)
+                sweep_full_run<E>(cb, mid, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
+        }
         if (iter_stats && lane == 0) {
             atomicAdd(&iter_stats[0], n_blocks);  // every block is in the general form here
             atomicAdd(&iter_stats[1], n_blocks);

@@ -474,8 +474,8 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
                                                       out_odd, redo_in);
             },
             [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
-                qmcp::launch_spec_verify_merge(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches,
-                                               redo_in, redo_out);
+                qmcp::launch_spec_verify(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches,
+                                         redo_in, redo_out);
             });
     }
     if (qmcp::sweep_uniform_mw_supported(span)) {

@@ -51,12 +51,12 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
 // seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
-// selend_odd (or null): odd stretches write there instead (speculative tables: neighbours overlap);
+// selend_run_in (or null): speculative tables -- a stretch's run-in is stored there, what it owns in selend;
 // redo_in (or null): a later tier -- only stretches whose exact stretch is marked there do anything
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
-                              uint32_t n_seg_max, uint32_t* selend_odd = nullptr,
+                              uint32_t n_seg_max, uint32_t* selend_run_in = nullptr,
                               const uint32_t* redo_in = nullptr);
 // Speculative boundaries (kernels/sweep_segments.inc.hip): further tables of the same windows (tier 1, 2
 // behind the exact one in seg_words), with a boundary `burn` positions of run-in wide wherever a window has no
@@ -67,9 +67,9 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
                                                   uint32_t ltot, uint32_t n_windows, uint32_t burn,
                                                   uint32_t* seg_words, uint32_t* n_speculative,
                                                   uint32_t run_ins_apart, uint32_t tier);
-void launch_spec_verify_merge(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
-                              uint32_t* out_even, const uint32_t* out_odd, uint32_t* mismatches,
-                              const uint32_t* redo_in, uint32_t* redo_out);
+void launch_spec_verify(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
+                        const uint32_t* owned, const uint32_t* run_in, uint32_t* mismatches,
+                        const uint32_t* redo_in, uint32_t* redo_out);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
