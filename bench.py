@@ -148,6 +148,9 @@ def main():
                          "launch of the run is then the workload's own)")
     ap.add_argument("--mode", choices=["per-gpu", "sharded"], default="per-gpu",
                     help="N > 1: the workload per GPU (weak scaling) or one workload sharded by contig (strong)")
+    ap.add_argument("--exchange", choices=["gather", "all_gather"], default="gather",
+                    help="N > 1: the keep masks go to rank 0 (what a caller needs: one Solution; N/8 bytes per rank over "
+                         "rank 0's seven links side by side) or to every rank")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="solves kept in flight per GPU (two solver contexts)")
     # rehearsal knobs (not used by the driver): run several ranks on ONE GPU over gloo to
@@ -221,7 +224,7 @@ def main():
     depth = args.in_flight
     solvers = [pkg.Solver(local_rank) for _ in range(depth)]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    gathers = [None] * n_buf        # async all_gather handles per mask buffer
+    gathers = [None] * n_buf        # async gather handles per mask buffer
     in_flight = [None] * depth      # per solver context: the mask buffer of its pending solve
     step_no = [0]
     last_buf = [0]
@@ -236,7 +239,11 @@ def main():
         last_buf[0] = b
         if world > 1:
             # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
-            gathers[b] = dist.all_gather_into_tensor(d_alls[b], d_masks[b], async_op=True)
+            if args.exchange == "all_gather":
+                gathers[b] = dist.all_gather_into_tensor(d_alls[b], d_masks[b], async_op=True)
+            else:
+                gathers[b] = dist.gather(d_masks[b], gather_list=list(d_alls[b].chunk(world)) if rank == 0 else None,
+                                         dst=0, async_op=True)
 
     def step():
         s_no = step_no[0]
@@ -349,7 +356,7 @@ def main():
                             + f"{n_contigs_job} contigs x rand_reads_uniform("
                             f"{pairs} pairs, L={L}, len={rl}), {n_contigs_job * 2 * pairs} reads, M={M}; "
                             "device-resident reads -> device keep bitmask"
-                            + ("; + RCCL all_gather of the keep masks, overlapped with the following "
+                            + (f"; + RCCL {args.exchange} of the keep masks" + (" at rank 0" if args.exchange == "gather" else "") + ", overlapped with the following "
                                "solves (all completed inside the timed region)"
                                if world > 1 else ""),
                 "multi_gpu_mode": args.mode if world > 1 else "single GPU",
