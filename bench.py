@@ -52,25 +52,16 @@ def cfg5_share(pkg, torch, dev, solver, stream):
     10^9 reads on 1.5 * 10^9 positions, M = 50) at 1/8 scale -- 125 M reads on 187.5 M positions, coverage
     2 x M -- outside the timed region and never `value`: device-resident reads -> device keep mask, best of
     three.  Its kept set is compared with the oracle contig by contig in tests/test_gpu_full_size.py."""
-    grch38_mb = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83,
-                 80, 59, 64, 47, 51, 156, 57]
-    frac = np.array(grch38_mb, dtype=np.float64) / sum(grch38_mb)
-    lengths = (frac * (1.5e9 / 8)).astype(np.int64)
-    pairs = (frac * (0.5e9 / 8)).astype(np.int64)
-    ss, ee = [], []
-    for c, (L, p) in enumerate(zip(lengths, pairs)):
-        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, int(p), int(L), 150, seed=12345 + c)
-        ss.append(s)
-        ee.append(e)
-    offs = np.concatenate([[0], np.cumsum(2 * pairs)]).astype(np.uint64)
-    n = int(offs[-1])
-    d_s = torch.from_numpy(np.concatenate(ss).view(np.int32)).to(dev)
-    d_e = torch.from_numpy(np.concatenate(ee).view(np.int32)).to(dev)
-    del ss, ee
+    synthetic = importlib.import_module("genome-downsampler_amd.synthetic")
+    s, e, offs, lengths = synthetic.wgs_contigs(int(1.5e9 / 8), int(0.5e9 / 8))
+    n = int(s.size)
+    d_s = torch.from_numpy(s.view(np.int32)).to(dev)
+    d_e = torch.from_numpy(e.view(np.int32)).to(dev)
+    del s, e
     d_m = torch.zeros(pkg.mask_words(n), dtype=torch.int64, device=dev)
     best = None
     for _ in range(3):
-        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n, lengths.astype(np.uint32), 50, d_m.data_ptr(),
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n, lengths, 50, d_m.data_ptr(),
                                  contig_read_offsets=offs, stream=stream)
         if best is None or st.ms_total < best["device_ms"]:
             best = {"device_ms": round(float(st.ms_total), 3), "sweep_ms": round(float(st.ms_sweep), 3),
@@ -90,9 +81,8 @@ def cfg3_full(pkg, solver):
     amplicons, M = 200) through the fused host entry -- FILTER, pair compaction, solve, mate completion, keep
     mask over the original read indices -- outside the timed region and never `value`: wall clock of the
     call (PCIe included), best of three.  Parity: tests/test_gpu_full_size.py (== composed oracle)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import workloads   # (the synthetic-input generators the tests use; nothing of the oracle)
-    s, e, a0, a1, straddle = workloads.amplicon_reads(15_000_000)
+    synthetic = importlib.import_module("genome-downsampler_amd.synthetic")
+    s, e, a0, a1, straddle = synthetic.amplicon_reads(15_000_000)
     best = None
     for _ in range(3):
         t0 = time.perf_counter()

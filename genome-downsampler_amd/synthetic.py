@@ -1,0 +1,58 @@
+"""Synthetic inputs for the BASELINE.json configs that libs/reads-gen does not produce directly
+(SURVEY.md section 8d): the amplicon panel of configs[2] and the GRCh38-shaped contig set of
+configs[4].  Deterministic (numpy PCG64 with fixed seeds).  Used by the tests (tests/workloads.py
+re-exports this module), by bench.py's other_configs legs and by the lab scripts."""
+import importlib
+
+import numpy as np
+
+# GRCh38 chr1-22, X, Y lengths in Mb (rounded) -- only the proportions matter
+GRCH38_MB = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83,
+             80, 59, 64, 47, 51, 156, 57]
+
+
+def amplicon_panel(genome_length=29_903, size=400, step=300):
+    """tiled amplicons [start, end] (inclusive), primers are the 25 bp at each end"""
+    starts = np.arange(0, genome_length - size, step, dtype=np.int64)
+    starts = starts[starts + size - 1 < genome_length][:98]
+    return starts.astype(np.uint32), (starts + size - 1).astype(np.uint32)
+
+
+def amplicon_reads(n_pairs, seed=12345, read_length=150, straddle_fraction=0.10):
+    """configs[2]: pairs drawn from 98 tiled amplicons with weights x - x^2 + 0.1; mate 1 starts
+    within 25 bp of the amplicon start, mate 2 ends within 25 bp of the amplicon end; a tenth of
+    the pairs take mate 2 from the NEXT amplicon (they must be dropped by the FILTER)."""
+    rng = np.random.default_rng(seed)
+    a0, a1 = amplicon_panel()
+    k = a0.size
+    x = np.arange(k) / (k - 1)
+    w = x - x * x + 0.1
+    w /= w.sum()
+    amp = rng.choice(k, size=n_pairs, p=w)
+    straddle = (rng.random(n_pairs) < straddle_fraction) & (amp < k - 1)
+    amp2 = np.where(straddle, amp + 1, amp)
+    s1 = a0[amp].astype(np.int64) + rng.integers(0, 26, size=n_pairs)
+    e2 = a1[amp2].astype(np.int64) - rng.integers(0, 26, size=n_pairs)
+    starts = np.empty(2 * n_pairs, np.uint32)
+    ends = np.empty(2 * n_pairs, np.uint32)
+    starts[0::2] = s1
+    ends[0::2] = s1 + read_length - 1
+    starts[1::2] = e2 - read_length + 1
+    ends[1::2] = e2
+    return starts, ends, a0, a1, straddle
+
+
+def wgs_contigs(total_length, total_pairs, read_length=150, seed=12345):
+    """configs[4] shape: 24 contigs with lengths proportional to GRCh38, reads proportional to
+    length, rand_reads_uniform(seed + c) per contig"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    frac = np.array(GRCH38_MB, dtype=np.float64) / sum(GRCH38_MB)
+    lengths = np.maximum((frac * total_length).astype(np.int64), 2 * read_length + 1)
+    pairs = np.maximum((frac * total_pairs).astype(np.int64), 1)
+    ss, ee = [], []
+    for c, (L, p) in enumerate(zip(lengths, pairs)):
+        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, int(p), int(L), read_length, seed=seed + c)
+        ss.append(s)
+        ee.append(e)
+    offs = np.concatenate([[0], np.cumsum(2 * pairs)]).astype(np.uint64)
+    return np.concatenate(ss), np.concatenate(ee), offs, lengths.astype(np.uint32)
