@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
 // its stretch starts `burn` positions earlier from the state of a cut point (every read over the start
 // kept) and OWNS the positions from b on (only every stride-th window is a candidate, so that stretches stay
 // several run-ins long); the stretch before it runs up to b as before.  The two have
-// then both computed [b - burn, b), into separate outputs (stretches alternate between two), and
+// then both computed [b - burn, b) -- a stretch's run-in is stored apart from what it owns -- and
 // k_spec_verify compares the last ell positions before b: equal kept counts there are equal states, so
 // everything the speculative stretch selected from b on is what the serial sweep selects.  A mismatch
 // marks the part of the genome it lies in for another go (see "Tiers" below).

@@ -350,8 +350,8 @@ SpecWords spec_words(qmcp_hip_ctx* c) {
 }
 
 // The tiers of a speculative sweep.  `unit`: positions per block of run-in (the span; the largest span of a
-// mix), `round_to`: the run-in is made a multiple of this many positions.  sweep(table, odd stretches' output
-// or null, marks to obey or null) launches the sweep kernel; check(table, mismatch counter, marks to obey or
+// mix), `round_to`: the run-in is made a multiple of this many positions.  sweep(table, second output or null,
+// marks to obey or null) launches the sweep kernel; check(table, mismatch counter, marks to obey or
 // null, marks to set) the comparison and the merge behind it.  A disagreement marks the exact stretch it
 // lies in; tier 2 (three times the run-in) sweeps only marked parts, the exact sweep only what tier 2 marked.
 template <class Sweep, class Check>
@@ -377,10 +377,11 @@ int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint3
         seg2 = qmcp::launch_sweep_segments_speculative(st, poff, n_contigs, ltot, windows, burn2, (uint32_t*)c->segs.p,
                                                        w.n_spec2, run_ins_apart, 2);
     }
-    uint32_t* out_odd = (uint32_t*)c->cstart.p;
+    // the second output: one span -- every stretch's run-in; a mix of spans -- the odd stretches' whole output
+    uint32_t* second_out = (uint32_t*)c->cstart.p;
     {
         KernelSpan sp(c, sweep_name, st);
-        if (!sweep(seg1, out_odd, nullptr)) return fail(QMCP_ERANGE, "speculative sweep: span not supported");
+        if (!sweep(seg1, second_out, nullptr)) return fail(QMCP_ERANGE, "speculative sweep: span not supported");
     }
     {
         KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
@@ -388,7 +389,7 @@ int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint3
     }
     {
         KernelSpan sp(c, "second tier, where the first disagreed", st);
-        (void)sweep(seg2, out_odd, redo1);
+        (void)sweep(seg2, second_out, redo1);
         check(seg2, w.mismatches2, redo1, redo2);
     }
     KernelSpan sp(c, "exact sweep, where the second tier disagreed", st);
@@ -469,9 +470,9 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     if (speculate && seg != nullptr) {
         return speculative_sweep(
             c, st, n_contigs, ltot, windows, span, span, burn_blocks, 4, seg, "k_sweep_uniform_gen",
-            [&](const uint32_t* table, uint32_t* out_odd, const uint32_t* redo_in) {
+            [&](const uint32_t* table, uint32_t* run_in_out, const uint32_t* redo_in) {
                 return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, span, M, ltot, selend, d_iters, table, n_seg_max,
-                                                      out_odd, redo_in);
+                                                      run_in_out, redo_in);
             },
             [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
                 qmcp::launch_spec_verify(st, table, n_seg_max, span, selend, (const uint32_t*)c->cstart.p, mismatches,
