@@ -99,10 +99,11 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
 
 // Cut-point segmentation: window count for a genome of ltot positions (0: not worth it).  Windows
 // hold at least 64 blocks, so a stretch is long enough to amortise a pipeline start.
-uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs) {
+uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs, uint32_t max_windows) {
     if (n_contigs >= 256 || ell == 0) return 0;
     const uint64_t w = (uint64_t)ltot / (64ull * ell);
-    const uint32_t cap = (uint32_t)kSegMaxCandidates - 256;
+    const uint32_t most = (uint32_t)kSegMaxCandidates - 256;
+    const uint32_t cap = max_windows < most ? max_windows : most;
     return (uint32_t)(w < 2 ? 0 : (w > cap ? cap : w));
 }
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
@@ -118,7 +119,7 @@ const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, cons
     uint32_t* seg = seg_words + n_windows;
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
     hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, eoff, d_poff, n_contigs, ltot, ell, M, win, cut);
-    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
+    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegThreads), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, 0u, 1u, seg, (uint32_t*)nullptr);
     return seg;
 }
@@ -134,7 +135,7 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
     const uint32_t* cut = seg_words;
     uint32_t* seg = seg_words + n_windows + (size_t)tier * (1 + 5 * ((size_t)n_contigs + n_windows));
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
-    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegMaxCandidates), 0, st, cut, n_windows, d_poff, n_contigs,
+    hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegThreads), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, burn, stride < 1 ? 1u : stride, seg, n_speculative);
     return seg;
 }

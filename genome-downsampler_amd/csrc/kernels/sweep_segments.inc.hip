@@ -13,7 +13,7 @@
 // sweep kernels index by workgroup: [count, then {start, end, contig end} per stretch].
 
 static constexpr uint32_t kNoCut = 0xFFFFFFFFu;
-static constexpr int kSegMaxCandidates = 1024;  // contigs + windows
+static constexpr int kSegMaxCandidates = 4096;  // contigs + windows (the one-span sweeps ask for at most 1024)
 
 __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ boff,
                                                    const uint32_t* __restrict__ eoff,  // null: one span, ell
@@ -66,93 +66,124 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
 // marks the part of the genome it lies in for another go (see "Tiers" below).
 // Table: [count, {start, end, contig end} per stretch, then the position each stretch owns from, then the
 // index of the exact table's stretch it lies in].
-__global__ __launch_bounds__(kSegMaxCandidates) void k_build_segments(const uint32_t* __restrict__ cut,
-                                                                      uint32_t n_windows,
-                                                                      const uint64_t* __restrict__ contig_pos_off,
-                                                                      uint32_t n_contigs, uint32_t ltot,
-                                                                      uint32_t win, uint32_t burn, uint32_t stride,
-                                                                      uint32_t* __restrict__ seg,
-                                                                      uint32_t* __restrict__ n_speculative /* += ; or null */) {
+static constexpr int kSegThreads = 1024;
+static constexpr int kSegPerThread = kSegMaxCandidates / kSegThreads;  // candidates a thread looks after
+
+__global__ __launch_bounds__(kSegThreads) void k_build_segments(const uint32_t* __restrict__ cut,
+                                                                uint32_t n_windows,
+                                                                const uint64_t* __restrict__ contig_pos_off,
+                                                                uint32_t n_contigs, uint32_t ltot,
+                                                                uint32_t win, uint32_t burn, uint32_t stride,
+                                                                uint32_t* __restrict__ seg,
+                                                                uint32_t* __restrict__ n_speculative /* = ; or null */) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[kSegMaxCandidates];
     __shared__ __attribute__((aligned(16))) uint32_t s_exact[kSegMaxCandidates];
     __shared__ uint32_t s_sorted[kSegMaxCandidates];
     __shared__ uint32_t s_count, s_spec;
     __shared__ uint32_t s_cpos[257];  // contig starts (+ the end of the last): read once, not in every thread's loops
-    const uint32_t t = threadIdx.x;
     const uint32_t n_cand = n_contigs + n_windows;
-    if (t <= n_contigs && t < 257) s_cpos[t] = (uint32_t)contig_pos_off[t];
+    const uint32_t n_pad = (n_cand + 3u) & ~3u;  // the loops below read four candidates at a time
+    if (threadIdx.x <= n_contigs && threadIdx.x < 257) s_cpos[threadIdx.x] = (uint32_t)contig_pos_off[threadIdx.x];
+    if (threadIdx.x == 0) { s_count = 0; s_spec = 0; }
     __syncthreads();
-    uint32_t mine = kNoCut;
-    bool spec = false;
-    if (t < n_contigs) {
-        if (s_cpos[t + 1] > s_cpos[t]) mine = s_cpos[t];  // empty contigs: no work
-    } else if (t - n_contigs < n_windows) {
-        const uint32_t w = t - n_contigs;
-        mine = cut[w];
-        if (mine == kNoCut && burn != 0 && w >= 1 && w % stride == 0 && (uint64_t)w * win < ltot) {
-            mine = w * win;
-            spec = true;
-        }
-    }
-    s_pos[t] = spec ? kNoCut : mine;  // the exact boundaries first
-    s_exact[t] = spec ? kNoCut : mine;
-    if (t == 0) { s_count = 0; s_spec = 0; }
-    __syncthreads();
-    if (spec) {
-        // the run-in must lie inside one stretch: no exact boundary in (mine - burn, mine]
-        bool ok = mine >= burn;
-        for (uint32_t k = 0; k < n_cand; k += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
-            const uint32_t q4[4] = {v.x, v.y, v.z, v.w};
+    // candidate t = threadIdx.x + j * kSegThreads: contig starts first, then the windows
+    uint32_t mine[kSegPerThread];
+    bool spec[kSegPerThread];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q4[j] != kNoCut && q4[j] <= mine && q4[j] + burn > mine) ok = false;
+    for (int j = 0; j < kSegPerThread; ++j) {
+        const uint32_t t = threadIdx.x + (uint32_t)j * kSegThreads;
+        mine[j] = kNoCut;
+        spec[j] = false;
+        if (t < n_contigs) {
+            if (s_cpos[t + 1] > s_cpos[t]) mine[j] = s_cpos[t];  // empty contigs: no work
+        } else if (t < n_cand) {
+            const uint32_t w = t - n_contigs;
+            mine[j] = cut[w];
+            if (mine[j] == kNoCut && burn != 0 && w >= 1 && w % stride == 0 && (uint64_t)w * win < ltot) {
+                mine[j] = w * win;
+                spec[j] = true;
+            }
         }
-        if (!ok) { mine = kNoCut; spec = false; }
+        if (t < n_pad) {
+            s_pos[t] = spec[j] ? kNoCut : mine[j];  // the exact boundaries first
+            s_exact[t] = spec[j] ? kNoCut : mine[j];
+        }
     }
     __syncthreads();
-    s_pos[t] = mine;
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) {
+        if (spec[j]) {
+            // the run-in must lie inside one stretch: no exact boundary in (mine - burn, mine]
+            const uint32_t m = mine[j];
+            bool ok = m >= burn;
+            for (uint32_t k = 0; k < n_pad; k += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
+                const uint32_t q4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (q4[i] != kNoCut && q4[i] <= m && q4[i] + burn > m) ok = false;
+            }
+            if (!ok) { mine[j] = kNoCut; spec[j] = false; }
+        }
+    }
     __syncthreads();
-    uint32_t rank = 0;
-    if (mine != kNoCut) {
-        // candidates are distinct: non-empty contigs start at distinct positions, windows are
-        // disjoint, a cut is never a contig's first position, and a speculative boundary has no exact one
-        // within `burn` before it
-        // (four candidates per LDS read: entries from n_cand on hold kNoCut, which is below nothing)
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) {
+        const uint32_t t = threadIdx.x + (uint32_t)j * kSegThreads;
+        if (t < n_pad) s_pos[t] = mine[j];
+    }
+    __syncthreads();
+    uint32_t rank[kSegPerThread];
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) {
+        rank[j] = 0;
+        if (mine[j] != kNoCut) {
+            // candidates are distinct: non-empty contigs start at distinct positions, windows are
+            // disjoint, a cut is never a contig's first position, and a speculative boundary has no exact one
+            // within `burn` before it
+            // (four candidates per LDS read: entries from n_cand on hold kNoCut, which is below nothing)
+            const uint32_t m = mine[j];
+            uint32_t r = 0;
 #pragma unroll 4
-        for (uint32_t k = 0; k < n_cand; k += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
-            rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+            for (uint32_t k = 0; k < n_pad; k += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
+                r += (v.x < m ? 1u : 0u) + (v.y < m ? 1u : 0u) + (v.z < m ? 1u : 0u) + (v.w < m ? 1u : 0u);
+            }
+            rank[j] = r;
+            s_sorted[r] = m;
+            atomicAdd(&s_count, 1u);
+            if (spec[j]) atomicAdd(&s_spec, 1u);
         }
-        s_sorted[rank] = mine;
-        atomicAdd(&s_count, 1u);
-        if (spec) atomicAdd(&s_spec, 1u);
     }
     __syncthreads();
-    if (mine != kNoCut) {
-        const uint32_t count = s_count;
-        uint32_t cend = ltot;
-        for (uint32_t c = 0; c < n_contigs; ++c) {
-            const uint32_t a = s_cpos[c], b = s_cpos[c + 1];
-            if (a <= mine && mine < b) cend = b;
-        }
-        const uint32_t next = rank + 1 < count ? s_sorted[rank + 1] : ltot;
-        seg[1 + 3 * rank + 0] = spec ? mine - burn : mine;
-        seg[1 + 3 * rank + 1] = min(next, cend);
-        seg[1 + 3 * rank + 2] = cend;
-        seg[1 + 3 * n_cand + rank] = mine;
-        // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
-        // disagreement marks for another go, and what the later tiers look up to see whether they have work
-        uint32_t exact_before = 0;
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) {
+        if (mine[j] != kNoCut) {
+            const uint32_t m = mine[j], r = rank[j];
+            const uint32_t count = s_count;
+            uint32_t cend = ltot;
+            for (uint32_t c = 0; c < n_contigs; ++c) {
+                const uint32_t a = s_cpos[c], b = s_cpos[c + 1];
+                if (a <= m && m < b) cend = b;
+            }
+            const uint32_t next = r + 1 < count ? s_sorted[r + 1] : ltot;
+            seg[1 + 3 * r + 0] = spec[j] ? m - burn : m;
+            seg[1 + 3 * r + 1] = min(next, cend);
+            seg[1 + 3 * r + 2] = cend;
+            seg[1 + 3 * n_cand + r] = m;
+            // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
+            // disagreement marks for another go, and what the later tiers look up to see whether they have work
+            uint32_t exact_before = 0;
 #pragma unroll 4
-        for (uint32_t k = 0; k < n_cand; k += 4) {  // (kNoCut is the largest value: never <= a position)
-            const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
-            exact_before += (v.x <= mine ? 1u : 0u) + (v.y <= mine ? 1u : 0u) + (v.z <= mine ? 1u : 0u) + (v.w <= mine ? 1u : 0u);
+            for (uint32_t k = 0; k < n_pad; k += 4) {  // (kNoCut is the largest value: never <= a position)
+                const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
+                exact_before += (v.x <= m ? 1u : 0u) + (v.y <= m ? 1u : 0u) + (v.z <= m ? 1u : 0u) + (v.w <= m ? 1u : 0u);
+            }
+            seg[1 + 4 * n_cand + r] = exact_before - 1u;  // (>= 1: every position lies behind its contig's start)
+            if (r == 0) seg[0] = count;
         }
-        seg[1 + 4 * n_cand + rank] = exact_before - 1u;  // (>= 1: every position lies behind its contig's start)
-        if (rank == 0) seg[0] = count;
     }
-    if (t == 0 && n_speculative != nullptr) *n_speculative = s_spec;
+    if (threadIdx.x == 0 && n_speculative != nullptr) *n_speculative = s_spec;
 }
 
 // Tiers.  A disagreement marks the EXACT stretch (between two cut points / contig starts) it lies in:

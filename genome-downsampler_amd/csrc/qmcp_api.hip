@@ -309,10 +309,11 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // choice is about speed only), else the single-wave kernel.  QMCP_HIP_SWEEP=fast|gen overrides.
 // Cut-point segmentation of the uniform sweeps (QMCP_HIP_CUTS=0|1 overrides): looked for where mean
 // coverage is a small multiple of M -- deep data has no cut points, and the look costs two launches.
-uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, bool shallow) {
+uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, bool shallow,
+                           uint32_t max_windows = qmcp::kSweepWindowsOneSpan) {
     bool on = shallow;
     if (const char* e = std::getenv("QMCP_HIP_CUTS")) on = e[0] == '1';
-    return on ? qmcp::sweep_segment_windows(ltot, span, n_contigs) : 0u;
+    return on ? qmcp::sweep_segment_windows(ltot, span, n_contigs, max_windows) : 0u;
 }
 
 // Speculative stretch boundaries: below this mean coverage (in units of M), with a run-in (in blocks)
@@ -539,9 +540,9 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
         TRY(ensure(c, c->scalars, 64));
-        TRY(ensure(c, c->segs, qmcp::sweep_segment_words(n_contigs < 256 ? n_contigs : 0, 768) * sizeof(uint32_t)));
-        TRY(ensure(c, c->specflags, 2 * 1024 * sizeof(uint32_t)));           // speculative sweeps: marks per exact stretch, two tiers
-        TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(1024)));            // ... and the mixed-span walk's states at boundaries
+        TRY(ensure(c, c->segs, qmcp::sweep_segment_words(n_contigs < 256 ? n_contigs : 0, qmcp::kMaxSweepWindows) * sizeof(uint32_t)));
+        TRY(ensure(c, c->specflags, 2 * 4096 * sizeof(uint32_t)));           // speculative sweeps: marks per exact stretch, two tiers
+        TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(4096)));            // ... and the mixed-span walk's states at boundaries
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
@@ -806,7 +807,9 @@ int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_e
         const uint32_t* seg = nullptr;
         uint32_t n_seg_max = 0;
         const double depth = (double)n * (double)max_span / ((double)ltot * (double)(M ? M : 1));
-        const uint32_t windows = sweep_cut_windows(ltot, max_span, n_contigs, depth < kGenDepth);
+        // (a mixed-span walk is one light workgroup per stretch and slow per position: five times the windows
+        //  the one-span sweeps get, whose seven-wave workgroups fill the chip at three per compute unit)
+        const uint32_t windows = sweep_cut_windows(ltot, max_span, n_contigs, depth < kGenDepth, qmcp::kMaxSweepWindows);
         if (windows != 0) {
             KernelSpan sp(c, "k_find_cuts");
             seg = qmcp::launch_sweep_segments(c->stream, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,

@@ -42,7 +42,9 @@ void launch_radix_scatter(hipStream_t st, bool wide, const void* keys_in, const 
 // table (k_prepare writes it, one plain scan over 256 * pitch entries turns it into offsets, the
 // partition reads it)
 uint32_t part_pass_pitch(uint32_t n);
-uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs);
+// (at most max_windows of them; the table kernels take up to 3840: kMaxSweepWindows)
+constexpr uint32_t kSweepWindowsOneSpan = 768, kMaxSweepWindows = 3840;
+uint32_t sweep_segment_windows(uint32_t ltot, uint32_t ell, uint32_t n_contigs, uint32_t max_windows = kSweepWindowsOneSpan);
 size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows);
 // eoff: prefix counts of read ends for mixed spans (coverage = starts - ends); null for one span ell
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
