@@ -193,3 +193,20 @@ def test_two_speculative_solves_in_flight_on_two_contexts(pkg, oracle):
         for st, d_m, (s, e, offs, lengths, M) in zip((st_a, st_b), masks, probs):
             assert st.spec_boundaries >= 2 and st.spec_mismatches == 0, st.as_dict()
             assert np.array_equal(d_m.cpu().numpy().view(np.uint64), oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
+
+
+@pytest.mark.parametrize("depth,M", [(1.0, 30), (2.0, 20)])
+def test_mixed_spans_with_more_than_a_thousand_stretches(pkg, oracle, solver, depth, M):
+    """the mixed-span route's table holds up to 3 840 windows (a thread of the table kernel then looks after
+    several candidates): shallow data full of real cut points, and 2 x M with speculative boundaries between them"""
+    rng = np.random.default_rng(int(depth * 10) + M)
+    s, e, offs, lengths = _mixed_contigs(rng, [11_000_000, 5_000_000], depth, M, 100, 150)
+    # (at 2 x M the run-in is forced short, so that boundaries are close enough together for a table this
+    #  large on a genome this small; those that then disagree are settled by the later tiers)
+    with _env(QMCP_HIP_SPEC_BURN="20" if depth >= 2.0 else None):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.path == pkg.PATH_GENERAL and st.sweep_stretches > 1024, st.as_dict()
+    if depth >= 2.0:
+        assert st.spec_boundaries > 500, st.as_dict()
+    assert np.array_equal(got, oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
