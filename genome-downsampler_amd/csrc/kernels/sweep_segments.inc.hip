@@ -67,8 +67,33 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
 // Table: [count, {start, end, contig end} per stretch, then the position each stretch owns from, then the
 // index of the exact table's stretch it lies in].
 static constexpr int kSegThreads = 1024;
-static constexpr int kSegPerThread = kSegMaxCandidates / kSegThreads;  // candidates a thread looks after
+static constexpr int kSegPerThread = kSegMaxCandidates / kSegThreads;  // consecutive windows a thread looks after
 
+// exclusive scan over the workgroup of kSegPerThread flags per thread (thread t owns entries t * kSegPerThread ...):
+// pre[j] = flags set before entry j; returns the total.  s_ws: one word per wave.
+__device__ __forceinline__ uint32_t seg_block_scan(const bool (&flag)[kSegPerThread], uint32_t (&pre)[kSegPerThread],
+                                                   uint32_t* __restrict__ s_ws) {
+    uint32_t local = 0;
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) { pre[j] = local; local += flag[j] ? 1u : 0u; }
+    const uint32_t inc = wave_incl_scan_add(local);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    __syncthreads();  // (s_ws may still be read from the scan before)
+    if (lane == 63) s_ws[w] = inc;
+    __syncthreads();
+    uint32_t before = inc - local, total = 0;
+    for (uint32_t x = 0; x < (uint32_t)(kSegThreads / 64); ++x) {
+        const uint32_t v = s_ws[x];
+        before += x < w ? v : 0u;
+        total += v;
+    }
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) pre[j] += before;
+    return total;
+}
+
+// The window candidates come in position order (window w's cut, or its speculative boundary, lies in window w),
+// so ranks are prefix counts over the windows plus a look at the (< 256) contig starts: no all-pairs compare.
 __global__ __launch_bounds__(kSegThreads) void k_build_segments(const uint32_t* __restrict__ cut,
                                                                 uint32_t n_windows,
                                                                 const uint64_t* __restrict__ contig_pos_off,
@@ -76,112 +101,121 @@ __global__ __launch_bounds__(kSegThreads) void k_build_segments(const uint32_t* 
                                                                 uint32_t win, uint32_t burn, uint32_t stride,
                                                                 uint32_t* __restrict__ seg,
                                                                 uint32_t* __restrict__ n_speculative /* = ; or null */) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[kSegMaxCandidates];
-    __shared__ __attribute__((aligned(16))) uint32_t s_exact[kSegMaxCandidates];
+    __shared__ uint32_t s_wexact[kSegMaxCandidates];      // window w's real cut (kNoCut: none)
+    __shared__ uint32_t s_wpos[kSegMaxCandidates];        // window w's boundary: the cut, a speculative one, or kNoCut
+    __shared__ uint32_t s_pe[kSegMaxCandidates + 1];      // real cuts in the windows before w
+    __shared__ uint32_t s_pv[kSegMaxCandidates + 1];      // boundaries in the windows before w
     __shared__ uint32_t s_sorted[kSegMaxCandidates];
-    __shared__ uint32_t s_count, s_spec;
-    __shared__ uint32_t s_cpos[257];  // contig starts (+ the end of the last): read once, not in every thread's loops
+    __shared__ uint32_t s_cpos[257];                      // contig starts (+ the end of the last)
+    __shared__ uint32_t s_ws[kSegThreads / 64];
+    __shared__ uint32_t s_spec;
     const uint32_t n_cand = n_contigs + n_windows;
-    const uint32_t n_pad = (n_cand + 3u) & ~3u;  // the loops below read four candidates at a time
+    const uint32_t w0 = threadIdx.x * (uint32_t)kSegPerThread;
     if (threadIdx.x <= n_contigs && threadIdx.x < 257) s_cpos[threadIdx.x] = (uint32_t)contig_pos_off[threadIdx.x];
-    if (threadIdx.x == 0) { s_count = 0; s_spec = 0; }
+    if (threadIdx.x == 0) s_spec = 0;
+    uint32_t ex[kSegPerThread];
+    bool flag[kSegPerThread];
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) {
+        const uint32_t w = w0 + (uint32_t)j;
+        ex[j] = w < n_windows ? cut[w] : kNoCut;
+        s_wexact[w] = ex[j];
+        flag[j] = ex[j] != kNoCut;
+    }
+    uint32_t pre[kSegPerThread];
+    const uint32_t total_exact = seg_block_scan(flag, pre, s_ws);  // (its first barrier publishes s_cpos, s_wexact)
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) s_pe[w0 + (uint32_t)j] = pre[j];
+    if (threadIdx.x == 0) s_pe[kSegMaxCandidates] = total_exact;
     __syncthreads();
-    // candidate t = threadIdx.x + j * kSegThreads: contig starts first, then the windows
-    uint32_t mine[kSegPerThread];
+    // non-empty contig starts before / up to a position
+    auto contigs_before = [&](uint32_t p, bool inclusive) {
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < n_contigs; ++c) {
+            const uint32_t a = s_cpos[c];
+            k += (s_cpos[c + 1] > a && (inclusive ? a <= p : a < p)) ? 1u : 0u;
+        }
+        return k;
+    };
+    // speculative boundaries: window w's first position, with a run-in that no exact boundary may fall into
+    uint32_t pos[kSegPerThread];
     bool spec[kSegPerThread];
+    uint32_t my_spec = 0;
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j) {
-        const uint32_t t = threadIdx.x + (uint32_t)j * kSegThreads;
-        mine[j] = kNoCut;
+        const uint32_t w = w0 + (uint32_t)j;
+        pos[j] = ex[j];
         spec[j] = false;
-        if (t < n_contigs) {
-            if (s_cpos[t + 1] > s_cpos[t]) mine[j] = s_cpos[t];  // empty contigs: no work
-        } else if (t < n_cand) {
-            const uint32_t w = t - n_contigs;
-            mine[j] = cut[w];
-            if (mine[j] == kNoCut && burn != 0 && w >= 1 && w % stride == 0 && (uint64_t)w * win < ltot) {
-                mine[j] = w * win;
-                spec[j] = true;
+        if (w < n_windows && ex[j] == kNoCut && burn != 0 && w >= 1 && w % stride == 0 && (uint64_t)w * win < ltot) {
+            const uint32_t b = w * win;
+            bool ok = b >= burn;
+            if (ok) {
+                const uint32_t lo = b - burn;        // an exact boundary q with lo < q <= b spoils it
+                const uint32_t wlo = lo / win;        // (window w itself holds no cut)
+                if (wlo < w) {
+                    if (s_pe[w] - s_pe[wlo + 1] != 0) ok = false;              // windows wholly inside (lo, b)
+                    const uint32_t q = s_wexact[wlo];
+                    if (q != kNoCut && q > lo) ok = false;
+                }
+                for (uint32_t c = 0; c < n_contigs; ++c) {
+                    const uint32_t q = s_cpos[c];
+                    if (s_cpos[c + 1] > q && q <= b && q > lo) ok = false;
+                }
             }
+            if (ok) { pos[j] = b; spec[j] = true; ++my_spec; }
         }
-        if (t < n_pad) {
-            s_pos[t] = spec[j] ? kNoCut : mine[j];  // the exact boundaries first
-            s_exact[t] = spec[j] ? kNoCut : mine[j];
-        }
+        s_wpos[w] = pos[j];
+        flag[j] = pos[j] != kNoCut;
     }
-    __syncthreads();
+    if (my_spec != 0) atomicAdd(&s_spec, my_spec);
+    const uint32_t total_windows = seg_block_scan(flag, pre, s_ws);  // (publishes s_wpos)
 #pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j) {
-        if (spec[j]) {
-            // the run-in must lie inside one stretch: no exact boundary in (mine - burn, mine]
-            const uint32_t m = mine[j];
-            bool ok = m >= burn;
-            for (uint32_t k = 0; k < n_pad; k += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
-                const uint32_t q4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (q4[i] != kNoCut && q4[i] <= m && q4[i] + burn > m) ok = false;
-            }
-            if (!ok) { mine[j] = kNoCut; spec[j] = false; }
-        }
-    }
+    for (int j = 0; j < kSegPerThread; ++j) s_pv[w0 + (uint32_t)j] = pre[j];
+    if (threadIdx.x == 0) s_pv[kSegMaxCandidates] = total_windows;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j) {
-        const uint32_t t = threadIdx.x + (uint32_t)j * kSegThreads;
-        if (t < n_pad) s_pos[t] = mine[j];
-    }
-    __syncthreads();
+    const uint32_t count = total_windows + contigs_before(0xFFFFFFFFu, true);
+    // ranks: window boundaries, then (threads below n_contigs) the contig starts
     uint32_t rank[kSegPerThread];
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j) {
         rank[j] = 0;
-        if (mine[j] != kNoCut) {
-            // candidates are distinct: non-empty contigs start at distinct positions, windows are
-            // disjoint, a cut is never a contig's first position, and a speculative boundary has no exact one
-            // within `burn` before it
-            // (four candidates per LDS read: entries from n_cand on hold kNoCut, which is below nothing)
-            const uint32_t m = mine[j];
-            uint32_t r = 0;
-#pragma unroll 4
-            for (uint32_t k = 0; k < n_pad; k += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(&s_pos[k]);
-                r += (v.x < m ? 1u : 0u) + (v.y < m ? 1u : 0u) + (v.z < m ? 1u : 0u) + (v.w < m ? 1u : 0u);
-            }
-            rank[j] = r;
-            s_sorted[r] = m;
-            atomicAdd(&s_count, 1u);
-            if (spec[j]) atomicAdd(&s_spec, 1u);
+        if (pos[j] != kNoCut) {
+            rank[j] = s_pv[w0 + (uint32_t)j] + contigs_before(pos[j], false);
+            s_sorted[rank[j]] = pos[j];
         }
     }
+    uint32_t c_pos = kNoCut, c_rank = 0, c_wc = 0;
+    if (threadIdx.x < n_contigs && s_cpos[threadIdx.x + 1] > s_cpos[threadIdx.x]) {
+        c_pos = s_cpos[threadIdx.x];
+        c_wc = min(c_pos / win, n_windows);  // the window the start lies in (n_windows: none)
+        const uint32_t in_window = (c_wc < n_windows && s_wpos[c_wc] != kNoCut && s_wpos[c_wc] < c_pos) ? 1u : 0u;
+        c_rank = contigs_before(c_pos, false) + (c_wc < n_windows ? s_pv[c_wc] : total_windows) + in_window;
+        s_sorted[c_rank] = c_pos;
+    }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j) {
-        if (mine[j] != kNoCut) {
-            const uint32_t m = mine[j], r = rank[j];
-            const uint32_t count = s_count;
-            uint32_t cend = ltot;
-            for (uint32_t c = 0; c < n_contigs; ++c) {
-                const uint32_t a = s_cpos[c], b = s_cpos[c + 1];
-                if (a <= m && m < b) cend = b;
-            }
-            const uint32_t next = r + 1 < count ? s_sorted[r + 1] : ltot;
-            seg[1 + 3 * r + 0] = spec[j] ? m - burn : m;
-            seg[1 + 3 * r + 1] = min(next, cend);
-            seg[1 + 3 * r + 2] = cend;
-            seg[1 + 3 * n_cand + r] = m;
-            // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
-            // disagreement marks for another go, and what the later tiers look up to see whether they have work
-            uint32_t exact_before = 0;
-#pragma unroll 4
-            for (uint32_t k = 0; k < n_pad; k += 4) {  // (kNoCut is the largest value: never <= a position)
-                const uint4 v = *reinterpret_cast<const uint4*>(&s_exact[k]);
-                exact_before += (v.x <= m ? 1u : 0u) + (v.y <= m ? 1u : 0u) + (v.z <= m ? 1u : 0u) + (v.w <= m ? 1u : 0u);
-            }
-            seg[1 + 4 * n_cand + r] = exact_before - 1u;  // (>= 1: every position lies behind its contig's start)
-            if (r == 0) seg[0] = count;
+    auto emit = [&](uint32_t m, uint32_t r, bool is_spec, uint32_t exact_upto) {
+        uint32_t cend = ltot;
+        for (uint32_t c = 0; c < n_contigs; ++c) {
+            const uint32_t a = s_cpos[c], b = s_cpos[c + 1];
+            if (a <= m && m < b) cend = b;
         }
+        const uint32_t next = r + 1 < count ? s_sorted[r + 1] : ltot;
+        seg[1 + 3 * r + 0] = is_spec ? m - burn : m;
+        seg[1 + 3 * r + 1] = min(next, cend);
+        seg[1 + 3 * r + 2] = cend;
+        seg[1 + 3 * n_cand + r] = m;
+        // which stretch of the EXACT table (contig starts and cut points only) this one lies in: what a
+        // disagreement marks for another go, and what the later tiers look up to see whether they have work
+        seg[1 + 4 * n_cand + r] = exact_upto + contigs_before(m, true) - 1u;  // (>= 1: every position lies behind its contig's start)
+        if (r == 0) seg[0] = count;
+    };
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
+        if (pos[j] != kNoCut)  // real cuts up to it: those of the windows before, and its own if it is one
+            emit(pos[j], rank[j], spec[j], s_pe[w0 + (uint32_t)j] + (ex[j] != kNoCut ? 1u : 0u));
+    if (c_pos != kNoCut) {
+        const uint32_t own = (c_wc < n_windows && s_wexact[c_wc] != kNoCut && s_wexact[c_wc] <= c_pos) ? 1u : 0u;
+        emit(c_pos, c_rank, false, (c_wc < n_windows ? s_pe[c_wc] : total_exact) + own);
     }
     if (threadIdx.x == 0 && n_speculative != nullptr) *n_speculative = s_spec;
 }
