@@ -2,7 +2,8 @@
 run-in forced SHORT (8 ... 128 blocks), so that many boundaries are accepted only just.  Whatever the
 verification decides, the kept set must equal the oracle's; the interesting class is "boundaries accepted
 (no mismatch) and the run-in far shorter than the product would use".
-   python lab/stress_spec.py [instances = 300] [seed = 1]"""
+   python lab/stress_spec.py [instances = 300] [seed = 1] [big]
+   (big: genomes of 8 ... 20 M positions, so that the mixed-span route's tables hold more than a thousand stretches)"""
 import importlib, os, sys, time
 import numpy as np
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -11,6 +12,7 @@ import oracle_py
 pkg = importlib.import_module("genome-downsampler_amd")
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 sol = pkg.Solver(0)
 os.environ["QMCP_HIP_SPEC"] = "1"
 accepted = rejected = none = bad = second = 0
@@ -22,7 +24,11 @@ for it in range(n_inst):
     depth = float(rng.uniform(1.3, 3.5))
     burn = int(rng.choice([8, 16, 32, 64, 128]))
     n_contigs = int(rng.integers(1, 4))
-    lengths = rng.integers(8 * burn * span + 1000, max(8 * burn * span + 2000, 1_200_000), size=n_contigs).astype(np.uint32)
+    if big:
+        lengths = rng.integers(8_000_000, 20_000_000, size=n_contigs).astype(np.uint32) // np.uint32(n_contigs)
+        M = int(rng.integers(8, 25))
+    else:
+        lengths = rng.integers(8 * burn * span + 1000, max(8 * burn * span + 2000, 1_200_000), size=n_contigs).astype(np.uint32)
     ss, offs = [], [0]
     for L in lengths:
         n = int(depth * M * int(L) / span)
@@ -50,7 +56,7 @@ for it in range(n_inst):
     elif st.spec_mismatches == 0: accepted += 1; acc_boundaries += st.spec_boundaries
     elif st.spec_retry_mismatches == 0: second += 1
     else: rejected += 1
-    if (it + 1) % 50 == 0:
+    if (it + 1) % (5 if big else 50) == 0:
         print(f"{it + 1} instances, {time.time() - t0:.0f} s: all boundaries accepted {accepted} (boundaries {acc_boundaries}), "
               f"settled by the second tier {second}, exact sweep needed {rejected}, none speculative {none}, wrong kept sets {bad}", flush=True)
 print(f"done: {n_inst} instances, first tier accepted {accepted} ({acc_boundaries} boundaries), second tier {second}, exact sweep {rejected}, none {none}, WRONG {bad}")
