@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
         const bool lean = part_hist != nullptr && gstart_out == nullptr && digit0_hist == nullptr &&
                           global_digit_hist == nullptr && cstart == nullptr && one_contig && tcount == 4096u;
         if (lean) {
+            // A contig that spans at most four digits (long genomes: the first partition level's digits are
+            // 8.4 M positions wide) sends all 64 lanes of a wave to one to four counters, and same-address LDS
+            // atomics take their turns: there the wave counts each digit with a ballot and adds once.
+            const bool few_digits = ((tile_p0 + tile_len - 1u) >> part_shift) - (tile_p0 >> part_shift) < 4u;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t s = sv[k], e = ev[k];
@@ -109,7 +113,21 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 const uint32_t span = e - s + 1;
                 mn = min(mn, span);
                 mx = max(mx, span);
-                atomicAdd(&s_h[((tile_p0 + s) >> part_shift) & 255u], 1u);
+                const uint32_t d = ((tile_p0 + s) >> part_shift) & 255u;
+                if (few_digits) {
+                    uint64_t rest = ~0ull;  // (every lane holds a read: the tile is whole)
+                    for (int round = 0; round < 4 && rest != 0; ++round) {
+                        const int first = __ffsll((long long)rest) - 1;
+                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+                        const uint64_t same = __ballot(d == d0) & rest;
+                        if ((int)(threadIdx.x & 63u) == first) atomicAdd(&s_h[d0], (uint32_t)__popcll(same));
+                        rest &= ~same;
+                    }
+                    // (an invalid start can fall outside the contig's digits: whatever is left goes one by one)
+                    if ((rest >> (threadIdx.x & 63u)) & 1ull) atomicAdd(&s_h[d], 1u);
+                } else {
+                    atomicAdd(&s_h[d], 1u);
+                }
             }
         } else
 #pragma unroll
