@@ -59,7 +59,8 @@ class Stats(C.Structure):
         ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_mark", C.c_float),
         ("ms_h2d", C.c_float), ("ms_d2h", C.c_float), ("columns_sent", C.c_uint32),
         ("spec_boundaries", C.c_uint32), ("spec_mismatches", C.c_uint32),
-        ("spec_retry_mismatches", C.c_uint32),
+        ("spec_retry_mismatches", C.c_uint32), ("contig_groups", C.c_uint32),
+        ("arena_grown_mid_solve", C.c_uint32),
     ]
 
     def as_dict(self):

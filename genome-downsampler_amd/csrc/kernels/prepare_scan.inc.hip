@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             tile_p0 = (uint32_t)p0;
             tile_len = (uint32_t)(p1 - p0);
         }
+        const uint32_t tile_last = tile_len ? tile_len - 1u : 0u;
         // the ranked route's whole tiles inside one contig (all but a handful): validate, span range and
         // the partition digit, nothing else and no branch per read (an invalid read makes the call fail;
         // what its span adds to the statistics is then never looked at)
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             // A contig that spans at most four digits (long genomes: the first partition level's digits are
             // 8.4 M positions wide) sends all 64 lanes of a wave to one to four counters, and same-address LDS
             // atomics take their turns: there the wave counts each digit with a ballot and adds once.
-            const bool few_digits = ((tile_p0 + tile_len - 1u) >> part_shift) - (tile_p0 >> part_shift) < 4u;
+            const bool few_digits = ((tile_p0 + tile_last) >> part_shift) - (tile_p0 >> part_shift) < 4u;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t s = sv[k], e = ev[k];
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 const uint32_t span = e - s + 1;
                 mn = min(mn, span);
                 mx = max(mx, span);
-                const uint32_t d = ((tile_p0 + s) >> part_shift) & 255u;
+                // (a start beyond the contig -- the call will fail -- is counted at the contig's last position,
+                //  as the partition queued behind this kernel will place it: k_range_partition)
+                const uint32_t d = ((tile_p0 + min(s, tile_last)) >> part_shift) & 255u;
                 if (few_digits) {
                     uint64_t rest = ~0ull;  // (every lane holds a read: the tile is whole)
                     for (int round = 0; round < 4 && rest != 0; ++round) {
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 // stay in bounds: the read is counted under the digit the partition will compute
                 bad = 1;
                 if (gstart_out) gstart_out[i] = gs;
-                if (part_hist) atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
+                if (part_hist) atomicAdd(&s_h[((pos0 + min(s, len_c ? len_c - 1u : 0u)) >> part_shift) & 255u], 1u);
                 continue;
             }
             const uint32_t span = e - s + 1;

@@ -45,6 +45,42 @@ struct SegTables {                   // device tables of the two-level route (25
     const uint32_t* pass_base;       // partition passes (kPartTiles tiles) of all lower super-ranges
 };
 
+// In-wave stable ranking of one pass's records by digit: BITS ballots per round of 64 records tell the
+// lanes of one digit apart (the digits of a pass differ in their low BITS bits only, see the kernel).  A
+// lane's peers are a 64-bit mask per lane, kept as two words: per bit one sign-extended bit field (all ones
+// or zero), one compare (the ballot) and an XNOR + AND per word; ranks inside the group and the group's
+// first lane come from the mask-count instructions.  BITS is a template argument so that no bit costs a
+// scalar branch (the run-time loop over eight bits took 72 instructions per record; this takes 12 + 6 BITS,
+// and the partition is bound by instruction issue, not by its bytes).
+template <int BITS>
+__device__ __forceinline__ void part_rank_rounds(const Rec (&rec)[kSortItems], uint32_t (&rank)[kSortItems],
+                                                 uint32_t wbase, uint32_t bound, uint32_t shift, int lane,
+                                                 uint32_t* __restrict__ s_cnt_w /* the wave's 256 counters */) {
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < bound;
+        const uint32_t d = (rec[k].key >> shift) & 255u;
+        const uint64_t v = __ballot(valid);
+        uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
+        if (!valid) { plo = ~plo; phi = ~phi; }
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const uint32_t fill = (uint32_t)((int32_t)(d << (31 - b)) >> 31);  // bit b of d, in every bit
+            const uint64_t m = __ballot(fill != 0u);
+            plo &= ~(fill ^ (uint32_t)m);
+            phi &= ~(fill ^ (uint32_t)(m >> 32));
+        }
+        const uint32_t in_group = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));  // peers below this lane
+        // every lane of the group reads the wave's running count of its digit (a broadcast read), then
+        // the group's first lane moves it on: a wave's LDS operations execute in order, so the read is
+        // the value before this round and the next round's read sees the write
+        const uint32_t old = s_cnt_w[d];
+        if (valid && in_group == 0u) s_cnt_w[d] = old + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+        rank[k] = old + in_group;
+    }
+}
+
 template <int MODE, bool OUT_REC>
 __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t* __restrict__ keys, const Rec* __restrict__ recs_in, SegTables seg,
@@ -59,7 +95,6 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     uint32_t* s_gbase = s_cnt + kPartWaves * 256;                      // [256]
     uint32_t* s_wave = s_gbase + 256;                                  // [4] (+ pad to 16)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     // this pass: records [base, base + count), none at or beyond `bound`; its row of the offset
     // table: entry of digit d = offs[off0 + d * off_stride]
     uint32_t base, bound, off0, off_stride;
@@ -142,44 +177,48 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         // bits tell them apart, so the in-wave match below needs that many ballots, not eight
         {
             const uint32_t d_lo = ((uint32_t)contig_pos_off[c_first] >> shift) & 255u;
-            const uint32_t d_hi = (((uint32_t)contig_pos_off[c_last + 1] - 1u) >> shift) & 255u;
+            // (up to and including the first position behind the last contig: where a read of a zero-length
+            //  contig is counted, see below)
+            const uint32_t d_hi = ((uint32_t)contig_pos_off[c_last + 1] >> shift) & 255u;
             match_bits = d_hi >= d_lo ? 32u - (uint32_t)__builtin_clz((d_hi - d_lo) | 1u) : 8u;
             if (d_hi == d_lo) match_bits = 0;
         }
+        // A start at or beyond its contig's length (an invalid read: the call will fail, but this pass is
+        // queued before the host knows) is taken as the contig's last position, here and in k_prepare's
+        // histogram alike: its digit then lies in the pass's digit interval, which the BITS-bit match and the
+        // scanned table's run lengths both rely on.
         if (c_first == c_last) {
             const uint32_t p0 = (uint32_t)contig_pos_off[c_first];
+            const uint32_t len = (uint32_t)contig_pos_off[c_first + 1] - p0;
+            const uint32_t last = len ? len - 1u : 0u;
 #pragma unroll
-            for (int k = 0; k < kSortItems; ++k) rec[k].key += p0;
+            for (int k = 0; k < kSortItems; ++k) rec[k].key = p0 + min(rec[k].key, last);
         } else {
 #pragma unroll
             for (int k = 0; k < kSortItems; ++k) {
                 const uint32_t i = wbase + k * 64 + lane;
-                if (i < bound) rec[k].key += (uint32_t)contig_pos_off[contig_of(i)];
+                if (i < bound) {
+                    const uint32_t cc = contig_of(i);
+                    const uint32_t p0 = (uint32_t)contig_pos_off[cc];
+                    const uint32_t len = (uint32_t)contig_pos_off[cc + 1] - p0;
+                    rec[k].key = p0 + min(rec[k].key, len ? len - 1u : 0u);
+                }
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t i = wbase + k * 64 + lane;
-        const bool valid = i < bound;
-        const uint32_t d = (rec[k].key >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-        if (!valid) peers = ~peers;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if ((uint32_t)b < match_bits) {  // uniform
-                const uint64_t m = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? m : ~m;
-            }
+    {
+        uint32_t* const s_cnt_w = s_cnt + w * 256;
+        switch (match_bits) {  // uniform
+            case 0: part_rank_rounds<0>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 1: part_rank_rounds<1>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 2: part_rank_rounds<2>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 3: part_rank_rounds<3>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 4: part_rank_rounds<4>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 5: part_rank_rounds<5>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 6: part_rank_rounds<6>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 7: part_rank_rounds<7>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            default: part_rank_rounds<8>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
         }
-        const uint32_t in_group = __popcll(peers & lt_mask);
-        const int leader = __ffsll((long long)peers) - 1;
-        // every lane of the group reads the wave's running count of its digit (a broadcast read), then
-        // the group's first lane moves it on: a wave's LDS operations execute in order, so the read is
-        // the value before this round and the next round's read sees the write
-        const uint32_t old = s_cnt[w * 256 + d];
-        if (valid && lane == leader) s_cnt[w * 256 + d] = old + __popcll(peers);
-        rank[k] = old + in_group;
     }
     __syncthreads();
     if (threadIdx.x < 256) {
@@ -398,7 +437,14 @@ __global__ __launch_bounds__(1024) void k_range_offsets(const uint16_t* __restri
 // chunk's records backwards, skips that many matches and keeps the rest.  Every position runs out
 // at most once, so the list needs at most one entry per position.  The kept set is exactly the
 // S(p) lowest indices of every bucket, independent of LDS arbitration order.
-static constexpr int kRankU = 1;
+#ifndef QMCP_RANK_U
+#define QMCP_RANK_U 1
+#endif
+static constexpr int kRankU = QMCP_RANK_U;  // records per thread and chunk
+#ifndef QMCP_RANK_DEPTH
+#define QMCP_RANK_DEPTH 8
+#endif
+static constexpr int kRankDepth = QMCP_RANK_DEPTH;  // register sets of records in flight per thread
 
 __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__ keys16,
                                                     const uint32_t* __restrict__ idx,
@@ -408,7 +454,9 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
                                                     const uint32_t* __restrict__ selend,
                                                     unsigned long long* __restrict__ mask,
                                                     unsigned long long* __restrict__ kept_total,
-                                                    uint2* __restrict__ amb_lists, int lists_by_records) {
+                                                    uint2* __restrict__ amb_lists, int lists_by_records,
+                                                    uint32_t mask_bit0 /* bit of mask[0] that stands for read 0 (a contig
+                                                        group of a larger call need not start at a multiple of 64) */) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1]; the last entry absorbs idle threads
     __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
@@ -443,22 +491,38 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
 
     // thread tid owns record tid of each of the chunk's kRankU sub-chunks
     struct Recs { uint32_t key[kRankU], val[kRankU]; };
+    // The record loads are issued and waited for BY HAND (inline assembly, which the compiler's wait-count
+    // pass does not look into).  Left to the compiler, the loop's other vector-memory operations -- the mask
+    // atomics and the list stores, of another event type than loads -- make that pass give up counting: it
+    // waited for all but the two youngest loads once per eight chunks (s_waitcnt vmcnt(2)), i.e. for records
+    // asked for one chunk earlier, a full trip to memory on the chain of every eighth chunk (rocprofv3: 0.25 ms
+    // at cfg4 where the bytes take 0.12).  A counted wait is safe whatever else is in flight: loads complete in
+    // issue order, so while a record's load is outstanding so are the 2 (kRankDepth - 1) kRankU loads issued
+    // after it, and "at most that many outstanding" cannot hold.  Younger atomics and stores only make the wait
+    // longer.  Addresses are the stream's base (scalar) + a 32-bit byte offset: record j < 2^30.
     auto fetch = [&](Recs& dst, uint32_t c) {
 #pragma unroll
         for (int u = 0; u < kRankU; ++u) {
             const uint32_t j = min(lo + c * chunk_recs + u * nthreads + tid, hi - 1);
-            dst.key[u] = keys16[j];  // position inside the range
-            dst.val[u] = idx[j];
+            asm volatile("global_load_ushort %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
+                         : "=&v"(dst.key[u]), "=&v"(dst.val[u])
+                         : "v"(j * 2u), "s"(keys16), "v"(j * 4u), "s"(idx)
+                         : "memory");
         }
     };
-    auto chunk = [&](const Recs& r, uint32_t c) {
+    auto chunk = [&](Recs& r, uint32_t c) {
         bool valid[kRankU];
         uint32_t li[kRankU];
         int32_t old[kRankU];
+        // the chunk's records have landed once at most the loads of the kRankDepth - 1 chunks asked for
+        // after it are outstanding (the operands tie the wait to the registers: nothing reads them before)
+#pragma unroll
+        for (int u = 0; u < kRankU; ++u)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.key[u]), "+v"(r.val[u]) : "n"(2 * (kRankDepth - 1) * kRankU) : "memory");
 #pragma unroll
         for (int u = 0; u < kRankU; ++u) {
             valid[u] = lo + c * chunk_recs + u * nthreads + tid < hi;
-            li[u] = valid[u] ? r.key[u] : width;
+            li[u] = valid[u] ? r.key[u] : width;  // (the 16-bit load zero-extends)
             old[u] = atomicSub(&s_q[li[u]], 1);
         }
         __syncthreads();
@@ -476,28 +540,28 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
         __syncthreads();  // every q_after is read before the next chunk draws
 #pragma unroll
         for (int u = 0; u < kRankU; ++u) {
-            if (keep[u]) atomicOr(&mask[r.val[u] >> 6], 1ull << (r.val[u] & 63u));
+#ifndef QMCP_LAB_NO_MASK_ATOMIC  // (lab: what the walk costs without its mask writes -- wrong masks)
+            if (keep[u]) { const uint32_t v = r.val[u] + mask_bit0; atomicOr(&mask[v >> 6], 1ull << (v & 63u)); }
+#endif
             kept += (uint32_t)__popcll(__ballot(keep[u]));
         }
     };
-    // Records are prefetched seven chunks ahead into eight register sets that rotate by NAME (the
-    // loop is unrolled eight times): no register copies, so the wait for a chunk's records is a
-    // counted s_waitcnt that leaves the younger loads (and the fire-and-forget mask atomics) in
-    // flight.  A thread loads only 6 bytes per chunk, so this depth is what keeps enough bytes in
-    // flight per CU (3 chunks ahead: 2.2 TB/s over the chip).  Chunks past the end run with every
-    // thread idle (dummy quota slot).
-    Recs R0, R1, R2, R3, R4, R5, R6, R7;
-    fetch(R0, 0); fetch(R1, 1); fetch(R2, 2); fetch(R3, 3); fetch(R4, 4); fetch(R5, 5); fetch(R6, 6);
-    for (uint32_t c = 0; c < n_chunks; c += 8) {
-        fetch(R7, c + 7);  chunk(R0, c);
-        fetch(R0, c + 8);  chunk(R1, c + 1);
-        fetch(R1, c + 9);  chunk(R2, c + 2);
-        fetch(R2, c + 10); chunk(R3, c + 3);
-        fetch(R3, c + 11); chunk(R4, c + 4);
-        fetch(R4, c + 12); chunk(R5, c + 5);
-        fetch(R5, c + 13); chunk(R6, c + 6);
-        fetch(R6, c + 14); chunk(R7, c + 7);
+    // Records are prefetched kRankDepth - 1 chunks ahead into kRankDepth register sets that rotate by NAME (the
+    // loop is unrolled kRankDepth times, every index below is a constant): no register copies -- a copy of a
+    // register whose load is still in flight would read what was there before.  A thread loads only 6 bytes
+    // per chunk, so this depth is what keeps enough bytes in flight per CU (3 chunks ahead: 2.2 TB/s over the
+    // chip).  Chunks past the end run with every thread idle (dummy quota slot).
+    Recs R[kRankDepth];
+#pragma unroll
+    for (int k = 0; k < kRankDepth - 1; ++k) fetch(R[k], (uint32_t)k);
+    for (uint32_t c = 0; c < n_chunks; c += kRankDepth) {
+#pragma unroll
+        for (int k = 0; k < kRankDepth; ++k) {
+            fetch(R[(k + kRankDepth - 1) % kRankDepth], c + (uint32_t)k + (uint32_t)(kRankDepth - 1));
+            chunk(R[k], c + (uint32_t)k);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads asked for beyond the last chunk)
     // settle the listed (chunk, position) groups: one wave per entry, walking the chunk backwards
     __threadfence_block();
     __syncthreads();
@@ -522,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
             if (m == 0) continue;
             const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
             if (member && above >= skip) {
-                const uint32_t v = idx[j];
+                const uint32_t v = idx[j] + mask_bit0;
                 atomicOr(&mask[v >> 6], 1ull << (v & 63u));
             }
             const uint32_t in_step = (uint32_t)__popcll(m);

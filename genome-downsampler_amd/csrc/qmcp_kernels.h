@@ -119,7 +119,7 @@ void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_
                                     uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
-                 unsigned long long* n_kept);
+                 unsigned long long* n_kept, uint32_t mask_bit0 = 0);
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
                          uint32_t n, uint32_t span_bits, uint32_t ltot, uint32_t* boff);
 void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_t* spine);
@@ -174,7 +174,7 @@ bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n);
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
-                      void* scratch, bool scratch_by_records);
+                      void* scratch, bool scratch_by_records, uint32_t mask_bit0 = 0);
 
 }  // namespace qmcp
 #endif

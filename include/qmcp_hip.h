@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMCP_HIP_ABI_VERSION 2
+#define QMCP_HIP_ABI_VERSION 3
 
 enum {
     QMCP_OK = 0,
@@ -97,6 +97,11 @@ typedef struct qmcp_hip_stats {
                                  run-in                                                              */
     uint32_t spec_retry_mismatches; /* ... and how many disagreed in that sweep: those parts were
                                  swept exactly                                                       */
+    uint32_t contig_groups;   /* 1, or the number of contig groups a deep multi-contig call was dealt to
+                                 (each on a stream of its own: one group's selection chain runs beside the
+                                 next groups' bandwidth-bound stages)                                 */
+    uint32_t arena_grown_mid_solve; /* device buffers that had to grow after the solve's first launch (a
+                                 stall on queued work); 0 from the second call of a shape on         */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);
