@@ -133,6 +133,7 @@ if _host is not None:
     _host.qmcp_host_downsample_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
                                                C.c_uint32, C.c_uint32]
     _host.qmcp_host_downsample_bam.restype = C.c_int64
+    _host.qmcp_host_check_bam.argtypes = [C.c_char_p, _u64p, C.c_char_p, C.c_size_t]
     _host.qmcp_host_bamapi_probe.argtypes = [_u32p, _u32p, C.c_uint64, C.c_uint32, C.c_int, _u64p,
                                              C.c_uint64, _u32p, _u32p, _u64p]
     _host.qmcp_host_bamapi_probe.restype = C.c_int64
@@ -528,6 +529,16 @@ def read_bam(path, bed=None, tsv=None, amplicon_mode=0, min_length=0, min_mapq=0
     out.update(bam_ids=ids[:n].copy(), is_first=first[:n].astype(bool), filtered_out=filt[:nf.value].copy(),
                ref_genome_length=int(ref.value))
     return out
+
+
+def check_bam(path):
+    """read_bam's own verdict on a file (no exit-on-error as in BamApi): (True, reads imported, "") or
+    (False, 0, the reader's message)"""
+    _need_host()
+    n = C.c_uint64(0)
+    buf = C.create_string_buffer(512)
+    rc = _host.qmcp_host_check_bam(str(path).encode(), C.byref(n), buf, 512)
+    return rc == 0, int(n.value) if rc == 0 else 0, buf.value.decode(errors="replace")
 
 
 def downsample_bam(solver_name, in_path, out_path, max_coverage, filtered_path=None, min_length=0, min_mapq=0):

@@ -149,6 +149,12 @@ class BgzfWriter {
     std::vector<unsigned char> buf_;
 };
 
+// caps on the sizes a file may claim (a corrupt or hostile length field must not wrap an allocation)
+constexpr std::size_t kMaxHeaderText = std::size_t(1) << 30;   // l_text
+constexpr std::size_t kMaxRefName = std::size_t(1) << 16;      // l_name
+constexpr std::size_t kMaxRecordBytes = std::size_t(1) << 28;  // block_size
+constexpr std::size_t kMaxReferences = std::size_t(1) << 24;   // n_ref
+
 // the BAM header (magic, text, reference names and lengths), kept verbatim for the copy in write_bam
 struct BamHeader {
     std::vector<unsigned char> raw;
@@ -160,17 +166,22 @@ bool read_header(BgzfReader& in, BamHeader& h, std::string* err) {
     unsigned char b[8];
     if (!in.read(b, 8) || std::memcmp(b, "BAM\1", 4) != 0) return set_err(err, in.error().empty() ? "not a BAM file (magic)" : in.error());
     h.raw.assign(b, b + 8);
-    const std::uint32_t l_text = le32(b + 4);
+    // sizes come from the file: all arithmetic on them in size_t, every one capped before anything is allocated
+    // (the reference lets HTSlib reject such files: sam_hdr_read, bam_api.cpp:366-372)
+    const std::size_t l_text = le32(b + 4);
+    if (l_text > kMaxHeaderText) return set_err(err, "BAM header text length out of range");
     std::vector<unsigned char> text(l_text);
     if (l_text && !in.read(text.data(), l_text)) return set_err(err, "truncated BAM header text");
     h.raw.insert(h.raw.end(), text.begin(), text.end());
     if (!in.read(b, 4)) return set_err(err, "truncated BAM header (n_ref)");
     h.raw.insert(h.raw.end(), b, b + 4);
     h.n_ref = le32(b);
+    if (h.n_ref > kMaxReferences) return set_err(err, "BAM reference count out of range");
     for (std::uint32_t r = 0; r < h.n_ref; ++r) {
         if (!in.read(b, 4)) return set_err(err, "truncated BAM reference list");
         h.raw.insert(h.raw.end(), b, b + 4);
-        const std::uint32_t l_name = le32(b);
+        const std::size_t l_name = le32(b);
+        if (l_name == 0 || l_name > kMaxRefName) return set_err(err, "BAM reference name length out of range");
         std::vector<unsigned char> name(l_name + 4);
         if (!in.read(name.data(), name.size())) return set_err(err, "truncated BAM reference entry");
         h.raw.insert(h.raw.end(), name.begin(), name.end());
@@ -186,8 +197,9 @@ bool read_record(BgzfReader& in, std::vector<unsigned char>& rec, std::string* e
         if (!in.eof()) set_err(err, in.error().empty() ? "truncated BAM record" : in.error());
         return false;
     }
-    const std::uint32_t block_size = le32(b);
+    const std::size_t block_size = le32(b);
     if (block_size < 32) return set_err(err, "BAM record shorter than its fixed fields");
+    if (block_size > kMaxRecordBytes) return set_err(err, "BAM record length out of range");
     rec.resize(4 + block_size);
     std::memcpy(rec.data(), b, 4);
     if (!in.read(rec.data() + 4, block_size)) return set_err(err, in.error().empty() ? "truncated BAM record" : in.error());

@@ -2,6 +2,7 @@
 // restatement and the C++ solver adapter driven exactly as the reference drives a solver
 // (SolverManager::get(name).solve(M, BamApi)).
 #include <chrono>
+#include <new>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -198,18 +199,49 @@ std::int64_t qmcp_host_read_bam(const char* path, const char* bed, const char* t
     cfg.min_mapq = min_mapq;
     cfg.amplicon_behaviour = amplicon_mode == 1 ? bam_api::AmpliconBehaviour::FILTER
                            : amplicon_mode == 2 ? bam_api::AmpliconBehaviour::GRADE : bam_api::AmpliconBehaviour::IGNORE;
-    bam_api::BamApi api(path, cfg);
-    const bam_api::SOAPairedReads& r = api.get_paired_reads_soa();
-    const std::uint64_t n = r.ids.size();
-    if (n > cap || api.get_filtered_out_reads().size() > cap_f) return -2;
-    for (std::uint64_t i = 0; i < n; ++i) {
-        bam_ids[i] = r.ids[i]; starts[i] = (std::uint32_t)r.start_inds[i]; ends[i] = (std::uint32_t)r.end_inds[i];
-        qualities[i] = r.qualities[i]; seq_lengths[i] = r.seq_lengths[i]; is_first[i] = r.is_first_reads[i] ? 1 : 0;
+    try {
+        bam_api::BamApi api(path, cfg);
+        const bam_api::SOAPairedReads& r = api.get_paired_reads_soa();
+        const std::uint64_t n = r.ids.size();
+        if (n > cap || api.get_filtered_out_reads().size() > cap_f) return -2;
+        for (std::uint64_t i = 0; i < n; ++i) {
+            bam_ids[i] = r.ids[i]; starts[i] = (std::uint32_t)r.start_inds[i]; ends[i] = (std::uint32_t)r.end_inds[i];
+            qualities[i] = r.qualities[i]; seq_lengths[i] = r.seq_lengths[i]; is_first[i] = r.is_first_reads[i] ? 1 : 0;
+        }
+        *n_filtered_out = api.get_filtered_out_reads().size();
+        for (std::size_t i = 0; i < api.get_filtered_out_reads().size(); ++i) filtered_out[i] = api.get_filtered_out_reads()[i];
+        *ref_len = (std::uint32_t)r.ref_genome_length;
+        return (std::int64_t)n;
+    } catch (const std::bad_alloc&) {
+        return -3;  // (nothing is thrown through the C boundary)
     }
-    *n_filtered_out = api.get_filtered_out_reads().size();
-    for (std::size_t i = 0; i < api.get_filtered_out_reads().size(); ++i) filtered_out[i] = api.get_filtered_out_reads()[i];
-    *ref_len = (std::uint32_t)r.ref_genome_length;
-    return (std::int64_t)n;
+}
+
+// read_bam's own verdict on a file, without BamApi's exit-on-error (the reference exits the process on an
+// unreadable input; a caller that wants to look first -- and the tests of corrupt files -- use this): 0 and the
+// number of imported reads in *n_reads, or -1 and the reader's message in err (capacity cap).  Allocation
+// failures on absurd sizes are reported the same way, never thrown through the C boundary.
+int qmcp_host_check_bam(const char* path, std::uint64_t* n_reads, char* err, std::size_t cap) {
+    std::string msg;
+    int rc = -1;
+    try {
+        bam_api::SOAPairedReads reads;
+        std::vector<bam_api::BAMReadId> filtered;
+        bam_api::BamFilters f;
+        if (bam_api::read_bam(path, f, reads, filtered, nullptr, &msg)) {
+            if (n_reads) *n_reads = reads.ids.size();
+            rc = 0;
+        }
+    } catch (const std::bad_alloc&) {
+        msg = "out of memory while reading the BAM file";
+    } catch (const std::exception& e) {
+        msg = e.what();
+    }
+    if (err && cap) {
+        std::strncpy(err, msg.c_str(), cap - 1);
+        err[cap - 1] = 0;
+    }
+    return rc;
 }
 
 // The file-to-file flow of App::execute (src/app.cpp:113-151) for one solver: BamApi(path) -> solve ->
@@ -222,12 +254,16 @@ std::int64_t qmcp_host_downsample_bam(const char* solver_name, const char* in_pa
     bam_api::BamApiConfig cfg;
     cfg.min_seq_length = min_len;
     cfg.min_mapq = min_mapq;
-    bam_api::BamApi api(in_path, cfg);
-    auto solution = manager().get(solver_name).solve(max_coverage, api);
-    std::vector<bam_api::ReadIndex> paired = api.find_pairs(*solution);
-    const std::uint32_t written = api.write_paired_reads(out_path, paired);
-    if (filtered_path && filtered_path[0]) api.write_bam_api_filtered_out_reads(filtered_path);
-    return written;
+    try {
+        bam_api::BamApi api(in_path, cfg);
+        auto solution = manager().get(solver_name).solve(max_coverage, api);
+        std::vector<bam_api::ReadIndex> paired = api.find_pairs(*solution);
+        const std::uint32_t written = api.write_paired_reads(out_path, paired);
+        if (filtered_path && filtered_path[0]) api.write_bam_api_filtered_out_reads(filtered_path);
+        return written;
+    } catch (const std::bad_alloc&) {
+        return -3;
+    }
 }
 
 // The span the reference times as "solve took" (src/app.cpp:132-139) at the plugin boundary: a BamApi

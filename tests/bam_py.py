@@ -59,3 +59,49 @@ def pair_like_the_reference(recs, min_len=0, min_mapq=0, inside=None):
         else:
             seen[r["qname"]] = cur
     return out, [i for i, a in enumerate(accepted) if not a]
+
+
+# ---------------------------------------------------------------- an independent WRITER (tests only)
+# BGZF blocks by Python's zlib (raw deflate + the gzip member header with the "BC" extra field and the CRC32 /
+# ISIZE trailer, SAM specification section 4.1), records packed with struct -- nothing shared with the C++
+# writer in genome-downsampler_amd/host/src/bam_io.cpp, so the C++ reader is not only checked against its
+# sibling.
+import zlib
+
+CIGAR_OPS = "MIDNSHP=X"
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(payload, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(payload) + co.flush()
+    bsize = 12 + 6 + len(body) + 8 - 1     # total block size - 1
+    assert bsize < 65536
+    head = struct.pack("<4BIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, bsize)
+    return head + body + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
+
+
+def pack_record(qname, flag, pos, mapq, cigar, l_seq, ref_id=0, next_ref=-1, next_pos=-1, tlen=0, aux=b""):
+    """one alignment record (block_size included); cigar = [(length, op char), ...]; sequence all 'A', no
+    qualities (0xFF)"""
+    name = qname.encode() + b"\0"
+    cig = b"".join(struct.pack("<I", (n << 4) | CIGAR_OPS.index(op)) for n, op in cigar)
+    seq = bytes([0x11]) * ((l_seq + 1) // 2)
+    qual = b"\xff" * l_seq
+    body = struct.pack("<iiBBHHHIiii", ref_id, pos, len(name), mapq, 4680, len(cigar), flag, l_seq, next_ref,
+                       next_pos, tlen) + name + cig + seq + qual + aux
+    return struct.pack("<I", len(body)) + body
+
+
+def write_bam(path, references, records, text="@HD\tVN:1.6\tSO:unsorted\n", block_payload=40_000):
+    """references = [(name, length), ...]; records = packed records (pack_record).  Records straddle BGZF
+    block borders (blocks are cut every `block_payload` bytes), as in files written by other tools."""
+    text = text + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in references)
+    data = b"BAM\x01" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(references))
+    for n, l in references:
+        data += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", l)
+    data += b"".join(records)
+    with open(path, "wb") as f:
+        for o in range(0, len(data), block_payload):
+            f.write(_bgzf_block(data[o:o + block_payload]))
+        f.write(BGZF_EOF)

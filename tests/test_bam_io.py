@@ -116,3 +116,119 @@ def test_file_to_file_downsampling(tmp_path):
     assert [r["raw"] for r in orecs] == [recs[i]["raw"] for i in kept_ids.tolist()]
     _, frecs, _ = bam_py.parse(filt)
     assert [r["raw"] for r in frecs] == [recs[i]["raw"] for i in reads["filtered_out"].tolist()]
+
+
+# ---------------------------------------------------------------- files from ANOTHER writer, and corrupt ones
+import json
+import os
+import struct
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reader_on_a_file_written_by_another_writer():
+    """tests/golden/tiny_other_writer.bam comes from the pure-Python writer (make_tiny_bam.py): two references,
+    unmapped / secondary / supplementary records, every CIGAR operation, aux tags, records across BGZF block
+    borders.  read_bam treats flags as the reference does -- it pairs by name only (bam_api.cpp:428-461)."""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    path = os.path.join(GOLDEN, "tiny_other_writer.bam")
+    want = json.load(open(os.path.join(GOLDEN, "tiny_other_writer.expected.json")))
+    ok, n, msg = pkg.check_bam(path)
+    assert ok and n == len(want["bam_ids"]), msg
+    got = pkg.read_bam(path)
+    assert got["ref_genome_length"] == want["ref_lengths"][0]          # bam_api.cpp:422: target_len[0]
+    assert got["bam_ids"].tolist() == want["bam_ids"]
+    assert got["starts"].tolist() == [v % (1 << 32) for v in want["starts"]]   # (the binding narrows Index to 32 bits)
+    assert got["ends"].tolist() == [v % (1 << 32) for v in want["ends"]]
+    assert got["qualities"].tolist() == want["qualities"]
+    assert got["seq_lengths"].tolist() == want["seq_lengths"]
+    assert got["is_first"].tolist() == want["is_first"]
+    assert got["filtered_out"].tolist() == want["filtered_out"]
+    # and the fixture is what the committed script makes of the in-test parse today
+    header, recs, ref_lengths = bam_py.parse(path)
+    reads, filtered = bam_py.pair_like_the_reference(recs)
+    assert [r["bam_id"] for r in reads] == want["bam_ids"] and filtered == want["filtered_out"]
+
+
+def test_python_written_file_with_many_records_equals_the_pairing_rules(tmp_path):
+    """2 000 pairs in random order with soft clips, deletions, skips and unmapped mates, blocks cut every 5 000
+    bytes: C++ reader == independent parse + restated pairing, with and without the -l / -q filters"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    rng = np.random.default_rng(17)
+    recs = []
+    for q in range(2000):
+        for first in (True, False):
+            unmapped = rng.random() < 0.03
+            flag = (0x41 if first else 0x81) | (0x4 if unmapped else 0) | (0x100 if rng.random() < 0.02 else 0)
+            if unmapped:
+                recs.append(bam_py.pack_record(f"r{q}", flag, -1, 0, [], 100, ref_id=-1))
+                continue
+            m1, dl, m2 = int(rng.integers(30, 120)), int(rng.integers(0, 9)), int(rng.integers(1, 40))
+            cigar = ([(int(rng.integers(1, 20)), "S")] if rng.random() < 0.2 else []) + [(m1, "M")]
+            if dl:
+                cigar += [(dl, "D" if rng.random() < 0.7 else "N"), (m2, "M")]
+            l_seq = sum(n for n, op in cigar if op in "MIS=X")
+            recs.append(bam_py.pack_record(f"r{q}", flag, int(rng.integers(0, 29_000)), int(rng.integers(0, 61)),
+                                           cigar, l_seq))
+    order = rng.permutation(len(recs))
+    path = tmp_path / "py.bam"
+    bam_py.write_bam(path, [("ref", 30_000)], [recs[i] for i in order], block_payload=5_000)
+    header, parsed, _ = bam_py.parse(path)
+    for kw, (min_len, min_mapq) in (({}, (0, 0)), (dict(min_length=90, min_mapq=30), (90, 30))):
+        got = pkg.read_bam(path, **kw)
+        want, filtered = bam_py.pair_like_the_reference(parsed, min_len, min_mapq)
+        assert got["bam_ids"].tolist() == [r["bam_id"] for r in want]
+        assert got["starts"].tolist() == [r["start"] % (1 << 32) for r in want]
+        assert got["ends"].tolist() == [r["end"] % (1 << 32) for r in want]
+        assert got["filtered_out"].tolist() == filtered
+
+
+def _corrupt(tmp_path, name, mutate):
+    """a valid two-record file whose uncompressed bytes are changed by mutate(bytearray) before compression"""
+    import gzip
+    good = tmp_path / "good.bam"
+    recs = [bam_py.pack_record("a", 0x41, 10, 30, [(50, "M")], 50), bam_py.pack_record("a", 0x81, 90, 30, [(50, "M")], 50)]
+    bam_py.write_bam(good, [("ref", 1000)], recs)
+    data = bytearray(gzip.decompress(open(good, "rb").read()))
+    data = mutate(data)
+    path = tmp_path / name
+    with open(path, "wb") as f:
+        for o in range(0, len(data), 40_000):
+            f.write(bam_py._bgzf_block(bytes(data[o:o + 40_000])))
+        f.write(bam_py.BGZF_EOF)
+    return path
+
+
+def test_corrupt_length_fields_are_rejected_not_wrapped(tmp_path):
+    """block_size 0xFFFFFFFE (4 + block_size wrapped to 2 in 32-bit arithmetic: a heap overflow), absurd l_text and
+    l_name, a record cut short: each is an error message, none an allocation of its claimed size"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    ok, n, _ = pkg.check_bam(_corrupt(tmp_path, "fine.bam", lambda d: d))
+    assert ok and n == 2
+
+    def header_end(d):
+        l_text, = struct.unpack_from("<I", d, 4)
+        o = 8 + l_text + 4
+        l_name, = struct.unpack_from("<I", d, o)
+        return o + 4 + l_name + 4
+
+    def huge_block(d):
+        struct.pack_into("<I", d, header_end(d), 0xFFFFFFFE)
+        return d
+
+    def huge_text(d):
+        struct.pack_into("<I", d, 4, 0xFFFFFFF0)
+        return d
+
+    def huge_name(d):
+        l_text, = struct.unpack_from("<I", d, 4)
+        struct.pack_into("<I", d, 8 + l_text + 4, 0xFFFFFFFC)
+        return d
+
+    def cut_short(d):
+        return d[:len(d) - 20]
+
+    for name, mut, word in (("block.bam", huge_block, "record length"), ("text.bam", huge_text, "header text"),
+                            ("name.bam", huge_name, "reference name"), ("cut.bam", cut_short, "truncated")):
+        ok, n, msg = pkg.check_bam(_corrupt(tmp_path, name, mut))
+        assert not ok and word in msg, (name, msg)
