@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
 # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction), keyed by workload
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic_{workload}.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic_{workload}_inflight{depth}.json")
 
 WORKLOADS = {
     # name: (contigs per GPU, pairs per contig, contig length, read length, M)
@@ -74,6 +74,82 @@ def cfg5_share(pkg, torch, dev, solver, stream):
                  "whole_solve_frac": round(b_alg / (best["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                  "note": "one solve alone on the device (HIP events), inputs resident; not the headline workload"})
     return best
+
+
+def cfg5_real_share(pkg, torch, dev, solver, stream):
+    """The heaviest rank's REAL share of configs[4] at full size (24 contigs, 1.5e9 positions, 1e9 reads dealt to 8
+    ranks by sharding.assign_contigs): three contigs at full length -- 117.7 M, 52.0 M and 24.8 M positions, 129.7 M
+    reads, M = 50 -- device-resident, one solve alone, best of three; never `value`.  Parity:
+    tests/test_gpu_full_size.py::test_cfg5_real_share_of_the_heaviest_rank_at_full_length (== oracle)."""
+    synthetic = importlib.import_module("genome-downsampler_amd.synthetic")
+    share, owned = synthetic.cfg5_heaviest_share(8)
+    s, e, offs, lengths = synthetic.wgs_contigs(int(1.5e9), int(0.5e9), only=share)
+    n = int(s.size)
+    d_s = torch.from_numpy(s.view(np.int32)).to(dev)
+    d_e = torch.from_numpy(e.view(np.int32)).to(dev)
+    del s, e
+    d_m = torch.zeros(pkg.mask_words(n), dtype=torch.int64, device=dev)
+    best = None
+    for _ in range(3):
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n, lengths, 50, d_m.data_ptr(),
+                                 contig_read_offsets=offs, stream=stream)
+        if best is None or st.ms_total < best["device_ms"]:
+            best = {"device_ms": round(float(st.ms_total), 3), "sweep_ms": round(float(st.ms_sweep), 3),
+                    "kept": int(st.n_kept), "stretches": int(st.sweep_stretches),
+                    "speculative_boundaries": int(st.spec_boundaries),
+                    "boundaries_that_disagreed": int(st.spec_mismatches)}
+    b_alg = algorithmic_bytes(n, int(lengths.sum()), lengths.size)
+    best.update({"contigs_of_the_whole_genome": [int(c) for c in share], "reads": n,
+                 "positions": int(lengths.sum()), "longest_contig": int(lengths.max()), "max_coverage": 50,
+                 "reads_per_rank_of_the_assignment": [int(sum(2 * synthetic.wgs_shape(int(1.5e9), int(0.5e9))[1][c] for c in o)) for o in owned],
+                 "Mreads_per_s": round(n / best["device_ms"] / 1e3, 1),
+                 "whole_solve_frac": round(b_alg / (best["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                 "note": "one solve alone on the device (HIP events), inputs resident; not the headline workload"})
+    return best
+
+
+def clipped_configs(pkg, torch, dev, solver, stream, d_starts, d_ends, n_reads, lengths, offs, M):
+    """What one read of another length costs (BamApi derives a read's span from its CIGAR, libs/bam-api/src/read.cpp:
+    11-13: real BAMs are never of one length; every BASELINE config is).  cfg4 with 1 % of the reads soft-clipped by
+    1...50 bases, and cfg3's shape (30 M amplicon reads, M = 200) with 15 % clipped: device ms of one solve alone on
+    the mixed-span route, next to the same reads with one length.  Never `value`; parity of the routes:
+    tests/test_gpu_baseline_configs.py, tests/test_gpu_parity.py."""
+    synthetic = importlib.import_module("genome-downsampler_amd.synthetic")
+    out = {}
+    # cfg4, 1 % clipped
+    s = d_starts.cpu().numpy().view(np.uint32)
+    e = d_ends.cpu().numpy().view(np.uint32)
+    s2, e2 = synthetic.clipped_mix(s, e, 0.01)
+    d_s = torch.from_numpy(s2.view(np.int32)).to(dev)
+    d_e = torch.from_numpy(e2.view(np.int32)).to(dev)
+    d_m = torch.zeros(pkg.mask_words(n_reads), dtype=torch.int64, device=dev)
+    ms = []
+    for _ in range(2):
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n_reads, lengths, M, d_m.data_ptr(),
+                                 contig_read_offsets=offs, stream=stream)
+        ms.append(float(st.ms_total))
+    out["cfg4_1pct_clipped"] = {"device_ms": round(min(ms), 3), "path": int(st.path), "min_span": int(st.min_span),
+                                "max_span": int(st.max_span), "stretches": int(st.sweep_stretches),
+                                "kept": int(st.n_kept),
+                                "note": "cfg4 with 1 % of the reads shortened by 1...50 bases: mixed-span event sweep"}
+    del d_s, d_e, d_m
+    # cfg3's shape: 30 M amplicon reads, one length vs 85 / 15 mix
+    a, b, _, _, _ = synthetic.amplicon_reads(15_000_000)
+    res = {}
+    for name, (x, y) in (("one_length", (a, b)), ("clipped_tail_15pct", synthetic.clipped_mix(a, b, 0.15))):
+        d_s = torch.from_numpy(x.view(np.int32)).to(dev)
+        d_e = torch.from_numpy(y.view(np.int32)).to(dev)
+        d_m = torch.zeros(pkg.mask_words(x.size), dtype=torch.int64, device=dev)
+        ms = []
+        for _ in range(3):
+            st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), x.size, np.array([29_903], np.uint32), 200,
+                                     d_m.data_ptr(), stream=stream)
+            ms.append(float(st.ms_total))
+        res[name] = {"device_ms": round(min(ms), 3), "path": int(st.path), "kept": int(st.n_kept)}
+    res["ratio"] = round(res["clipped_tail_15pct"]["device_ms"] / res["one_length"]["device_ms"], 2)
+    res["note"] = "30 M amplicon reads on 29 903 bases, M = 200 (no FILTER): mixed-span route over one-length route"
+    out["cfg3_clipped_tail"] = res
+    return out
 
 
 def cfg3_full(pkg, solver):
@@ -138,11 +214,12 @@ def main():
                          "launch of the run is then the workload's own)")
     ap.add_argument("--mode", choices=["per-gpu", "sharded"], default="per-gpu",
                     help="N > 1: the workload per GPU (weak scaling) or one workload sharded by contig (strong)")
-    ap.add_argument("--exchange", choices=["gather", "all_gather"], default="gather",
+    ap.add_argument("--exchange", choices=["gather", "all_gather", "none"], default="gather",
                     help="N > 1: the keep masks go to rank 0 (what a caller needs: one Solution; N/8 bytes per rank over "
-                         "rank 0's seven links side by side) or to every rank")
+                         "rank 0's seven links side by side), to every rank, or nowhere (none: the solves alone, to "
+                         "separate them from the exchange in a scaling run)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="solves kept in flight per GPU (two solver contexts)")
+                    help="solves kept in flight per GPU (one solver context each; 1 = one at a time)")
     # rehearsal knobs (not used by the driver): run several ranks on ONE GPU over gloo to
     # exercise the N > 1 plumbing on a single-GPU box
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
@@ -227,7 +304,7 @@ def main():
         solvers[slot].solve_end()
         in_flight[slot] = None
         last_buf[0] = b
-        if world > 1:
+        if world > 1 and args.exchange != "none":
             # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
             if args.exchange == "all_gather":
                 gathers[b] = dist.all_gather_into_tensor(d_alls[b], d_masks[b], async_op=True)
@@ -302,6 +379,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # did the collective library see every rank?  (answerable from the line alone)
+    rccl_info = None
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, {"rank": rank, "device": torch.cuda.get_device_name(dev),
+                                       "local_rank": local_rank})
+        rccl_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": names}
     if sharded:
         total_reads = n_contigs_job * 2 * pairs      # one workload for the whole job
     else:
@@ -324,11 +408,15 @@ def main():
         step_ms = elapsed / args.steps * 1e3
         traffic, traffic_source, total_traffic = None, None, None
         try:
-            pmc = json.load(open(PMC_TRAFFIC_FILE.format(workload=args.workload)))
+            # collected with the same number of solves in flight as this run (profiles/collect.sh makes one file per
+            # depth); a run at another depth, or sharded, reports no traffic rather than another configuration's
+            pmc_file = PMC_TRAFFIC_FILE.format(workload=args.workload, depth=depth)
+            pmc = json.load(open(pmc_file)) if not sharded else {}
             traffic = pmc.get(dom_name, {}).get("hbm_bytes_per_launch")
             total_traffic = pmc.get("_total", {}).get("hbm_bytes_per_solve")
-            traffic_source = ("constant read from " + os.path.relpath(PMC_TRAFFIC_FILE.format(workload=args.workload), ROOT)
-                              + " (" + str(pmc.get("_source", "rocprofv3 --pmc passes, profiles/collect.sh")) + "); not measured in this run")
+            if pmc:
+                traffic_source = ("constant read from " + os.path.relpath(pmc_file, ROOT)
+                                  + " (" + str(pmc.get("_source", "rocprofv3 --pmc passes, profiles/collect.sh")) + "); not measured in this run")
         except (OSError, ValueError):
             pass
         # what bounds the dominant kernel itself: the event sweep's chain wave is a serial dependency
@@ -339,6 +427,10 @@ def main():
             "value": round(value, 2), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            # SURVEY 8(d)'s own definition, N / time of one solve() alone on the device (HIP events, nothing else in
+            # flight), beside the pipelined rate above -- per GPU, rank 0's
+            "value_single_solve": round(n_reads / (alone_ms * 1e-3) / 1e6, 2) if alone_ms > 0 else None,
+            "single_solve_ms": round(alone_ms, 4),
             "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": (f"{args.workload} sharded over {world} GPUs by contig (one workload for the job): "
@@ -350,6 +442,8 @@ def main():
                                "solves (all completed inside the timed region)"
                                if world > 1 else ""),
                 "multi_gpu_mode": args.mode if world > 1 else "single GPU",
+                "exchange": args.exchange if world > 1 else None,
+                "rccl_ranks": rccl_info,
                 "solves_in_flight_per_gpu": depth,
                 "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
                 "path": {1: "uniform-span block sweep", 2: "mixed-span event sweep"}.get(st.path),
@@ -363,6 +457,7 @@ def main():
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_launches,
                 "kernel_bound": "latency (one wave's dependency chain; see kernel_own_GBps)" if latency_bound else "hbm",
                 "kernel_own_GBps": (round(traffic / (dom_avg_ms * 1e-3) / 1e9, 2) if traffic else None),
+                "bytes_are_of": "rank 0's share of the job" if sharded else "one GPU's whole workload",
                 "whole_solve": {
                     "note": "algorithmic bytes of one solve over the time one solve takes: pipelined "
                             "(ms_per_step, two in flight) and alone on the device (HIP events)",
@@ -413,7 +508,10 @@ def main():
             out["plugin_entry"] = best
         if world == 1 and not args.no_extras and args.workload == "cfg4":
             out["other_configs"] = {"cfg3_full_size": cfg3_full(pkg, solvers[1 % depth]),
-                                    "cfg5_share_one_gpu": cfg5_share(pkg, torch, dev, solvers[0], stream)}
+                                    "cfg5_share_one_gpu": cfg5_share(pkg, torch, dev, solvers[0], stream),
+                                    "cfg5_real_share_heaviest_rank": cfg5_real_share(pkg, torch, dev, solvers[0], stream)}
+            out["other_configs"].update(clipped_configs(pkg, torch, dev, solvers[0], stream, d_starts, d_ends,
+                                                        n_reads, lengths, offs, M))
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             base, oracle_mask = cpu_baseline(pkg, args.workload)
             out["cpu_baseline"] = base

@@ -14,6 +14,13 @@
 
 static constexpr uint32_t kNoCut = 0xFFFFFFFFu;
 static constexpr int kSegMaxCandidates = 4096;  // contigs + windows (the one-span sweeps ask for at most 1024)
+// the host asks for at most kMaxSweepWindows windows and splits only calls of fewer than 256 contigs
+static_assert(kMaxSweepWindows + 256 <= (uint32_t)kSegMaxCandidates, "stretch tables: windows + contigs must fit k_build_segments' LDS arrays");
+// k_build_segments declares five arrays of kSegMaxCandidates words (~80 KiB of static LDS): fine on gfx950's
+// 160 KiB per workgroup, beyond the 64 KiB of gfx90a / gfx942 -- this library is written for gfx950 only
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "qmcp kernels are written for gfx950 (MI355X): k_build_segments alone needs more than 64 KiB of LDS per workgroup"
+#endif
 
 __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ boff,
                                                    const uint32_t* __restrict__ eoff,  // null: one span, ell

@@ -2050,11 +2050,18 @@ namespace {
 // LONGEST contig for the sweep (a device's chains run side by side)
 constexpr double kNsPerRead = 0.008, kNsPerPosition = 1.5, kNsPerPositionStretches = 0.012;
 
-// (sharding.py: _chain_free) a contig shallow and long enough for its sweep to run as stretches
-bool chain_free(double reads, double length, uint32_t span, uint32_t M) {
-    if (span == 0 || M == 0 || length <= 0) return false;
-    const double depth = reads * (double)span / (length * (double)M);
-    return depth < 4.1 && length >= 8.0 * 320.0 * (double)span;
+// (sharding.py: share_sweeps_as_stretches / share_cost) a share's sweep is cut into stretches exactly when the
+// solver would cut it: the AGGREGATE depth of everything the device owns (launch_uniform_sweep above)
+bool share_sweeps_as_stretches(double reads, double positions, size_t n_contigs, uint32_t span, uint32_t M) {
+    if (span == 0 || M == 0 || positions <= 0 || n_contigs >= 256) return false;
+    const double depth = reads * (double)span / (positions * (double)M);
+    if (depth <= kSpecMinDepth) return positions >= 128.0 * (double)span;  // nearly every window has a real cut
+    return depth < kSpecDepth && positions >= 8.0 * (double)spec_burn_blocks(depth) * (double)span;
+}
+double share_cost(double reads, double positions, double longest, size_t n_contigs, uint32_t span, uint32_t M) {
+    if (share_sweeps_as_stretches(reads, positions, n_contigs, span, M))
+        return kNsPerRead * reads + kNsPerPositionStretches * positions;
+    return kNsPerRead * reads + kNsPerPosition * longest;
 }
 
 void assign_contigs_by_cost(const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, int n_dev,
@@ -2063,26 +2070,21 @@ void assign_contigs_by_cost(const uint64_t* roff, const uint32_t* lengths, uint3
     std::vector<uint32_t> order(n_contigs);
     for (uint32_t c = 0; c < n_contigs; ++c) order[c] = c;
     auto n_reads_of = [&](uint32_t c) { return (double)(roff[c + 1] - roff[c]); };
-    auto stretched = [&](uint32_t c) { return chain_free(n_reads_of(c), (double)lengths[c], span, M); };
-    auto alone = [&](uint32_t c) {
-        return kNsPerRead * n_reads_of(c) + (stretched(c) ? kNsPerPositionStretches : kNsPerPosition) * (double)lengths[c];
-    };
+    auto alone = [&](uint32_t c) { return share_cost(n_reads_of(c), (double)lengths[c], (double)lengths[c], 1, span, M); };
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return alone(a) > alone(b); });
     std::vector<double> reads((size_t)n_dev, 0.0), longest((size_t)n_dev, 0.0), positions((size_t)n_dev, 0.0);
     for (uint32_t c : order) {
         int best = 0;
         double best_cost = 0;
-        const bool st = stretched(c);
         for (int d = 0; d < n_dev; ++d) {
-            const double cost = kNsPerRead * (reads[d] + n_reads_of(c)) +
-                                kNsPerPosition * (st ? longest[d] : std::max(longest[d], (double)lengths[c])) +
-                                kNsPerPositionStretches * (positions[d] + (st ? (double)lengths[c] : 0.0));
+            const double cost = share_cost(reads[d] + n_reads_of(c), positions[d] + (double)lengths[c],
+                                           std::max(longest[d], (double)lengths[c]), owned[d].size() + 1, span, M);
             if (d == 0 || cost < best_cost) { best = d; best_cost = cost; }
         }
         owned[best].push_back(c);
         reads[best] += n_reads_of(c);
-        if (st) positions[best] += (double)lengths[c];
-        else longest[best] = std::max(longest[best], (double)lengths[c]);
+        positions[best] += (double)lengths[c];
+        longest[best] = std::max(longest[best], (double)lengths[c]);
     }
     for (auto& o : owned) std::sort(o.begin(), o.end());
 }

@@ -10,40 +10,53 @@ import numpy as np
 
 # Cost model of one rank's share (measured on MI355X): the bandwidth-bound stages
 # cost time per READ and add up over a rank's contigs; the selection sweep is one serial chain per
-# contig, all of a rank's chains side by side, so it costs the LONGEST contig's length -- unless the contig
-# is shallow enough (mean coverage below 4.1 x M) and long enough for its sweep to run as hundreds of
-# stretches from cut points and speculative boundaries: then the sweep is throughput too, per position.
+# contig, all of a rank's chains side by side, so it costs the LONGEST contig's length -- unless the share's
+# sweep is cut into stretches (cut points, speculative boundaries): then it is throughput too, per position.
+# Whether it is cut is decided exactly as the solver decides it (csrc/qmcp_api.hip: launch_uniform_sweep,
+# spec_wanted, spec_burn_blocks), from the AGGREGATE depth of everything the rank owns -- not contig by
+# contig: a rank that mixes one deep contig with shallow ones sweeps whole contigs, and is priced so.
 NS_PER_READ = 0.008        # prepare + partition + offsets + ranking: ~0.8 ms per 1e8 reads
 NS_PER_POSITION = 1.5      # block-scan sweep on shallow data; deep data (event sweep) is ~0.5
 NS_PER_POSITION_STRETCHES = 0.012   # the same sweep cut into stretches (2.0 ms per 187.5 M positions)
-STRETCH_DEPTH = 4.1        # mean coverage in units of M below which a contig's sweep is cut into stretches
-STRETCH_MIN_BLOCKS = 8 * 320   # ... if it is at least this many read lengths long
+STRETCH_DEPTH = 4.1        # kSpecDepth: aggregate coverage in units of M below which boundaries are speculated on
+CUT_DEPTH = 1.3            # kSpecMinDepth: below it nearly every window holds a real cut point
+MAX_SPLIT_CONTIGS = 256    # the stretch tables take calls of fewer contigs than this
 
 
-def _chain_free(reads, length, read_length, max_coverage):
-    if not read_length or not max_coverage or length <= 0:
+def spec_burn_blocks(depth):
+    """run-in of a speculative boundary, in blocks (csrc/qmcp_api.hip: spec_burn_blocks)"""
+    return 320 if depth < 2.1 else 640 if depth < 2.6 else 1152 if depth < 3.1 else 2304
+
+
+def share_sweeps_as_stretches(reads, positions, n_contigs, read_length, max_coverage):
+    """the solver's own predicate on a whole share (a list of contigs solved in one call)"""
+    if not read_length or not max_coverage or positions <= 0 or n_contigs >= MAX_SPLIT_CONTIGS:
         return False
-    depth = float(reads) * float(read_length) / (float(length) * float(max_coverage))
-    return depth < STRETCH_DEPTH and length >= STRETCH_MIN_BLOCKS * read_length
+    depth = float(reads) * float(read_length) / (float(positions) * float(max_coverage))
+    if depth <= CUT_DEPTH:
+        return positions >= 128 * read_length
+    return depth < STRETCH_DEPTH and positions >= 8 * spec_burn_blocks(depth) * read_length
+
+
+def share_cost(reads, positions, longest, n_contigs, read_length=None, max_coverage=None):
+    if share_sweeps_as_stretches(reads, positions, n_contigs, read_length, max_coverage):
+        return NS_PER_READ * reads + NS_PER_POSITION_STRETCHES * positions
+    return NS_PER_READ * reads + NS_PER_POSITION * longest
 
 
 def rank_cost(read_counts, contig_lengths, contigs, read_length=None, max_coverage=None):
     reads = sum(int(read_counts[c]) for c in contigs)
-    longest, stretched = 0, 0
-    for c in contigs:
-        if _chain_free(int(read_counts[c]), int(contig_lengths[c]), read_length, max_coverage):
-            stretched += int(contig_lengths[c])
-        else:
-            longest = max(longest, int(contig_lengths[c]))
-    return NS_PER_READ * reads + NS_PER_POSITION * longest + NS_PER_POSITION_STRETCHES * stretched
+    positions = sum(int(contig_lengths[c]) for c in contigs)
+    longest = max([int(contig_lengths[c]) for c in contigs], default=0)
+    return share_cost(reads, positions, longest, len(contigs), read_length, max_coverage)
 
 
 def assign_contigs(read_counts, world_size, contig_lengths=None, read_length=None, max_coverage=None):
     """deterministic longest-processing-time assignment of contigs to ranks.  With contig_lengths the
     cost of a rank is reads * NS_PER_READ + (its longest contig) * NS_PER_POSITION -- the sweep's
     chains run side by side, so a rank pays for its longest one --, without it the read count alone;
-    with read_length and max_coverage as well, contigs whose sweep is cut into stretches (see above)
-    pay per position instead.  Returns a list (per rank) of ascending contig ids."""
+    with read_length and max_coverage as well, a share whose sweep the solver cuts into stretches (see
+    above) pays per position instead.  Returns a list (per rank) of ascending contig ids."""
     n = len(read_counts)
     if contig_lengths is None:
         contig_lengths = [0] * n

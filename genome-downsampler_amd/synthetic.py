@@ -42,17 +42,52 @@ def amplicon_reads(n_pairs, seed=12345, read_length=150, straddle_fraction=0.10)
     return starts, ends, a0, a1, straddle
 
 
-def wgs_contigs(total_length, total_pairs, read_length=150, seed=12345):
-    """configs[4] shape: 24 contigs with lengths proportional to GRCh38, reads proportional to
-    length, rand_reads_uniform(seed + c) per contig"""
-    pkg = importlib.import_module("genome-downsampler_amd")
+def wgs_shape(total_length, total_pairs, read_length=150):
+    """contig lengths and pair counts of the configs[4] shape (24 contigs ~ GRCh38 proportions)"""
     frac = np.array(GRCH38_MB, dtype=np.float64) / sum(GRCH38_MB)
     lengths = np.maximum((frac * total_length).astype(np.int64), 2 * read_length + 1)
     pairs = np.maximum((frac * total_pairs).astype(np.int64), 1)
+    return lengths, pairs
+
+
+def wgs_contigs(total_length, total_pairs, read_length=150, seed=12345, only=None):
+    """configs[4] shape: 24 contigs with lengths proportional to GRCh38, reads proportional to
+    length, rand_reads_uniform(seed + c) per contig.  only: the contig ids to generate (a rank's share of the
+    full-size configuration), in that order -- the seeds stay those of the whole genome."""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    lengths, pairs = wgs_shape(total_length, total_pairs, read_length)
+    ids = list(range(lengths.size)) if only is None else list(only)
     ss, ee = [], []
-    for c, (L, p) in enumerate(zip(lengths, pairs)):
-        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, int(p), int(L), read_length, seed=seed + c)
+    for c in ids:
+        s, e = pkg.reads_gen(pkg.KIND_UNIFORM, int(pairs[c]), int(lengths[c]), read_length, seed=seed + c)
         ss.append(s)
         ee.append(e)
-    offs = np.concatenate([[0], np.cumsum(2 * pairs)]).astype(np.uint64)
-    return np.concatenate(ss), np.concatenate(ee), offs, lengths.astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(2 * pairs[ids])]).astype(np.uint64)
+    return np.concatenate(ss), np.concatenate(ee), offs, lengths[ids].astype(np.uint32)
+
+
+def cfg5_heaviest_share(world=8, read_length=150, max_coverage=50):
+    """configs[4] at FULL size (24 contigs, 1.5e9 positions, 1e9 reads) dealt to `world` ranks by
+    sharding.assign_contigs: the contig ids of the rank with the most reads (its contigs at full length are one
+    GPU's real share -- chr1-sized contigs of > 10^8 positions, unlike the 1/8-scale genome of wgs_contigs(...))"""
+    sharding = importlib.import_module("genome-downsampler_amd.sharding")
+    lengths, pairs = wgs_shape(int(1.5e9), int(0.5e9), read_length)
+    owned = sharding.assign_contigs((2 * pairs).tolist(), world, contig_lengths=lengths.tolist(),
+                                    read_length=read_length, max_coverage=max_coverage)
+    heaviest = max(owned, key=lambda o: sum(int(pairs[c]) for c in o))
+    return heaviest, owned
+
+
+def clipped_mix(starts, ends, fraction, max_clip=50, seed=7):
+    """a fraction of the reads soft-clipped by 1 ... max_clip bases at either end (BamApi derives a read's span from
+    its CIGAR, libs/bam-api/src/read.cpp:11-13, so real BAMs are never of one length): returns new (starts, ends);
+    reads stay inside their contig because they only shrink"""
+    rng = np.random.default_rng(seed)
+    s = np.array(starts, dtype=np.uint32, copy=True)
+    e = np.array(ends, dtype=np.uint32, copy=True)
+    pick = np.flatnonzero(rng.random(s.size) < fraction)
+    clip = rng.integers(1, max_clip + 1, size=pick.size).astype(np.uint32)
+    front = rng.random(pick.size) < 0.5
+    s[pick[front]] += clip[front]
+    e[pick[~front]] -= clip[~front]
+    return s, e

@@ -62,6 +62,29 @@ def test_cfg5_one_gpus_share_contig_by_contig(pkg, oracle, solver):
         assert np.array_equal(bits[a:b], wbits), f"contig {c}"
 
 
+def test_cfg5_real_share_of_the_heaviest_rank_at_full_length(pkg, oracle, solver):
+    """configs[4] at FULL size dealt to 8 ranks by sharding.assign_contigs (24 contigs, 1.5e9 positions, 1e9
+    reads): the rank with the most reads owns three contigs at their full length -- 117.7 M, 52.0 M and 24.8 M
+    positions, 129.7 M reads -- unlike the 1/8-scale genome above, whose longest contig has 15 M positions.
+    Limits of the C ABI (include/qmcp_hip.h: 2^31 - 2 positions per call, 2^28 reads per contig on the block
+    sweep) hold with room; kept set == oracle contig by contig."""
+    share, owned = workloads.cfg5_heaviest_share(8)
+    assert sorted(sum(owned, [])) == list(range(24))
+    s, e, offs, lengths = workloads.wgs_contigs(int(1.5e9), int(0.5e9), only=share)
+    assert int(lengths.sum()) < (1 << 31) - 2 and int(np.diff(offs.astype(np.int64)).max()) < (1 << 28)
+    assert int(lengths.max()) > 100_000_000 and s.size > 120_000_000
+    got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_UNIFORM and st.sort_passes == 1 and st.n_contigs == len(share)
+    assert st.spec_boundaries > 500 and st.spec_mismatches == 0 and st.sweep_stretches > 500, st.as_dict()
+    bits = np.unpackbits(got.view(np.uint8), bitorder="little")
+    for c in range(lengths.size):
+        a, b = int(offs[c]), int(offs[c + 1])
+        want = oracle.solve(s[a:b], e[a:b], int(lengths[c]), 50)
+        wbits = np.unpackbits(want.view(np.uint8), bitorder="little")[:b - a]
+        assert np.array_equal(bits[a:b], wbits), f"contig {share[c]}"
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_emulated_on_one_gpu(pkg, oracle, solver, world):
     """the N > 1 composition with the HIP solver: assign_contigs -> local_problem -> HIP solve per

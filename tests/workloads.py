@@ -7,3 +7,6 @@ GRCH38_MB = _syn.GRCH38_MB
 amplicon_panel = _syn.amplicon_panel
 amplicon_reads = _syn.amplicon_reads
 wgs_contigs = _syn.wgs_contigs
+wgs_shape = _syn.wgs_shape
+cfg5_heaviest_share = _syn.cfg5_heaviest_share
+clipped_mix = _syn.clipped_mix
