@@ -74,6 +74,7 @@ struct SolveRun {
     qmcp_hip_stats local;
     bool trivial = false, head_done = false, may_rank = false, two_level = false, have_gstart = true;
     bool ranked_counted = false, wait_empty = false;
+    bool pm = false;                    // range-ranked route in its pass-major form (kernels/pass_major.inc.hip)
     uint32_t range_shift = 0;
     // a contig group whose tail was queued on the FIRST group's statistics (no host wait of its own): what was
     // assumed, checked against the group's own read-back when the solve is collected
@@ -97,6 +98,7 @@ struct qmcp_hip_ctx {
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
+    DevBuf pm_ccur;    // pass-major form: wave 0's slice cursor at every 1024-record chunk of every range
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     unsigned long long* h_scalars = nullptr;  // pinned landing zone of the solve's result scalars (4 words)
@@ -541,6 +543,32 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     return QMCP_OK;
 }
 
+// The pass-major form of the range-ranked route keeps, per range, the row of the passes that can hold its records
+// in LDS: those of the contigs whose positions overlap the range (kernels/pass_major.inc.hip: pm_relevant_passes,
+// restated here on the host's tables).  True if no row is longer than the kernels' share of LDS.
+bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift) {
+    if (const char* e = std::getenv("QMCP_HIP_PM"))
+        if (e[0] == '0') return false;  // (A/B: the range-major form)
+    const uint32_t ltot = (uint32_t)pr.ltot, n_contigs = pr.n_contigs;
+    auto contig_at = [&](uint32_t pos) {
+        uint32_t lo = 0, hi = n_contigs;  // last c with poff[c] <= pos
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)pr.poff[mid] <= pos) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t pass = qmcp::pm_pass();
+    for (uint32_t d = 0; d <= (ltot >> shift); ++d) {
+        const uint32_t pos0 = d << shift;
+        const uint32_t pos1 = std::min(pos0 + (1u << shift), ltot + 1u) - 1u;
+        const uint64_t p_lo = roff[contig_at(pos0)] / pass;
+        const uint64_t p_hi = (roff[contig_at(pos1) + 1] + pass - 1) / pass;
+        if (p_hi - p_lo > qmcp::pm_max_row()) return false;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // One solve = enqueue_head (everything that depends only on the reads' start positions: prepare, the
 // range partition and the bucket offsets; nothing in it waits for the device on large calls) +
@@ -595,7 +623,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
-        TRY(ensure(c, c->hist2, (size_t)256 * qmcp::part_pass_pitch(n) * sizeof(uint32_t)));
+        TRY(ensure(c, c->hist2, ((size_t)256 * qmcp::part_pass_pitch(n) + 4) * sizeof(uint32_t)));  // (+ the scan's total)
+        TRY(ensure(c, c->pm_ccur, ((size_t)n / 1024 + 260) * sizeof(uint32_t)));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 8) * sizeof(uint32_t)));  // also the event sweep's changed-block S
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
@@ -653,6 +682,27 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         hipStream_t s1 = c->stream;
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
+        run.pm = !two_level && pm_rows_fit(roff, pr, range_shift);
+        if (run.pm) {
+            // One pass over the reads: validate, statistics, mask clear, and every pass of 8 192 reads sorted by range
+            // in place (4 B per read out, two [range][pass] tables); a scan of the count table gives the flat
+            // coordinates the per-range kernels walk.  No range-major copy, no second read of the starts.
+            {
+                KernelSpan sp(c, "k_pm_prepare_sort");
+                qmcp::launch_pm_prepare_sort(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
+                                             n_contigs, range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
+                                             (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->stats.p,
+                                             mask_cleared ? nullptr : (unsigned long long*)d_mask);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
+            {
+                KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+                qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::pm_pitch(n),
+                                            (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, true);
+                qmcp::launch_pm_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
+            }
+        } else {
         {
             KernelSpan sp(c, "k_prepare");
             qmcp::launch_prepare(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
@@ -668,7 +718,10 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
             qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::part_pass_pitch(n),
                                         (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
         }
-        if (!two_level) {
+        }
+        if (run.pm) {
+            // (nothing: the pass-major form has no partition)
+        } else if (!two_level) {
             KernelSpan sp(c, "k_range_partition");
             qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
                                          (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
@@ -689,7 +742,12 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
                                           (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
         }
         HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
-        {
+        if (run.pm) {
+            KernelSpan sp(c, "k_pm_offsets");
+            qmcp::launch_pm_offsets(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p,
+                                    n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p, n_contigs, range_shift, ltot,
+                                    (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
+        } else {
             // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan; it also
             // counts the positions that start no read (stats word 3: the host picks the sweep kernel by it)
             KernelSpan sp(c, "k_range_offsets");
@@ -829,7 +887,16 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         ranked = (uint64_t)max_load * kRankBalance <= (uint64_t)n;
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
         run.assumed_ranked = ranked;
-        if (ranked) {
+        if (ranked && run.pm) {
+            KernelSpan sp(c, "k_pm_rank_mark");
+            qmcp::launch_pm_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p,
+                                      (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, (const uint64_t*)c->roff.p,
+                                      (const uint64_t*)c->poff.p, n_contigs, range_shift, ltot, (const uint32_t*)c->boff.p,
+                                      (const uint32_t*)c->selend.p, (unsigned long long*)d_mask,
+                                      (unsigned long long*)c->scalars.p, c->rankamb.p,
+                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
+            HIP_TRY(hipGetLastError());
+        } else if (ranked) {
             KernelSpan sp(c, "k_rank_mark");
             qmcp::launch_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p,
                                    d_range_start, range_shift, ltot,
@@ -1488,7 +1555,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -176,5 +176,23 @@ void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* id
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
                       void* scratch, bool scratch_by_records, uint32_t mask_bit0 = 0);
 
+// range-ranked route, pass-major layout (kernels/pass_major.inc.hip): one-level genomes
+uint32_t pm_pitch(uint32_t n);     // row pitch of the [range][pass] tables
+uint32_t pm_max_row();             // passes of a range's row the per-range kernels hold in LDS
+uint32_t pm_pass();                // reads per pass
+void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
+                            const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
+                            uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
+                            uint32_t* stats, unsigned long long* zero_mask);
+void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load);
+void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
+                       const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
+                       uint32_t* boff, uint32_t* empty_positions);
+void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* T,
+                         const uint32_t* lst_tab, uint32_t n, const uint64_t* d_roff, const uint64_t* d_poff,
+                         uint32_t n_contigs, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                         unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
+                         uint32_t* chunk_cursor, uint32_t mask_bit0);
+
 }  // namespace qmcp
 #endif

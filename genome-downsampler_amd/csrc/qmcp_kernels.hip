@@ -17,6 +17,8 @@
 //   radix_sort               LSD radix passes (sort-based routes)
 //   bucket_offsets           sort-based routes: bucket offsets from the sorted keys (heads + reverse min-scan)
 //   ranked_route             range partition (one or two levels), per-range offsets, ordered ranking
+//   pass_major               the same route without the range-major copy: one pass over the reads sorts every pass of
+//                            8 192 in place; the per-range kernels walk its slices (included last: uses the launchers' helpers)
 //   sweep_uniform            block forms of the uniform-span sweep, single-wave kernel
 //   sweep_segments           cut points (coverage <= M): contigs split into independently swept stretches
 //   sweep_uniform_pipelines  seven-wave pipelines: fast form with checked fallback, all-general form
@@ -53,5 +55,6 @@ static constexpr uint32_t kInf = 0x40000000u;
 #include "kernels/sweep_mixed.inc.hip"
 #include "kernels/mark_and_next_rows.inc.hip"
 #include "kernels/launchers.inc.hip"
+#include "kernels/pass_major.inc.hip"
 
 }  // namespace qmcp

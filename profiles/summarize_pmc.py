@@ -27,6 +27,9 @@ KERNEL_WIDTHS = {
     "k_range_partition": ("read_4", "write_4"),   # dword loads; u16 + u32 stores (4 of every 6 bytes are dwords)
     "k_range_offsets": ("read_8", "write_4"),     # 8-byte loads of four u16 keys; dword stores of bucket offsets
     "k_rank_mark": ("rw_2_4", "atomic_or64"),     # u16 + u32 record streams; 64-bit atomic ORs
+    "k_pm_prepare_sort": ("read_4", "write_4"),   # dword loads of starts and ends; dword stores of two 16-bit records
+    "k_pm_offsets": ("read_8", "write_4"),        # 8-byte loads of four u16 keys; dword stores of bucket offsets
+    "k_pm_rank_mark": ("read_2", "atomic_or64"),  # two u16 record streams; 64-bit atomic ORs
     "k_sweep_pack": ("read_4", "write_16"),
     "k_sweep_uniform_ev": ("read_16", "write_4"),
     "k_sweep_expand": ("read_4", "write_4"),
