@@ -375,9 +375,16 @@ uint32_t sweep_cut_windows(uint32_t ltot, uint32_t span, uint32_t n_contigs, boo
 // if some boundary disagreed -- a second with three times that (or, where the genome is too short for it,
 // none: the exact table); the exact sweep runs only if the second tier disagrees somewhere too.  Every
 // tier's launches are queued at once and gated by device words, so nothing waits for the host.
-constexpr double kSpecDepth = 4.1, kSpecMinDepth = 1.3;
+// Round 3 (lab/spec_depth_gap.py, one contig of 20 M positions at 100 x coverage, profiles/r03_spec_depth_gap.log):
+// between 4.1 and 11 x M -- where round 2 swept whole contigs as one chain each -- the sweep forgets its start too,
+// within about a thousand blocks: boundaries that disagreed at a run-in of 256 / 512 / 1024 / 2048 blocks: depth 4.2:
+// 55 of 127 / 2 of 63 / 0 of 31 / 0; 5.9: 85 / 11 / 0 / 0; 8.3: 100 / 20 / 0 / 0; 10: 108 / 23 / 1 of 31 / 0 of 15 --
+// sweep 30.9 -> 1.3 ms.  So every depth the general-form sweep takes (below kGenDepth) is speculated on; at cfg4's
+// depth (18.75, and at 37.5) every boundary still disagrees at 2 048 blocks (lab/spec_deep_probe.py): the event-driven
+// chain stays whole there.
+constexpr double kSpecDepth = kGenDepth, kSpecMinDepth = 1.3;
 uint32_t spec_burn_blocks(double depth) {
-    return depth < 2.1 ? 320u : depth < 2.6 ? 640u : depth < 3.1 ? 1152u : 2304u;
+    return depth < 2.1 ? 320u : depth < 2.6 ? 640u : depth < 3.1 ? 1152u : depth < 4.1 ? 2304u : 1536u;
 }
 bool spec_wanted(double depth) {
     bool on = depth < kSpecDepth && depth > kSpecMinDepth;  // (shallower: nearly every window has a real cut point)

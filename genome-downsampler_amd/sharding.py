@@ -18,14 +18,14 @@ import numpy as np
 NS_PER_READ = 0.008        # prepare + partition + offsets + ranking: ~0.8 ms per 1e8 reads
 NS_PER_POSITION = 1.5      # block-scan sweep on shallow data; deep data (event sweep) is ~0.5
 NS_PER_POSITION_STRETCHES = 0.012   # the same sweep cut into stretches (2.0 ms per 187.5 M positions)
-STRETCH_DEPTH = 4.1        # kSpecDepth: aggregate coverage in units of M below which boundaries are speculated on
+STRETCH_DEPTH = 11.0       # kSpecDepth (= kGenDepth): aggregate coverage in units of M below which boundaries are speculated on
 CUT_DEPTH = 1.3            # kSpecMinDepth: below it nearly every window holds a real cut point
 MAX_SPLIT_CONTIGS = 256    # the stretch tables take calls of fewer contigs than this
 
 
 def spec_burn_blocks(depth):
     """run-in of a speculative boundary, in blocks (csrc/qmcp_api.hip: spec_burn_blocks)"""
-    return 320 if depth < 2.1 else 640 if depth < 2.6 else 1152 if depth < 3.1 else 2304
+    return 320 if depth < 2.1 else 640 if depth < 2.6 else 1152 if depth < 3.1 else 2304 if depth < 4.1 else 1536
 
 
 def share_sweeps_as_stretches(reads, positions, n_contigs, read_length, max_coverage):

@@ -210,3 +210,23 @@ def test_mixed_spans_with_more_than_a_thousand_stretches(pkg, oracle, solver, de
     if depth >= 2.0:
         assert st.spec_boundaries > 500, st.as_dict()
     assert np.array_equal(got, oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
+
+
+@pytest.mark.parametrize("M,depth", [(12, 5.0), (8, 7.5), (6, 10.0)])
+def test_depths_between_4_and_11_times_m_are_swept_as_stretches_too(pkg, oracle, solver, M, depth):
+    """round 2 swept such data as one chain per contig (it had measured the forgetting only up to 4 x M); measured in
+    round 3 (lab/spec_depth_gap.py) the sweep forgets its start within about a thousand blocks up to 10 x M, so
+    boundaries are speculated on at every depth the general-form sweep takes; whatever they do, the kept set is the
+    oracle's"""
+    rng = np.random.default_rng(1000 + M)
+    s, e, offs, lengths = _uniform_contigs(rng, [3_200_000, 900_000], depth, M, 150)
+    with _env(QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        st = solver.last_stats
+    assert st.path == pkg.PATH_UNIFORM and st.spec_boundaries >= 1, st.as_dict()
+    want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(got, want)
+    with _env(QMCP_HIP_SPEC="0"):
+        plain = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        assert solver.last_stats.spec_boundaries == 0
+    assert np.array_equal(plain, want)
