@@ -230,32 +230,10 @@ __global__ __launch_bounds__(256) void k_pm_range_table(const uint32_t* __restri
     if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-// The passes that can hold records of range d -- those of the contigs whose positions overlap the range -- as
-// [p_lo, p_hi); tests/pass_major_model.py: relevant_passes.  (uniform: every thread computes the same)
-__device__ __forceinline__ void pm_relevant_passes(uint32_t d, uint32_t shift, uint32_t ltot,
-                                                   const uint64_t* __restrict__ contig_read_off,
-                                                   const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs,
-                                                   uint32_t& p_lo, uint32_t& p_hi) {
-    const uint32_t pos0 = d << shift;
-    const uint32_t pos1 = min(pos0 + (1u << shift), ltot + 1u) - 1u;  // (ltot itself: where a zero-length contig's reads count)
-    auto contig_at = [&](uint32_t pos) {
-        uint32_t lo = 0, hi = n_contigs;  // last c with poff[c] <= pos
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)contig_pos_off[mid] <= pos) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-    const uint32_t c_first = contig_at(pos0), c_last = contig_at(pos1);
-    p_lo = (uint32_t)(contig_read_off[c_first] >> 13);
-    p_hi = (uint32_t)((contig_read_off[c_last + 1] + (kPmPass - 1)) >> 13);
-}
-
 // k_range_offsets for the pass-major layout: the range's positions come as slices, one per pass, in any order.
 __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ T,
                                                      const uint32_t* __restrict__ lst_tab, uint32_t pitch,
-                                                     const uint64_t* __restrict__ contig_read_off,
-                                                     const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs,
+                                                     const uint32_t* __restrict__ rows /* [2][256]: p_lo, p_hi of every range (the host's pm_relevant_passes) */,
                                                      uint32_t shift, uint32_t ltot, uint32_t* __restrict__ boff,
                                                      uint32_t* __restrict__ empty_positions) {
     extern __shared__ uint32_t s_cnt32[];  // [(1 << shift) padded] counters, then [kPmMaxRow + 1] + [kPmMaxRow] row copies
@@ -265,8 +243,7 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
     uint32_t* const s_T = s_cnt32 + width + (width >> 5) + 1;
     uint32_t* const s_L = s_T + kPmMaxRow + 1;
     const uint32_t lo = T[(size_t)range * pitch];
-    uint32_t p_lo, p_hi;
-    pm_relevant_passes(range, shift, ltot, contig_read_off, contig_pos_off, n_contigs, p_lo, p_hi);
+    const uint32_t p_lo = rows[range], p_hi = rows[256 + range];
     const uint32_t n_rel = min(p_hi - p_lo, kPmMaxRow);  // (the host takes this route only where no row is longer)
     for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[PADDED(i)] = 0;
     for (uint32_t i = threadIdx.x; i <= n_rel; i += blockDim.x) s_T[i] = T[(size_t)range * pitch + p_lo + i];
@@ -278,44 +255,59 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
     // wave w takes the slices w, w + 16, ...; four slices' loads in flight (records four at a time, 8-byte loads from
     // the 8-byte-aligned address at or below the slice: what lies outside the slice is the neighbouring ranges')
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    constexpr int U = 8;  // slices in flight per wave: up to 16 x 512 B = 8 KiB per wave, 128 KiB per CU
-    for (uint32_t k0 = w; k0 < n_rel; k0 += U * nw) {
-        uint32_t first[U], n_q[U], skip[U], end[U];  // (uniform: read through the first lane, so that branches on them are scalar)
-        uint2 q[U][2];
+    // Two batches of four slices alternate: the next batch's loads are under way while this one's are counted
+    // (single batches of eight left the wave idle for a trip to memory twelve to twenty-four times: 0.12 ms).
+    constexpr int U = 4;
+    struct Batch { uint32_t first[U], n_q[U], skip[U], end[U]; uint2 q[U][2]; };
+    auto fetch = [&](Batch& b, uint32_t k0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t k = k0 + u * nw;
             const uint32_t cnt = k < n_rel ? s_T[k + 1] - s_T[k] : 0u;
             const uint32_t f = k < n_rel ? (p_lo + k) * kPmStride + s_L[k] : 0u;
-            const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+            const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);  // (uniform: scalar branches below)
             const uint32_t fu = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-            first[u] = fu & ~3u;                       // aligned record index the quads start at
-            skip[u] = fu & 3u;                         // elements of the first quad that belong to the slice before
-            end[u] = skip[u] + cu;                     // one past the slice's last element, counted from first[u]
-            n_q[u] = cu ? (end[u] + 3u) >> 2 : 0u;
+            b.first[u] = fu & ~3u;                       // aligned record index the quads start at
+            b.skip[u] = fu & 3u;                         // elements of the first quad that belong to the slice before
+            b.end[u] = b.skip[u] + cu;                   // one past the slice's last element, counted from first[u]
+            b.n_q[u] = cu ? (b.end[u] + 3u) >> 2 : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint2* __restrict__ quads = reinterpret_cast<const uint2*>(keys16 + first[u]);
-            q[u][0] = lane < n_q[u] ? quads[lane] : make_uint2(0u, 0u);
-            if (n_q[u] > 64u) q[u][1] = lane + 64u < n_q[u] ? quads[lane + 64u] : make_uint2(0u, 0u);
+            const uint2* __restrict__ quads = reinterpret_cast<const uint2*>(keys16 + b.first[u]);
+            b.q[u][0] = lane < b.n_q[u] ? quads[lane] : make_uint2(0u, 0u);
+            if (b.n_q[u] > 64u) b.q[u][1] = lane + 64u < b.n_q[u] ? quads[lane + 64u] : make_uint2(0u, 0u);
         }
+    };
+    auto consume = [&](const Batch& b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             auto count_quad = [&](uint2 v, uint32_t j) {
                 const uint32_t e0 = 4u * j;  // element index of the quad's first, from first[u]
-                if (e0 >= skip[u] && e0 < end[u]) count(v.x & 0xFFFFu);
-                if (e0 + 1 >= skip[u] && e0 + 1 < end[u]) count(v.x >> 16);
-                if (e0 + 2 >= skip[u] && e0 + 2 < end[u]) count(v.y & 0xFFFFu);
-                if (e0 + 3 >= skip[u] && e0 + 3 < end[u]) count(v.y >> 16);
+                if (e0 >= b.skip[u] && e0 < b.end[u]) count(v.x & 0xFFFFu);
+                if (e0 + 1 >= b.skip[u] && e0 + 1 < b.end[u]) count(v.x >> 16);
+                if (e0 + 2 >= b.skip[u] && e0 + 2 < b.end[u]) count(v.y & 0xFFFFu);
+                if (e0 + 3 >= b.skip[u] && e0 + 3 < b.end[u]) count(v.y >> 16);
             };
-            if (lane < n_q[u]) count_quad(q[u][0], lane);
-            if (n_q[u] > 64u) {
-                if (lane + 64u < n_q[u]) count_quad(q[u][1], lane + 64u);
+            if (lane < b.n_q[u]) count_quad(b.q[u][0], lane);
+            if (b.n_q[u] > 64u) {
+                if (lane + 64u < b.n_q[u]) count_quad(b.q[u][1], lane + 64u);
                 // slices longer than 128 quads (a pass whose reads fall into few ranges): the rest, plainly
-                for (uint32_t j = lane + 128u; j < n_q[u]; j += 64u)
-                    count_quad(reinterpret_cast<const uint2*>(keys16 + first[u])[j], j);
+                for (uint32_t j = lane + 128u; j < b.n_q[u]; j += 64u)
+                    count_quad(reinterpret_cast<const uint2*>(keys16 + b.first[u])[j], j);
             }
+        }
+    };
+    {
+        Batch A, B;
+        const uint32_t step = U * nw;
+        uint32_t k0 = w;
+        if (k0 < n_rel) fetch(A, k0);
+        for (; k0 < n_rel; k0 += 2 * step) {
+            if (k0 + step < n_rel) fetch(B, k0 + step);
+            consume(A);
+            if (k0 + 2 * step < n_rel) fetch(A, k0 + 2 * step);
+            if (k0 + step < n_rel) consume(B);
         }
     }
     __syncthreads();
@@ -401,8 +393,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
                                                        const uint16_t* __restrict__ idx16,
                                                        const uint32_t* __restrict__ T,
                                                        const uint32_t* __restrict__ lst_tab, uint32_t pitch,
-                                                       const uint64_t* __restrict__ contig_read_off,
-                                                       const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs,
+                                                       const uint32_t* __restrict__ rows /* [2][256]: p_lo, p_hi of every range */,
                                                        uint32_t shift, uint32_t ltot, uint32_t n,
                                                        const uint32_t* __restrict__ boff,
                                                        const uint32_t* __restrict__ selend,
@@ -422,8 +413,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
     const uint32_t lo = T[(size_t)range * pitch];
     const uint32_t hi = range + 1 < 256 ? T[(size_t)(range + 1) * pitch] : n;
     if (lo >= hi) return;  // uniform: a range without reads needs no quotas either
-    uint32_t p_lo, p_hi;
-    pm_relevant_passes(range, shift, ltot, contig_read_off, contig_pos_off, n_contigs, p_lo, p_hi);
+    const uint32_t p_lo = rows[range], p_hi = rows[256 + range];
     const uint32_t n_rel = min(p_hi - p_lo, kPmMaxRow);
     uint2* const amb = amb_lists + (lists_by_records ? (size_t)lo : (size_t)range * width);
     uint32_t* const ccur = chunk_cursor + (lo >> 10) + range;  // (ranges' chunk counts add up to at most n / 1024 + one each)
@@ -567,12 +557,39 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
         uint32_t key[kSteps], slot[kSteps];
         uint32_t scur = __hip_atomic_load(&ccur[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (uniform; own workgroup's store)
         scur = (uint32_t)__builtin_amdgcn_readfirstlane((int)scur);
+        {
+            // the chunk's 1024 positions cross few slices: ONE read of the 64 row entries behind the chunk's cursor serves
+            // all sixteen steps from registers (more than 63 borders inside a chunk: step by step through pm_slot_of)
+            const uint32_t ci = scur + 1u + lane;
+            const uint32_t cand_t = ci <= n_rel ? s_T[ci] : 0xFFFFFFFFu;
+            const uint32_t cand_l = ci < n_rel ? s_L[ci] : 0u;
+            const uint32_t t0 = s_T[scur], l0 = s_L[min(scur, n_rel - 1u)];
+            const bool few = (uint32_t)__popcll(__ballot(cand_t <= min(first + chunk_recs - 1u, hi - 1))) < 64u;
 #pragma unroll
-        for (int t = 0; t < kSteps; ++t) {
-            const uint32_t x0 = min(first + t * 64u, hi - 1);
-            const uint32_t x = min(first + t * 64u + lane, hi - 1);
-            slot[t] = pm_slot_of(s_T, s_L, n_rel, p_lo, scur, x0, x, lane);
-            key[t] = keys16[slot[t]];
+            for (int t = 0; t < kSteps; ++t) {
+                const uint32_t x0 = min(first + t * 64u, hi - 1);
+                const uint32_t x = min(first + t * 64u + lane, hi - 1);
+                if (few) {
+                    const uint32_t nb = (uint32_t)__popcll(__ballot(cand_t <= x0));
+                    const uint32_t tot = (uint32_t)__popcll(__ballot(cand_t <= x0 + 63u));
+                    uint32_t ts = nb ? (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)(nb - 1u)) : t0;
+                    uint32_t ls = nb ? (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)(nb - 1u)) : l0;
+                    uint32_t sl = scur + nb;
+                    for (uint32_t u = nb; u < tot; ++u) {  // uniform: the borders inside the step's positions
+                        const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)u);
+                        const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)u);
+                        const bool in = x >= bt;
+                        ts = in ? bt : ts;
+                        ls = in ? bl : ls;
+                        sl += in ? 1u : 0u;
+                    }
+                    sl = min(sl, n_rel - 1u);
+                    slot[t] = (p_lo + sl) * kPmStride + ls + (x - ts);
+                } else {
+                    slot[t] = pm_slot_of(s_T, s_L, n_rel, p_lo, scur, x0, x, lane);
+                }
+                key[t] = keys16[slot[t]];
+            }
         }
 #pragma unroll
         for (int t = kSteps - 1; t >= 0; --t) {
@@ -616,24 +633,23 @@ void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32
     hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, T, pm_pitch(n), n, range_start, max_load);
 }
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
-                       const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
-                       uint32_t* boff, uint32_t* empty_positions) {
+                       const uint32_t* rows, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
     const size_t width = (size_t)1 << shift;
     const size_t lds = (width + width / 32 + 1 + 2 * (size_t)kPmMaxRow + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_offsets, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, T, lst_tab, pm_pitch(n), d_roff, d_poff,
-                       n_contigs, shift, ltot, boff, empty_positions);
+    hipLaunchKernelGGL(k_pm_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, T, lst_tab, pm_pitch(n), rows, shift, ltot,
+                       boff, empty_positions);
 }
 void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* T,
-                         const uint32_t* lst_tab, uint32_t n, const uint64_t* d_roff, const uint64_t* d_poff,
-                         uint32_t n_contigs, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                         const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
+                         const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
                          uint32_t* chunk_cursor, uint32_t mask_bit0) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const size_t lds = (((size_t)1 << shift) + 1 + 2 * (size_t)kPmMaxRow + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, T, lst_tab, pm_pitch(n), d_roff,
-                       d_poff, n_contigs, shift, ltot, n, boff, selend, mask, kept_total, (uint2*)scratch,
+    hipLaunchKernelGGL(k_pm_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, T, lst_tab, pm_pitch(n), rows,
+                       shift, ltot, n, boff, selend, mask, kept_total, (uint2*)scratch,
                        scratch_by_records ? 1 : 0, chunk_cursor, mask_bit0);
 }

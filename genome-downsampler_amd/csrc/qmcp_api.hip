@@ -99,6 +99,8 @@ struct qmcp_hip_ctx {
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
     DevBuf pm_ccur;    // pass-major form: wave 0's slice cursor at every 1024-record chunk of every range
+    DevBuf pm_rows;    // ... and every range's row of passes [p_lo, p_hi) (2 x 256 words), from the host
+    uint32_t* h_pm_rows = nullptr;  // pinned staging of the same
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     unsigned long long* h_scalars = nullptr;  // pinned landing zone of the solve's result scalars (4 words)
@@ -553,7 +555,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
 // The pass-major form of the range-ranked route keeps, per range, the row of the passes that can hold its records
 // in LDS: those of the contigs whose positions overlap the range (kernels/pass_major.inc.hip: pm_relevant_passes,
 // restated here on the host's tables).  True if no row is longer than the kernels' share of LDS.
-bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift) {
+bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift, uint32_t* rows /* [2][256] out: p_lo, p_hi */) {
     if (const char* e = std::getenv("QMCP_HIP_PM"))
         if (e[0] == '0') return false;  // (A/B: the range-major form)
     const uint32_t ltot = (uint32_t)pr.ltot, n_contigs = pr.n_contigs;
@@ -572,7 +574,10 @@ bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift) {
         const uint64_t p_lo = roff[contig_at(pos0)] / pass;
         const uint64_t p_hi = (roff[contig_at(pos1) + 1] + pass - 1) / pass;
         if (p_hi - p_lo > qmcp::pm_max_row()) return false;
+        rows[d] = (uint32_t)p_lo;
+        rows[256 + d] = (uint32_t)p_hi;
     }
+    for (uint32_t d = (ltot >> shift) + 1; d < 256; ++d) rows[d] = rows[256 + d] = 0;
     return true;
 }
 
@@ -632,6 +637,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist2, ((size_t)256 * qmcp::part_pass_pitch(n) + 4) * sizeof(uint32_t)));  // (+ the scan's total)
         TRY(ensure(c, c->pm_ccur, ((size_t)n / 1024 + 260) * sizeof(uint32_t)));
+        TRY(ensure(c, c->pm_rows, 512 * sizeof(uint32_t)));
+        if (!c->h_pm_rows) HIP_TRY(hipHostMalloc((void**)&c->h_pm_rows, 512 * sizeof(uint32_t), hipHostMallocDefault));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 8) * sizeof(uint32_t)));  // also the event sweep's changed-block S
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
@@ -689,8 +696,9 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         hipStream_t s1 = c->stream;
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
-        run.pm = !two_level && pm_rows_fit(roff, pr, range_shift);
+        run.pm = !two_level && pm_rows_fit(roff, pr, range_shift, c->h_pm_rows);
         if (run.pm) {
+            HIP_TRY(hipMemcpyAsync(c->pm_rows.p, c->h_pm_rows, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s1));
             // One pass over the reads: validate, statistics, mask clear, and every pass of 8 192 reads sorted by range
             // in place (4 B per read out, two [range][pass] tables); a scan of the count table gives the flat
             // coordinates the per-range kernels walk.  No range-major copy, no second read of the starts.
@@ -752,7 +760,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         if (run.pm) {
             KernelSpan sp(c, "k_pm_offsets");
             qmcp::launch_pm_offsets(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p,
-                                    n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p, n_contigs, range_shift, ltot,
+                                    n, (const uint32_t*)c->pm_rows.p, range_shift, ltot,
                                     (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
         } else {
             // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan; it also
@@ -897,8 +905,8 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         if (ranked && run.pm) {
             KernelSpan sp(c, "k_pm_rank_mark");
             qmcp::launch_pm_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p,
-                                      (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, (const uint64_t*)c->roff.p,
-                                      (const uint64_t*)c->poff.p, n_contigs, range_shift, ltot, (const uint32_t*)c->boff.p,
+                                      (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p,
+                                      range_shift, ltot, (const uint32_t*)c->boff.p,
                                       (const uint32_t*)c->selend.p, (unsigned long long*)d_mask,
                                       (unsigned long long*)c->scalars.p, c->rankamb.p,
                                       qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
@@ -1562,7 +1570,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->pm_rows, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -1582,6 +1590,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_go) (void)hipEventDestroy(c->ev_go);
     if (c->h_head) (void)hipHostFree(c->h_head);
+    if (c->h_pm_rows) (void)hipHostFree(c->h_pm_rows);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) c->stream = c->own_stream;  // (a group context's `stream` may stand for its parent's)
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -186,11 +186,11 @@ void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32
                             uint32_t* stats, unsigned long long* zero_mask);
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load);
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
-                       const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
-                       uint32_t* boff, uint32_t* empty_positions);
+                       const uint32_t* rows /* [2][256]: first and one-past-last pass of every range's row */, uint32_t shift,
+                       uint32_t ltot, uint32_t* boff, uint32_t* empty_positions);
 void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* T,
-                         const uint32_t* lst_tab, uint32_t n, const uint64_t* d_roff, const uint64_t* d_poff,
-                         uint32_t n_contigs, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                         const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
+                         const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
                          uint32_t* chunk_cursor, uint32_t mask_bit0);
 
