@@ -4,9 +4,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <thread>
 
 namespace bam_api {
 namespace {
@@ -26,20 +28,29 @@ bool set_err(std::string* err, const std::string& msg) {
     return false;
 }
 
-// Sequential reader of the uncompressed stream of a BGZF file: one gzip member (with the "BC" extra
-// subfield giving its size) at a time, raw inflate of its payload, CRC and length checked.
+// Sequential reader of the uncompressed stream of a BGZF file.  The file is a sequence of gzip members whose extra
+// subfield "BC" gives the member's size (SAM specification 4.1); every member inflates on its own, so the calling
+// thread reads a batch of members from the file (about 8 MiB of compressed bytes) and several threads inflate it,
+// one member per task, CRC and length checked -- what HTSlib's thread pool does for the reference
+// (bam_api.cpp:386-397: hts_tpool_init, hts_set_opt(HTS_OPT_THREAD_POOL)).  QMCP_BAM_THREADS sets the number of
+// inflating threads (default: up to 8 of the host's cores; 1: the calling thread alone).
 class BgzfReader {
    public:
     ~BgzfReader() { if (f_) std::fclose(f_); }
     bool open(const std::filesystem::path& p) {
         f_ = std::fopen(p.c_str(), "rb");
+        threads_ = 8;
+        if (const char* e = std::getenv("QMCP_BAM_THREADS")) threads_ = (unsigned)std::strtoul(e, nullptr, 10);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw != 0 && threads_ > hw) threads_ = hw;
+        if (threads_ < 1) threads_ = 1;
         return f_ != nullptr;
     }
     // reads exactly n bytes; false at a clean end of file before the first byte (eof() tells) or on error
     bool read(void* dst, std::size_t n) {
         unsigned char* out = static_cast<unsigned char*>(dst);
         while (n != 0) {
-            if (pos_ == block_.size() && !next_block()) return false;
+            if (pos_ == block_.size() && !next_batch()) return false;
             const std::size_t take = std::min(n, block_.size() - pos_);
             std::memcpy(out, block_.data() + pos_, take);
             pos_ += take; out += take; n -= take;
@@ -50,50 +61,93 @@ class BgzfReader {
     const std::string& error() const { return error_; }
 
    private:
-    bool next_block() {
-        for (;;) {  // (empty blocks -- the end-of-file marker is one -- are skipped)
+    struct Member { std::size_t in_off, in_len, out_off, out_len; std::uint32_t crc; };
+
+    bool next_batch() {
+        constexpr std::size_t kBatchBytes = std::size_t(8) << 20;  // compressed bytes per batch
+        block_.clear();
+        pos_ = 0;
+        if (!error_.empty() || eof_) return false;
+        comp_.clear();
+        members_.clear();
+        std::size_t out_total = 0;
+        while (comp_.size() < kBatchBytes) {
             unsigned char hdr[12];
             const std::size_t got = std::fread(hdr, 1, sizeof(hdr), f_);
-            if (got == 0) { eof_ = true; return false; }
+            if (got == 0) { at_end_ = true; break; }
             if (got != sizeof(hdr) || hdr[0] != 0x1F || hdr[1] != 0x8B || hdr[2] != 8 || !(hdr[3] & 4)) {
                 error_ = "not a BGZF block (gzip header without an extra field)";
                 return false;
             }
-            const std::uint16_t xlen = le16(hdr + 10);
-            std::vector<unsigned char> extra(xlen);
-            if (std::fread(extra.data(), 1, xlen, f_) != xlen) { error_ = "truncated BGZF header"; return false; }
-            std::uint32_t bsize = 0;
-            for (std::size_t o = 0; o + 4 <= extra.size();) {
-                const std::uint16_t slen = le16(extra.data() + o + 2);
-                if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) bsize = le16(extra.data() + o + 4) + 1u;
+            const std::size_t xlen = le16(hdr + 10);
+            extra_.resize(xlen);
+            if (std::fread(extra_.data(), 1, xlen, f_) != xlen) { error_ = "truncated BGZF header"; return false; }
+            std::size_t bsize = 0;
+            for (std::size_t o = 0; o + 4 <= extra_.size();) {
+                const std::size_t slen = le16(extra_.data() + o + 2);
+                if (extra_[o] == 'B' && extra_[o + 1] == 'C' && slen == 2 && o + 6 <= extra_.size()) bsize = (std::size_t)le16(extra_.data() + o + 4) + 1u;
                 o += 4u + slen;
             }
             if (bsize < 12u + xlen + 8u) { error_ = "BGZF block without a BC size field"; return false; }
             const std::size_t payload = bsize - 12u - xlen - 8u;
-            comp_.resize(payload + 8);
-            if (std::fread(comp_.data(), 1, comp_.size(), f_) != comp_.size()) { error_ = "truncated BGZF block"; return false; }
-            const std::uint32_t crc = le32(comp_.data() + payload), isize = le32(comp_.data() + payload + 4);
+            const std::size_t off = comp_.size();
+            comp_.resize(off + payload + 8);
+            if (std::fread(comp_.data() + off, 1, payload + 8, f_) != payload + 8) { error_ = "truncated BGZF block"; return false; }
+            const std::uint32_t crc = le32(comp_.data() + off + payload);
+            const std::size_t isize = le32(comp_.data() + off + payload + 4);
             if (isize > kBgzfMaxBlock) { error_ = "BGZF block larger than 64 KiB"; return false; }
-            block_.resize(isize);
-            pos_ = 0;
-            if (isize != 0) {
-                z_stream zs;
-                std::memset(&zs, 0, sizeof(zs));
-                if (inflateInit2(&zs, -15) != Z_OK) { error_ = "inflateInit2 failed"; return false; }
-                zs.next_in = comp_.data(); zs.avail_in = (uInt)payload;
-                zs.next_out = block_.data(); zs.avail_out = (uInt)isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.avail_out != 0) { error_ = "BGZF block does not inflate to its stated size"; return false; }
-                if (crc32(crc32(0L, Z_NULL, 0), block_.data(), (uInt)isize) != crc) { error_ = "BGZF block checksum mismatch"; return false; }
-                return true;
+            if (isize != 0) {  // (empty blocks -- the end-of-file marker is one -- are skipped)
+                members_.push_back(Member{off, payload, out_total, isize, crc});
+                out_total += isize;
             }
         }
+        if (members_.empty()) {
+            if (at_end_) eof_ = true;
+            if (!at_end_) return next_batch();  // (a batch of empty members only: go on)
+            return false;
+        }
+        block_.resize(out_total);
+        std::atomic<std::size_t> next{0};
+        std::atomic<int> failed{0};
+        auto work = [&]() {
+            for (std::size_t i = next.fetch_add(1); i < members_.size() && failed.load() == 0; i = next.fetch_add(1)) {
+                const Member& m = members_[i];
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { failed.store(1); return; }
+                zs.next_in = comp_.data() + m.in_off; zs.avail_in = (uInt)m.in_len;
+                zs.next_out = block_.data() + m.out_off; zs.avail_out = (uInt)m.out_len;
+                const int rc = inflate(&zs, Z_FINISH);
+                const bool sized = rc == Z_STREAM_END && zs.avail_out == 0;
+                inflateEnd(&zs);
+                if (!sized) { failed.store(2); return; }
+                if (crc32(crc32(0L, Z_NULL, 0), block_.data() + m.out_off, (uInt)m.out_len) != m.crc) { failed.store(3); return; }
+            }
+        };
+        const unsigned t = (unsigned)std::min<std::size_t>(threads_, members_.size());
+        if (t <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            pool.reserve(t - 1);
+            for (unsigned k = 1; k < t; ++k) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        if (failed.load() != 0) {
+            error_ = failed.load() == 1 ? "inflateInit2 failed"
+                   : failed.load() == 2 ? "BGZF block does not inflate to its stated size" : "BGZF block checksum mismatch";
+            block_.clear();
+            return false;
+        }
+        return true;
     }
     std::FILE* f_ = nullptr;
-    std::vector<unsigned char> comp_, block_;
+    unsigned threads_ = 1;
+    std::vector<unsigned char> comp_, block_, extra_;
+    std::vector<Member> members_;
     std::size_t pos_ = 0;
-    bool eof_ = false;
+    bool eof_ = false, at_end_ = false;
     std::string error_;
 };
 

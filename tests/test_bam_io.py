@@ -232,3 +232,33 @@ def test_corrupt_length_fields_are_rejected_not_wrapped(tmp_path):
                             ("name.bam", huge_name, "reference name"), ("cut.bam", cut_short, "truncated")):
         ok, n, msg = pkg.check_bam(_corrupt(tmp_path, name, mut))
         assert not ok and word in msg, (name, msg)
+
+
+def test_inflating_on_several_threads_reads_the_same_file(tmp_path, monkeypatch):
+    """BGZF members inflate on their own: read in batches of ~8 MiB of compressed bytes and inflated on up to 8
+    threads (QMCP_BAM_THREADS), as the reference hands the file to HTSlib's thread pool (bam_api.cpp:386-397).  A
+    file of several batches read with one thread and with eight: the same reads, and the independent parse's."""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    rng = np.random.default_rng(23)
+    n_pairs = 200_000
+    n = 2 * n_pairs
+    names = np.repeat(np.arange(n_pairs), 2)[rng.permutation(n)]
+    flags = np.where(rng.random(n) < 0.5, 0x41, 0x81).astype(np.uint16)
+    pos = rng.integers(0, 2_000_000, size=n)
+    mapq = rng.integers(0, 61, size=n)
+    clip = rng.integers(0, 30, size=n)
+    match = rng.integers(50, 151, size=n)
+    dele = np.where(rng.random(n) < 0.2, rng.integers(1, 9, size=n), 0)
+    match2 = np.where(dele > 0, rng.integers(5, 40, size=n), 0)
+    path = tmp_path / "big.bam"
+    pkg.write_synthetic_bam(path, 2_100_000, names, flags, pos, mapq, clip, match, dele, match2)
+    assert path.stat().st_size > 9 * (1 << 20)      # more than one batch of compressed bytes
+    monkeypatch.setenv("QMCP_BAM_THREADS", "1")
+    one = pkg.read_bam(path)
+    monkeypatch.setenv("QMCP_BAM_THREADS", "8")
+    many = pkg.read_bam(path)
+    for k in ("bam_ids", "starts", "ends", "qualities", "seq_lengths", "is_first", "filtered_out"):
+        assert np.array_equal(one[k], many[k]), k
+    header, recs, _ = bam_py.parse(path)
+    want, filtered = bam_py.pair_like_the_reference(recs)
+    assert many["bam_ids"].tolist() == [r["bam_id"] for r in want] and many["filtered_out"].tolist() == filtered
