@@ -39,6 +39,9 @@ def test_single_gpu_line_carries_what_the_driver_reads():
     c = b["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and b["parity_vs_oracle_on_sample"] is True
     assert "host_entry" in b and "plugin_entry" in b
+    # SURVEY 8(d)'s own definition beside the pipelined rate: N / time of one solve alone
+    assert b["value_single_solve"] > 0 and b["single_solve_ms"] > 0
+    assert abs(b["value_single_solve"] - 1.0 / b["single_solve_ms"] * 1e3) / b["value_single_solve"] < 0.02
 
 
 def test_two_ranks_over_gloo_on_one_gpu():
@@ -51,3 +54,19 @@ def test_two_ranks_over_gloo_on_one_gpu():
     b = _one_json_line(out.stdout)
     assert b["n_gpus"] == 2 and b["scaling"] == "weak" and "gather of the keep masks at rank 0" in b["config"]["workload"]
     assert b["value"] > 0 and "cpu_baseline" not in b
+    # what the collective library saw, answerable from the line alone
+    rr = b["config"]["rccl_ranks"]
+    assert rr["backend"] == "gloo" and rr["world_size"] == 2 and sorted(r["rank"] for r in rr["ranks"]) == [0, 1]
+    assert b["config"]["exchange"] == "gather"
+
+
+def test_two_ranks_without_the_exchange():
+    """--exchange none: the solves alone, so that a scaling run can tell them from the gather"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "cfg2", "--dist-backend", "gloo",
+                          "--single-device", "--exchange", "none"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = _one_json_line(out.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["exchange"] == "none" and b["value"] > 0
