@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
 )
 
 QMCP_OK = 0
-PATH_UNIFORM, PATH_GENERAL = 1, 2
+PATH_UNIFORM, PATH_GENERAL, PATH_NEAR_UNIFORM = 1, 2, 3
 KIND_UNIFORM, KIND_LOW_BOTH_SIDES, KIND_HOLE, KIND_ZERO_BOTH_SIDES = 0, 1, 2, 3
 
 
@@ -60,7 +60,8 @@ class Stats(C.Structure):
         ("ms_h2d", C.c_float), ("ms_d2h", C.c_float), ("columns_sent", C.c_uint32),
         ("spec_boundaries", C.c_uint32), ("spec_mismatches", C.c_uint32),
         ("spec_retry_mismatches", C.c_uint32), ("contig_groups", C.c_uint32),
-        ("arena_grown_mid_solve", C.c_uint32),
+        ("arena_grown_mid_solve", C.c_uint32), ("near_uniform_exceptions", C.c_uint32),
+        ("near_uniform_selected", C.c_uint32), ("near_uniform_rounds", C.c_uint32),
     ]
 
     def as_dict(self):

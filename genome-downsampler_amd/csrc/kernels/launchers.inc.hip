@@ -215,6 +215,9 @@ bool sweep_uniform_ev_supported(uint32_t ell, uint32_t M) {
 }
 uint32_t sweep_ev_pieces(uint32_t ltot, uint32_t ell, uint32_t n_wg) { return ltot / (4u * ell) + n_wg + 1; }
 size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) { return (size_t)sweep_ev_pieces(ltot, ell, n_wg) * 1024; }
+size_t sweep_ev_ckpt_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {  // the chain's state at every 64th block
+    return ((size_t)sweep_ev_pieces(ltot, ell, n_wg) / 16 + 2 * (size_t)n_wg + 4) * 512 * sizeof(uint32_t);
+}
 size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {
     return ((size_t)sweep_ev_pieces(ltot, ell, n_wg) * 4 + 64) * sizeof(uint32_t);
 }
@@ -229,20 +232,21 @@ size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {
     }
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk) {
+                          uint32_t* pk, const int32_t* nadj) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
 #define QMCP_CALL(EE)                                                                                      \
     hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, ell, \
-                       M, ltot, seg, pieces, pk);
+                       M, ltot, seg, pieces, pk, nadj);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;
 }
 bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats) {
+                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats,
+                           const int32_t* nadj, uint32_t* ckpt, const uint32_t* restart) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const size_t lds = (size_t)kEvSlots * 1024;
@@ -250,7 +254,7 @@ bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t*
     (void)hipFuncSetAttribute((const void*)k_sweep_uniform_ev<EE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                    \
     hipLaunchKernelGGL(k_sweep_uniform_ev<EE>, dim3(n_wg), dim3(128), lds, st, boff, d_poff, n_contigs, ell,  \
-                       M, ltot, pk, sev, lastns, iter_stats, seg);
+                       M, ltot, pk, sev, lastns, iter_stats, seg, nadj, ckpt, restart);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;

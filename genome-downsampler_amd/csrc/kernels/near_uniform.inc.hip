@@ -1,0 +1,331 @@
+// near_uniform.inc.hip -- part of qmcp_kernels.hip (one translation unit; included inside namespace qmcp).
+// ------------------------------------------------------------------ near-uniform route
+// Calls whose reads have one dominant span ell and a small share of SHORTER ones (soft clips, insertions: BamApi
+// takes a read's span from its CIGAR, libs/bam-api/src/read.cpp:11-13).  The mixed-span walk is one wave's serial
+// chain per contig at ~165 cycles per position; the one-span sweep is ~1.2.  This route keeps the one-span machinery
+// and treats the short reads as EXCEPTIONS (tests/near_uniform_model.py restates it on the host, checked against the
+// oracle before these kernels were written):
+//
+//   The canonical greedy (oracle/qmcp_oracle.c, standing in for SimpleMaxFlow::Solve at
+//   quasi_mcp_cpu_max_flow_solver.cpp:19-20: at a position with a deficit take the unselected covering reads with the
+//   largest end, then the largest start, then the smallest index) files every read under its END: bucket
+//   v = end - ell + 1.  A regular read starts at its bucket; a shorter one is released late, at start > v, and from
+//   then on goes before its bucket's regular members.  A read selected at time t covers [t, end] whatever its start,
+//   so as long as no exception is wanted the selection is the one-span sweep over the regular reads with
+//   need'(p) = min(cov_all(p), M) - (exceptions selected so far that cover p, from the time they were selected).
+//
+//   k_pm_prepare_sort   (pass_major.inc.hip, ell_reg != 0) leaves the exceptions out of the sorted passes and lists them;
+//   k_nu_exc_diff + scan + k_nu_need_adjust   coverage of the exceptions -> nadj[p] = need'(p) - min(cov_regular(p), M);
+//   k_nu_prepick        an exception that starts where everything is kept (cov_all <= M) is selected when released;
+//   [ k_sweep_pack / k_sweep_uniform_ev / k_sweep_expand with nadj  ->  S(p) of the regular reads
+//     k_nu_verify       every unselected exception x = (v, s, e): it can only be reached at a time t in [s, e] if all
+//                       regular members of the buckets (v, t] are selected by then, hence in the sweep's FINAL counts:
+//                       one look at bucket s clears nearly all; the rest are listed as suspects
+//     k_nu_replay       one wave per suspect: the sweep's time-resolved picks over the run of exhausted buckets
+//                       around s, rebuilt from final counts (below the run's anchor nothing is picked late), give the
+//                       first time the demand exceeds what the buckets above x still offer
+//     k_nu_select / k_nu_apply   per contig the earliest such event (highest priority first) is exact -- before it
+//                       greedy and sweep agree -- so that exception is selected at that time: nadj -= 1 on [t, e] ]
+//   repeated until no exception is wanted; then k_pm_rank_mark for the regular reads and k_nu_mark_selected.
+// The host gives up (and takes the mixed-span route) when a suspect's run is longer than the window, when the loop
+// does not settle within its budget, or when any read is LONGER than the dominant span.
+static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
+static constexpr unsigned long long kNuNoKey = ~0ull;
+
+struct NuExc {  // the exception list: three arrays of cap words + the route's own two
+    const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
+    const uint32_t* count; uint32_t cap;
+};
+__device__ __forceinline__ uint32_t nu_count(const NuExc& x) { return min(*x.count, x.cap); }
+
+__global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
+                                                       uint32_t n, uint32_t span, uint32_t* __restrict__ out) {
+    uint32_t local = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        local += (ends[i] - starts[i] + 1u == span) ? 1u : 0u;
+    local = wave_sum_u32(local);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+// +1 at an exception's start, -1 behind its end, and its flags reset
+__global__ __launch_bounds__(256) void k_nu_exc_diff(NuExc x, uint32_t* __restrict__ diff) {
+    const uint32_t n = nu_count(x);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        atomicAdd(&diff[x.gs[i]], 1u);
+        atomicAdd(&diff[x.ge[i] + 1u], 0xFFFFFFFFu);
+        x.pick[i] = kNuUnpicked;
+        x.key[i] = kNuNoKey;
+    }
+}
+
+// ce = exclusive scan of diff: exceptions covering p = ce[p + 1]
+__device__ __forceinline__ uint32_t nu_cov_regular(const uint32_t* __restrict__ boff, uint32_t p, uint32_t ell) {
+    return boff[p + 1] - boff[p + 1 >= ell ? p + 1 - ell : 0u];  // (the global prefix needs no clamp at contig borders)
+}
+__global__ __launch_bounds__(256) void k_nu_need_adjust(const uint32_t* __restrict__ boff, const uint32_t* __restrict__ ce,
+                                                        uint32_t ltot, uint32_t ell, uint32_t M, int32_t* __restrict__ nadj) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p <= ltot; p += gridDim.x * blockDim.x) {
+        int32_t a = 0;
+        if (p < ltot) {
+            const uint32_t cr = nu_cov_regular(boff, p, ell);
+            a = (int32_t)min(cr + ce[p + 1], M) - (int32_t)min(cr, M);
+        }
+        nadj[p] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nu_prepick(NuExc x, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ ce,
+                                                    uint32_t ell, uint32_t M, int32_t* __restrict__ nadj,
+                                                    uint32_t* __restrict__ state) {
+    const uint32_t n = nu_count(x);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = x.gs[i], e = x.ge[i];
+        if (nu_cov_regular(boff, s, ell) + ce[s + 1] <= M) {
+            x.pick[i] = s;
+            for (uint32_t p = s; p <= e; ++p) atomicSub(&nadj[p], 1);
+            atomicAdd(&state[3], 1u);
+        }
+    }
+}
+
+struct NuView {  // what verify and replay read of the sweep's result
+    const uint32_t* boff; const uint32_t* selend; const int32_t* nadj; const uint64_t* poff; uint32_t n_contigs, ell, M;
+};
+__device__ __forceinline__ uint32_t nu_c(const NuView& v, uint32_t u) { return v.boff[u + 1] - v.boff[u]; }
+__device__ __forceinline__ uint32_t nu_S(const NuView& v, uint32_t u) { return v.selend[u] - v.boff[u]; }
+__device__ __forceinline__ uint32_t nu_contig_of(const NuView& v, uint32_t pos) {
+    uint32_t lo = 0, hi = v.n_contigs;  // last c with poff[c] <= pos
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)v.poff[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// a bucket before the contig's first position holds nothing (and nothing is kept across a contig's border)
+__device__ __forceinline__ bool nu_exhausted(const NuView& v, int32_t u, int32_t c0) {
+    return u < c0 || nu_S(v, (uint32_t)u) == nu_c(v, (uint32_t)u);
+}
+
+// suspects: {exception, contig} pairs
+__global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                   uint32_t* __restrict__ state,
+                                                   const uint32_t* __restrict__ swept_from /* per contig: the first block this round swept */) {
+    const uint32_t n = nu_count(x);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (x.pick[i] != kNuUnpicked) continue;
+        const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
+        const int32_t b = e - (int32_t)v.ell + 1;
+        const uint32_t contig = nu_contig_of(v, (uint32_t)s);
+        const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
+        // what an earlier round cleared stays cleared: nothing at or below e has changed if the round swept only
+        // from a later block on (a contig that is settled sweeps nothing)
+        const uint32_t from = swept_from[contig];
+        if (from == 0xFFFFFFFFu || (uint64_t)(uint32_t)(e - c0) < (uint64_t)from * v.ell) continue;
+        bool reach = true;
+        for (int32_t u = s; u > b && reach; --u) reach = nu_exhausted(v, u, c0);
+        if (!reach) continue;
+        const uint32_t slot = atomicAdd(&state[4], 1u);
+        if (slot < suspects_cap) suspects[slot] = make_uint2(i, contig);
+        else atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
+        x.key[i] = kNuNoKey;
+    }
+}
+
+// One wave per suspect.  Everything the replay reads -- bucket offsets, the sweep's result and nadj over
+// [s - 2 ell, e + 1] -- is staged in LDS first (a trip to memory per replayed position would make an exception in a
+// contig's last ell positions, where every bucket is empty and the run is as long as the read, cost half a millisecond).
+static constexpr int kNuStage = 3 * 256 + 16;  // ell <= 256 (the event-driven sweep's limit)
+static constexpr int kNuCur = 2 * 256 + 8;
+__global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                  uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key) {
+    __shared__ uint32_t s_b[kNuStage], s_e[kNuStage];
+    __shared__ int32_t s_a[kNuStage], s_cur[kNuCur], s_stack[kNuCur];
+    const int32_t lane = (int32_t)threadIdx.x;
+    const uint32_t n_sus = min(state[4], suspects_cap);
+    const int32_t ell = (int32_t)v.ell;
+    for (uint32_t q = blockIdx.x; q < n_sus; q += gridDim.x) {
+        const uint2 su = suspects[q];
+        const uint32_t i = su.x, contig = su.y;
+        const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
+        const int32_t b = e - ell + 1;
+        const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
+        const int32_t r0 = max(s - 2 * ell, 0);
+        const int32_t count = e + 1 - r0 + 1;  // <= 3 ell + 1
+        __syncthreads();  // (the previous suspect's reads of the stage are done)
+        for (int32_t k = lane; k < count && k < kNuStage; k += 64) {
+            s_b[k] = v.boff[r0 + k];
+            s_e[k] = v.selend[r0 + k];
+            s_a[k] = v.nadj[r0 + k];
+        }
+        for (int32_t k = lane; k < kNuCur; k += 64) s_cur[k] = 0;
+        __syncthreads();
+        auto C = [&](int32_t u) { return (int32_t)(s_b[u + 1 - r0] - s_b[u - r0]); };
+        auto S = [&](int32_t u) { return (int32_t)(s_e[u - r0] - s_b[u - r0]); };
+        auto exhausted = [&](int32_t u) { return u < c0 || S(u) == C(u); };
+        auto need = [&](int32_t t) {
+            const int32_t from = max(t + 1 - ell, 0);  // (>= r0: t > s - ell)
+            return (int32_t)min(s_b[t + 1 - r0] - s_b[from - r0], v.M) + s_a[t - r0];
+        };
+        // the run of exhausted buckets downwards from b; its anchor u1 - 1 is the first bucket that keeps members for
+        // good (or lies before the contig): nothing below it is picked at or after its own time
+        int32_t u1 = b + 1;
+        while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < ell) --u1;
+        if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
+            if (lane == 0) atomicOr(&state[2], 1u);  // ell exhausted buckets in a row below the read: not modelled
+            continue;
+        }
+        u1 = max(u1, c0);
+        const int32_t anchor = u1 - 1;
+        const bool has_anchor = anchor >= c0;
+        const int32_t base = has_anchor ? anchor : c0;  // replayed buckets [base, t) keep time-resolved counts in s_cur
+        auto wave_sum_S = [&](int32_t lo, int32_t hi) {  // final counts of buckets [lo, hi)
+            int32_t acc = 0;
+            for (int32_t u = lo + lane; u < hi; u += 64) acc += S(u);
+            return (int32_t)wave_sum_u32((uint32_t)acc);
+        };
+        // From here on every lane runs the same scalar program on the staged arrays (writes of one value to one
+        // address by all lanes): the window is kept as two running sums -- `fixed`, the final counts of the buckets
+        // below the replayed ones, and `repl`, the replayed buckets' counts so far -- and the replayed buckets that
+        // still offer members as a stack (a bucket enters once, at its own time, and leaves when it is used up).
+        int32_t repl = 0, n_stack = 0;
+        if (has_anchor) {
+            const int32_t d = need(anchor) - wave_sum_S(max(anchor - ell + 1, 0), anchor);
+            repl = min(max(d, 0), C(anchor));
+            s_cur[0] = repl;
+            s_stack[n_stack++] = anchor;  // (never used up: that is what makes it the anchor)
+        }
+        int32_t fixed = wave_sum_S(max(u1 - ell + 1, 0), base);
+        int32_t avail = 0;   // what the regular members of the buckets (b, t] still offer
+        unsigned long long key = kNuNoKey;
+        for (int32_t t = u1; t <= e; ++t) {
+            int32_t d = max(need(t) - fixed - repl, 0);
+            const int32_t ct = C(t);
+            if (t > b) avail += ct;
+            if (t >= s && d > avail) {
+                // earlier time first, then the larger end, the larger start (the index is settled by k_nu_select)
+                key = ((unsigned long long)(uint32_t)t << 18) | ((unsigned long long)(511 - (e - t)) << 9) |
+                      (unsigned long long)(t - s);
+                break;
+            }
+            avail -= min(d, avail);
+            if (ct > 0 && n_stack < kNuCur) s_stack[n_stack++] = t;
+            while (d > 0 && n_stack > 0) {  // top-down through what the replayed buckets still offer
+                const int32_t u = s_stack[n_stack - 1];
+                const int32_t have = C(u) - s_cur[u - base];
+                const int32_t k = min(d, have);
+                s_cur[u - base] += k;
+                repl += k;
+                d -= k;
+                if (k == have) --n_stack;
+            }
+            if (t >= s && !exhausted(t)) break;  // bucket t keeps members for good: x is never reached later
+            // the window moves on: bucket t - ell + 1 leaves it
+            const int32_t out = t - ell + 1;
+            if (out >= base) repl -= s_cur[out - base];
+            else if (out >= 0) fixed -= S(out);
+        }
+        if (lane == 0) {
+            x.key[i] = key;
+            if (key != kNuNoKey) atomicMin(&viol_key[contig], key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
+                                                        uint32_t* __restrict__ viol_idx, uint32_t* __restrict__ sweep_from_next,
+                                                        uint32_t n_contigs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { state[1] = 0; state[4] = 0; }
+    if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
+}
+__global__ __launch_bounds__(256) void k_nu_select(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                   const uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
+                                                   uint32_t* __restrict__ viol_idx) {
+    const uint32_t n_sus = min(state[4], suspects_cap);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+        const uint2 su = suspects[q];
+        const unsigned long long k = x.key[su.x];
+        if (k != kNuNoKey && k == viol_key[su.y]) atomicMin(&viol_idx[su.y], x.idx[su.x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_nu_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                  uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
+                                                  const uint32_t* __restrict__ viol_idx, int32_t* __restrict__ nadj,
+                                                  const uint64_t* __restrict__ poff, uint32_t ell,
+                                                  uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
+    const uint32_t n_sus = min(state[4], suspects_cap);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+        const uint2 su = suspects[q];
+        const unsigned long long k = x.key[su.x];
+        if (k == kNuNoKey || k != viol_key[su.y] || x.idx[su.x] != viol_idx[su.y]) continue;
+        const uint32_t t = (uint32_t)(k >> 18), e = x.ge[su.x];
+        x.pick[su.x] = t;
+        for (uint32_t p = t; p <= e; ++p) nadj[p] -= 1;  // (one exception per contig and round: no two writers meet)
+        // the next sweep of this contig: what happens from t on changes buckets above t - ell only, so the state
+        // entering the block two before t's is still the chain's (the chain keeps it at every 64th block)
+        const uint32_t kt = (t - (uint32_t)poff[su.y]) / ell;
+        sweep_from[su.y] = (kt >= 2u ? kt - 2u : 0u) & ~63u;
+        atomicAdd(&state[1], 1u);
+        atomicAdd(&state[3], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long long* __restrict__ mask, uint32_t mask_bit0,
+                                                          unsigned long long* __restrict__ kept_total) {
+    const uint32_t n = nu_count(x);
+    uint32_t kept = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (x.pick[i] == kNuUnpicked) continue;
+        const uint64_t bit = (uint64_t)x.idx[i] + mask_bit0;
+        atomicOr(&mask[bit >> 6], 1ull << (bit & 63));
+        ++kept;
+    }
+    kept = wave_sum_u32(kept);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(kept_total, (unsigned long long)kept);
+}
+
+// ---- launchers.  Device layout of the route's own buffers (all sized by the host):
+//   exc      5 * cap words + 2 * cap words: gs, ge, idx (written by k_pm_prepare_sort), pick, then key (64-bit, cap entries)
+//   state    8 words: [1] exceptions selected this round, [2] give-up flags, [3] selected in all, [4] suspects
+static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, const uint32_t* count) {
+    NuExc x;
+    x.gs = exc; x.ge = exc + cap; x.idx = exc + 2 * (size_t)cap; x.pick = exc + 3 * (size_t)cap;
+    x.key = reinterpret_cast<unsigned long long*>(exc + 4 * (size_t)cap);
+    x.count = count; x.cap = cap;
+    return x;
+}
+size_t nu_exc_bytes(uint32_t cap) { return (size_t)cap * 6 * sizeof(uint32_t) + 16; }
+void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out) {
+    hipLaunchKernelGGL(k_nu_count_span, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, span, out);
+}
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                     const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
+                     uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state) {
+    const NuExc x = nu_exc_view(exc, cap, count);
+    (void)hipMemsetAsync(ce, 0, ((size_t)ltot + 3) * sizeof(uint32_t), st);
+    (void)hipMemsetAsync(state, 0, 8 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_nu_exc_diff, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, ce);
+    launch_exclusive_scan(st, ce, ltot + 2, ce, spine, false);
+    hipLaunchKernelGGL(k_nu_need_adjust, dim3(grid_for((uint64_t)ltot + 1, 256)), dim3(256), 0, st, boff, ce, ltot, ell, M, nadj);
+    hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
+}
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
+                     uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
+                     unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next) {
+    const NuExc x = nu_exc_view(exc, cap, count);
+    NuView v;
+    v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
+    hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs);
+    hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
+                       swept_from);
+    hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key);
+    hipLaunchKernelGGL(k_nu_select, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx);
+    hipLaunchKernelGGL(k_nu_apply, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx, nadj, d_poff, ell,
+                       sweep_from_next);
+}
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                             unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total) {
+    const NuExc x = nu_exc_view(exc, cap, count);
+    hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, mask, mask_bit0, kept_total);
+}

@@ -30,7 +30,8 @@ static constexpr int kPmThreads = 512;           // 8 waves: wave w owns records
 static constexpr int kPmWaves = kPmThreads / 64;
 static constexpr int kPmPassesPerWg = 4;         // a workgroup's passes leave their table entries as 16-byte runs
 static constexpr uint32_t kPmMaxRow = 3072;      // passes of a range's row the consumers hold in LDS (2 x 12 KiB): 25 M reads over the contigs a range overlaps
-static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256) * sizeof(uint32_t);
+static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + 4) * sizeof(uint32_t);
+static constexpr uint32_t kPmExcPerPass = kPmPass / 3;  // exception records ({start, end, index}) a pass can stage
 
 #ifndef QMCP_PM_MIN_WAVES
 #define QMCP_PM_MIN_WAVES 4  // waves per SIMD the register allocation aims at (6 -- three workgroups per CU -- spills: 0.42 against 0.29 ms)
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     const uint64_t* __restrict__ contig_read_off, const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs,
     uint32_t shift, uint16_t* __restrict__ keys16, uint16_t* __restrict__ idx16,
     uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ lst_tab, uint32_t pitch /* multiple of 4 */,
-    uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask) {
+    uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask,
+    // near-uniform route (kernels/near_uniform.inc.hip): reads whose span is not ell_reg are left out of the sorted
+    // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words, in any
+    // order; stats[4] counts them (beyond exc_cap they are counted, not listed).  ell_reg == 0: every read is regular.
+    uint32_t ell_reg, uint32_t* __restrict__ exc, uint32_t exc_cap) {
     extern __shared__ uint32_t s_pm[];
     uint32_t* s_stage = s_pm;                           // [8192] a pass's records, sorted: key | index in pass << 16
     uint32_t* s_cnt = s_stage + kPmPass;                // [8][256] per-wave digit counts, then offsets
@@ -48,6 +53,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* s_wave = s_gbase + 256;                   // [16]
     uint32_t* s_tabc = s_wave + 16;                     // [4][256] the workgroup's table entries
     uint32_t* s_tabl = s_tabc + kPmPassesPerWg * 256;   // [4][256]
+    uint32_t* s_xc = s_tabl + kPmPassesPerWg * 256;     // [2] exceptions of the pass (staged in s_stage), their place in the list
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
     auto contig_of = [&](uint32_t i) {
@@ -58,6 +64,8 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         }
         return lo;
     };
+    if (threadIdx.x == 0) s_xc[0] = 0;
+    __syncthreads();
     for (int g = 0; g < kPmPassesPerWg; ++g) {
         const uint32_t P = blockIdx.x * kPmPassesPerWg + g;
         const uint64_t base64 = (uint64_t)P * kPmPass;
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             match_bits = d_hi >= d_lo ? 32u - (uint32_t)__builtin_clz((d_hi - d_lo) | 1u) : 8u;
             if (d_hi == d_lo) match_bits = 0;
         }
+        uint32_t skip = 0;  // bit k: the thread's k-th read is an exception (near-uniform route)
         // validate, span range, global start (a start beyond its contig -- the call fails -- is taken as the
         // contig's last position, so that its digit lies inside the pass's digit interval)
         if (c_first == c_last) {
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                     const uint32_t span = e - s + 1;
                     mn = min(mn, span);
                     mx = max(mx, span);
+                    if (ell_reg != 0u && span != ell_reg) { skip |= 1u << k; rec[k].val = p0 + min(e, last); }
                 }
                 rec[k].key = p0 + min(s, last);
             }
@@ -121,27 +131,64 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                     mn = min(mn, span);
                     mx = max(mx, span);
                     rec[k].key = p0 + min(s, len ? len - 1u : 0u);
+                    if (ell_reg != 0u && span != ell_reg) { skip |= 1u << k; rec[k].val = p0 + min(e, len ? len - 1u : 0u); }
                 }
             }
         }
-        __syncthreads();  // (counters cleared)
+        if (ell_reg != 0u) {
+            // the pass's exceptions: staged in s_stage (free until the sorted records are placed), one LDS counter
+            // update per wave and round that has any; one update of the list's global counter per pass, below
+#pragma unroll
+            for (int k = 0; k < kSortItems; ++k) {
+                const bool isx = (skip >> k) & 1u;
+                const uint64_t m = __ballot(isx);
+                if (m != 0ull) {  // (uniform)
+                    const int first = __ffsll((long long)m) - 1;
+                    uint32_t slot0 = 0;
+                    if (lane == first) slot0 = atomicAdd(&s_xc[0], (uint32_t)__popcll(m));
+                    slot0 = (uint32_t)__builtin_amdgcn_readlane((int)slot0, first);
+                    const uint32_t slot = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (isx && slot < kPmExcPerPass) {
+                        s_stage[3u * slot] = rec[k].key;
+                        s_stage[3u * slot + 1u] = rec[k].val;
+                        s_stage[3u * slot + 2u] = wbase + k * 64 + lane;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // (counters cleared; the pass's exceptions are staged)
+        if (ell_reg != 0u && threadIdx.x == 0) {
+            const uint32_t cnt = s_xc[0];
+            s_xc[1] = cnt ? atomicAdd(&stats[4], cnt) : 0u;
+            if (cnt > kPmExcPerPass) atomicOr(&stats[5], 1u);  // more than a pass can stage: the list is incomplete
+        }
         uint32_t rank[kSortItems];
         {
             uint32_t* const s_cnt_w = s_cnt + w * 256;
             const uint32_t bound = base + count;
             switch (match_bits) {  // uniform
-                case 0: part_rank_rounds<0>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 1: part_rank_rounds<1>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 2: part_rank_rounds<2>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 3: part_rank_rounds<3>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 4: part_rank_rounds<4>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 5: part_rank_rounds<5>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 6: part_rank_rounds<6>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                case 7: part_rank_rounds<7>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-                default: part_rank_rounds<8>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+                case 0: part_rank_rounds<0>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 1: part_rank_rounds<1>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 2: part_rank_rounds<2>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 3: part_rank_rounds<3>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 4: part_rank_rounds<4>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 5: part_rank_rounds<5>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 6: part_rank_rounds<6>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                case 7: part_rank_rounds<7>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+                default: part_rank_rounds<8>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
             }
         }
         __syncthreads();
+        if (ell_reg != 0u) {
+            const uint32_t cnt = min(s_xc[0], kPmExcPerPass), base_x = s_xc[1];
+            for (uint32_t r = threadIdx.x; r < cnt; r += kPmThreads) {
+                if (base_x + r < exc_cap) {
+                    exc[base_x + r] = s_stage[3u * r];
+                    exc[exc_cap + base_x + r] = s_stage[3u * r + 1u];
+                    exc[2 * (size_t)exc_cap + base_x + r] = s_stage[3u * r + 2u];
+                }
+            }
+        }
         if (threadIdx.x < 256) {
             // digit d = threadIdx.x: its total over the waves, then (below) where it begins inside the pass
             const uint32_t d = threadIdx.x;
@@ -168,7 +215,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
 #pragma unroll
         for (int k = 0; k < kSortItems; ++k) {
             const uint32_t i = wbase + k * 64 + lane;
-            if (i < n) {
+            if (i < n && !((skip >> k) & 1u)) {
                 const uint32_t d = (rec[k].key >> shift) & 255u;
                 const uint32_t local = (uint32_t)(w * (kSortItems * 64) + k * 64 + lane);  // < 8192
                 s_stage[s_cnt[w * 256 + d] + rank[k]] = (rec[k].key & ((1u << shift) - 1u)) | (local << 16);
@@ -186,6 +233,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                 *reinterpret_cast<uint32_t*>(idx16 + (size_t)P * kPmStride + j) = (v0 >> 16) | (v1 & 0xFFFF0000u);
             }
         }
+        if (threadIdx.x == 0) s_xc[0] = 0;
         __syncthreads();  // (the next pass clears the counters and re-fills the stage)
     }
     __syncthreads();
@@ -221,9 +269,10 @@ __global__ __launch_bounds__(256) void k_pm_range_table(const uint32_t* __restri
     __shared__ uint32_t s_red[4];
     const uint32_t d = threadIdx.x;
     const uint32_t lo = T[(size_t)d * pitch];
-    const uint32_t hi = d + 1 < 256 ? T[(size_t)(d + 1) * pitch] : n;
-    range_start[d] = lo;
-    if (d == 255) range_start[256] = n;
+    const uint32_t hi = T[(size_t)(d + 1) * pitch];  // (d == 255: the scan's total -- the records listed, which the
+    range_start[d] = lo;                             //  near-uniform route makes fewer than the call's reads)
+    if (d == 255) range_start[256] = hi;
+    (void)n;
     const uint32_t m = wave_max_u32(hi - lo);
     if ((d & 63) == 0) s_red[d >> 6] = m;
     __syncthreads();
@@ -411,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
     uint32_t* const s_T = reinterpret_cast<uint32_t*>(s_q) + width + 1;
     uint32_t* const s_L = s_T + kPmMaxRow + 1;
     const uint32_t lo = T[(size_t)range * pitch];
-    const uint32_t hi = range + 1 < 256 ? T[(size_t)(range + 1) * pitch] : n;
+    const uint32_t hi = T[(size_t)(range + 1) * pitch];  // (range 255: the scan's total)
     if (lo >= hi) return;  // uniform: a range without reads needs no quotas either
     const uint32_t p_lo = rows[range], p_hi = rows[256 + range];
     const uint32_t n_rel = min(p_hi - p_lo, kPmMaxRow);
@@ -622,12 +671,14 @@ uint32_t pm_pass() { return (uint32_t)kPmPass; }
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
-                            uint32_t* stats, unsigned long long* zero_mask) {
+                            uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg, uint32_t* exc,
+                            uint32_t exc_cap) {
     const uint32_t pitch = pm_pitch(n);
     if (pitch == 0) return;
     (void)hipFuncSetAttribute((const void*)k_pm_prepare_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPmSortLds);
     hipLaunchKernelGGL(k_pm_prepare_sort, dim3(pitch / kPmPassesPerWg), dim3(kPmThreads), kPmSortLds, st, starts, ends, n,
-                       d_roff, d_poff, n_contigs, shift, keys16, idx16, cnt_tab, lst_tab, pitch, stats, zero_mask);
+                       d_roff, d_poff, n_contigs, shift, keys16, idx16, cnt_tab, lst_tab, pitch, stats, zero_mask,
+                       exc != nullptr ? ell_reg : 0u, exc, exc_cap);
 }
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load) {
     hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, T, pm_pitch(n), n, range_start, max_load);

@@ -55,11 +55,12 @@ struct SegTables {                   // device tables of the two-level route (25
 template <int BITS>
 __device__ __forceinline__ void part_rank_rounds(const Rec (&rec)[kSortItems], uint32_t (&rank)[kSortItems],
                                                  uint32_t wbase, uint32_t bound, uint32_t shift, int lane,
-                                                 uint32_t* __restrict__ s_cnt_w /* the wave's 256 counters */) {
+                                                 uint32_t* __restrict__ s_cnt_w /* the wave's 256 counters */,
+                                                 uint32_t skip = 0 /* bit k: leave the lane's k-th record out */) {
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
-        const bool valid = i < bound;
+        const bool valid = i < bound && !((skip >> k) & 1u);
         const uint32_t d = (rec[k].key >> shift) & 255u;
         const uint64_t v = __ballot(valid);
         uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ contig_pos_off, uint32_t n_wg,
                                                     uint32_t ell, uint32_t M, uint32_t ltot,
                                                     const uint32_t* __restrict__ seg, uint32_t n_pieces_max,
-                                                    uint32_t* __restrict__ pk) {
+                                                    uint32_t* __restrict__ pk,
+                                                    const int32_t* __restrict__ nadj /* near-uniform route: need(p) += nadj[p]; else null */) {
     using P = EvPack<E>;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -123,6 +124,10 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
             word |= min(c, P::kSat) << (r * P::kW);
             // need(p) == need(p - 1) == M
             if (i < ell) deep = deep && (X[r + 1] - Pv[r + 1] >= M) && (X[r] - Pv[r] >= M);
+            if (nadj != nullptr && i < ell) {
+                const uint32_t p = min(p0 + r, ltot);
+                deep = deep && nadj[p] == 0 && nadj[p > 0 ? p - 1 : 0u] == 0;
+            }
         }
         const bool inside = (uint64_t)(k + 1) * ell <= g.L;
         const bool plain = k != 0 && k < g.n_blocks && inside && __all(deep);
@@ -194,7 +199,13 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
                                                          uint32_t* __restrict__ sev,      // ltot + 8: S of changed blocks
                                                          uint32_t* __restrict__ lastns,   // per block: last changed block <= it
                                                          uint32_t* __restrict__ iter_stats,
-                                                         const uint32_t* __restrict__ seg) {
+                                                         const uint32_t* __restrict__ seg,
+                                                         const int32_t* __restrict__ nadj /* see k_sweep_pack */,
+                                                         // near-uniform route: the chain's state entering every 64th block
+                                                         // is kept (512 words each), and a later sweep of the same stretch
+                                                         // may start from one of them: restart[stretch] = first block to
+                                                         // sweep (a multiple of 64; beyond the stretch: nothing to do)
+                                                         uint32_t* __restrict__ ckpt, const uint32_t* __restrict__ restart) {
     using P = EvPack<E>;
     extern __shared__ uint4 s_evring[];
     // two waves: wave 1 only moves pieces into the LDS ring (an LDS-DMA request costs its issuer ~96
@@ -209,23 +220,27 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
     if (!ev_geom(contig_pos_off, seg, blockIdx.x, ell, gm)) return;
     const uint32_t base = gm.base, L = gm.L, Lrun = gm.Lrun, n_blocks = gm.n_blocks;
     const uint32_t n_pieces = (n_blocks + 3) / 4;
+    const uint32_t k0 = restart != nullptr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)restart[blockIdx.x]) & ~63u : 0u;
+    if (k0 >= n_blocks && restart != nullptr) return;  // (uniform: both waves)
+    const uint32_t q0 = k0 / 4;  // first piece to sweep
+    uint32_t* const my_ckpt = ckpt != nullptr ? ckpt + ((size_t)(gm.piece_base / 16) + 2u * blockIdx.x) * 512u : nullptr;
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pk) + (size_t)gm.piece_base * 64 + lane;
     uint32_t* __restrict__ my_last = lastns + (size_t)gm.piece_base * 4;
     const uint32_t ring0 = (uint32_t)(uintptr_t)s_evring;
-    if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+    if (threadIdx.x == 0) { s_ctl[0] = q0; s_ctl[1] = q0; }
     __syncthreads();
     if (wv == 1) {
         // LOADER: keeps the ring full.  A slot is reused once the chain has said it read the piece in it;
         // "landed" is published 32 requests behind the issue point (counted wait).
         __builtin_amdgcn_s_setprio(1);
-        uint32_t read_seen = 0;
-        for (uint32_t idx = 0; idx < n_pieces; ++idx) {
+        uint32_t read_seen = q0;
+        for (uint32_t idx = q0; idx < n_pieces; ++idx) {
             while (idx - read_seen >= kEvSlots) {
                 read_seen = s_ctl[1];
                 if (idx - read_seen >= kEvSlots) __builtin_amdgcn_s_sleep(2);
             }
             ev_glds16(src + (size_t)idx * 64, ring0 + (idx % kEvSlots) * 1024u);
-            if ((idx & 3) == 3 && idx >= 32) {
+            if ((idx & 3) == 3 && idx >= q0 + 32) {
                 asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
                 if (lane == 0) s_ctl[0] = idx + 1 - 32;
             }
@@ -260,6 +275,16 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
     }
     uint32_t last_ns = 0, n_changed = 0;
     uint32_t lastv = 0;  // lane j: last changed block at or before block (current group of 64) + j
+    if (k0 != 0) {
+        // the state an earlier sweep of this stretch had when it entered block k0
+        const uint32_t* ck = my_ckpt + (size_t)(k0 / 64) * 512u + lane * 8u;
+        gp = 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) { g[r] = ck[r]; gp |= g[r] << (r * P::kW); }
+        cprevw = ck[4];
+        last_ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck[5]);
+        lastv = last_ns;
+    }
 
 #ifdef QMCP_EV_STAMP
     unsigned long long st_gen = 0, st_slow = 0, st_wait = 0;
@@ -268,7 +293,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
 #endif
     // pieces [0, landed) are in the ring; the chain looks at the ring's progress word only when it has
     // caught up with what it last saw there
-    uint32_t landed = 0;
+    uint32_t landed = q0;
     auto wait_for = [&](uint32_t upto) {  // pieces [0, min(upto, n_pieces)) have landed
         const uint32_t want = min(upto, n_pieces);
 #ifdef QMCP_EV_STAMP
@@ -282,10 +307,10 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         st_wait += __builtin_amdgcn_s_memtime() - w0;
 #endif
     };
-    wait_for(4);
+    wait_for(q0 + 4);
     uint4 cur[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = s_evring[i * 64 + lane];
+    for (int i = 0; i < 4; ++i) cur[i] = s_evring[((q0 + i) % kEvSlots) * 64 + lane];
 
     // the block's kept counts S[] become the profile; they and the block's index are recorded
     auto commit = [&](uint32_t k, const uint32_t (&S)[E], uint32_t cword) {
@@ -367,11 +392,15 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
                 const uint32_t a1 = boff[min(p + 1, ltot)], a0 = boff[p];
                 const uint32_t b1 = boff[p + 1 >= ell ? p + 1 - ell : 0u];  // (<= ltot: p <= ltot, ell >= 1)
                 const uint32_t b0 = boff[p >= ell ? p - ell : 0u];
-                const uint32_t need_p = min(a1 - b1, M);
-                uint32_t need_m = min(a0 - b0, M);
+                int32_t need_p = (int32_t)min(a1 - b1, M);
+                int32_t need_m = (int32_t)min(a0 - b0, M);
+                if (nadj != nullptr) {
+                    need_p += nadj[min(p, ltot)];
+                    need_m += nadj[p > 0 ? p - 1 : 0u];
+                }
                 if (pos == 0 && contig_start) need_m = 0;
                 c[r] = valid ? a1 - a0 : 0u;
-                dn[r] = valid ? (int32_t)need_p - (int32_t)need_m : 0;
+                dn[r] = valid ? need_p - need_m : 0;
                 kill[r] = !valid;
             }
         } else {
@@ -382,7 +411,8 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         for (uint32_t round = 0; round < 4096; ++round) {  // (bounded: every round hands back at least one more read)
             int32_t d[E];
 #pragma unroll
-            for (int r = 0; r < E; ++r) d[r] = kill[r] ? 0 : (int32_t)g[r] + dn[r];
+            for (int r = 0; r < E; ++r) d[r] = kill[r] ? 0 : max((int32_t)g[r] + dn[r], 0);  // (never negative for a true need;
+                                                                                              //  the near-uniform route's trial sweeps may ask)
             const uint32_t e = ev_block_step<E>(d, c, lane, S);
             if (e == pushed) break;
             // hand e - pushed more back into the block before: top-down through its free room
@@ -461,7 +491,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
 
     // four pieces (sixteen blocks) per round; the next four are read from the ring meanwhile
     auto piece_and = [&](const uint4& w) { return ((w.x - gp) & (w.y - gp)) & ((w.z - gp) & (w.w - gp)); };
-    for (uint32_t q = 0; q < n_pieces; q += 4) {
+    for (uint32_t q = q0; q < n_pieces; q += 4) {
         if (landed < q + 8) wait_for(q + 8);  // pieces q + 4 .. q + 7 are in the ring
         uint4 nxt[4];
 #pragma unroll
@@ -485,6 +515,14 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
             const uint32_t kb = (q >> 4) * 64 + lane;
             if (kb < n_blocks) my_last[kb] = lastv;
             lastv = last_ns;
+            if (my_ckpt != nullptr && (q & 15) == 12) {
+                // the state entering block 64 (q / 16 + 1)
+                uint32_t* ck = my_ckpt + (size_t)((q >> 4) + 1u) * 512u + lane * 8u;
+#pragma unroll
+                for (int r = 0; r < E; ++r) ck[r] = g[r];
+                ck[4] = cprevw;
+                ck[5] = last_ns;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) cur[i] = nxt[i];

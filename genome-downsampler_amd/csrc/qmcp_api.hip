@@ -76,6 +76,7 @@ struct SolveRun {
     bool ranked_counted = false, wait_empty = false;
     bool pm = false;                    // range-ranked route in its pass-major form (kernels/pass_major.inc.hip)
     uint32_t range_shift = 0;
+    uint32_t nu_filter = 0;             // near-uniform route: the span the head's producer treated as regular (0: every read)
     // a contig group whose tail was queued on the FIRST group's statistics (no host wait of its own): what was
     // assumed, checked against the group's own read-back when the solve is collected
     bool speculated = false, assumed_ranked = false;
@@ -101,6 +102,11 @@ struct qmcp_hip_ctx {
     DevBuf pm_ccur;    // pass-major form: wave 0's slice cursor at every 1024-record chunk of every range
     DevBuf pm_rows;    // ... and every range's row of passes [p_lo, p_hi) (2 x 256 words), from the host
     uint32_t* h_pm_rows = nullptr;  // pinned staging of the same
+    // near-uniform route (kernels/near_uniform.inc.hip): the dominant span of the last call that took it -- the next
+    // call's head filters on it at once -- and the route's buffers
+    uint32_t nu_ell = 0;
+    DevBuf nu_exc, nu_nadj, nu_ce, nu_state, nu_sus, nu_ckpt;
+    uint32_t* h_nu = nullptr;       // pinned landing zone of the route's state words (8)
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;
     unsigned long long* h_scalars = nullptr;  // pinned landing zone of the solve's result scalars (4 words)
@@ -552,6 +558,23 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     return QMCP_OK;
 }
 
+// Near-uniform route: sizes.  Exceptions beyond a sixteenth of the reads are not worth the route (every one the sweep
+// wants costs a sweep of its own); the list holds that many.
+constexpr uint32_t kNuSuspects = 1u << 16;
+constexpr uint32_t kNuMaxRounds = 24;
+constexpr double kNuMinDepth = 6.0;  // mean coverage / M below which too many exceptions are wanted for the route to pay
+uint32_t nu_cap_for(uint32_t n) { return ((n >> 4) + 4096u) & ~1u; }
+int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
+    TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
+    TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
+    TRY(ensure(c, c->nu_ce, ((size_t)ltot + 4) * sizeof(uint32_t)));
+    TRY(ensure(c, c->nu_state, 64 + (size_t)n_contigs * 20 + 16));
+    TRY(ensure(c, c->nu_sus, (size_t)kNuSuspects * 8));
+    TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries(ltot + 2) + 1) * sizeof(uint32_t) + 16));
+    if (!c->h_nu) HIP_TRY(hipHostMalloc((void**)&c->h_nu, 8 * sizeof(uint32_t), hipHostMallocDefault));
+    return QMCP_OK;
+}
+
 // The pass-major form of the range-ranked route keeps, per range, the row of the passes that can hold its records
 // in LDS: those of the contigs whose positions overlap the range (kernels/pass_major.inc.hip: pm_relevant_passes,
 // restated here on the host's tables).  True if no row is longer than the kernels' share of LDS.
@@ -649,7 +672,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
-        TRY(ensure(c, c->stats, 4 * sizeof(uint32_t)));
+        TRY(ensure(c, c->stats, 8 * sizeof(uint32_t)));
+        if (c->nu_ell != 0) TRY(ensure_near_uniform(c, n, ltot, n_contigs));
         // The mixed-span route's own arrays.  Which route a call takes is known only after its first kernel,
         // so a context that has taken the mixed route once sizes them for every later call up front: growing
         // them after the partition has been queued would stall on it (ensure() waits for the streams).
@@ -694,9 +718,11 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         // start positions on this route -- the partition rebuilds them from the starts.
         run.have_gstart = false;
         hipStream_t s1 = c->stream;
-        const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+        static const uint32_t init[8] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
         run.pm = !two_level && pm_rows_fit(roff, pr, range_shift, c->h_pm_rows);
+        run.nu_filter = run.pm && !c->is_kid ? c->nu_ell : 0u;
+        hs[5] = hs[6] = 0;
         if (run.pm) {
             HIP_TRY(hipMemcpyAsync(c->pm_rows.p, c->h_pm_rows, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s1));
             // One pass over the reads: validate, statistics, mask clear, and every pass of 8 192 reads sorted by range
@@ -707,7 +733,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
                 qmcp::launch_pm_prepare_sort(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
                                              n_contigs, range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
                                              (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->stats.p,
-                                             mask_cleared ? nullptr : (unsigned long long*)d_mask);
+                                             mask_cleared ? nullptr : (unsigned long long*)d_mask,
+                                             run.nu_filter, run.nu_filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n));
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
@@ -774,6 +801,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         HIP_TRY(hipMemcpyAsync(hs, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
         HIP_TRY(hipMemcpyAsync(hs + 3, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
+        if (run.nu_filter) HIP_TRY(hipMemcpyAsync(hs + 5, (uint32_t*)c->stats.p + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
         // How spiky the starts are only decides WHICH exact sweep kernel runs, so the count of the previous
         // call of this shape is good enough (and saves waiting for k_range_offsets); a first call waits.
         if (c->spiky_known && c->spiky_n == n64 && c->spiky_ltot == pr.ltot) {
@@ -785,6 +813,175 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         run.ranked_counted = true;
     }
     run.head_done = true;
+    return QMCP_OK;
+}
+
+// The pass-major head's stages once more on `st` -- producer (regular reads: span == filter, or every read when
+// filter == 0), scan, range table, bucket offsets -- for a call whose head ran with the wrong idea of the spans.
+int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
+    SolveRun& run = c->run;
+    const uint32_t n = (uint32_t)run.pr.n, ltot = (uint32_t)run.pr.ltot, n_contigs = run.n_contigs;
+    uint32_t* d_stats = (uint32_t*)c->stats.p;
+    static const uint32_t zeros[3] = {0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(d_stats + 3, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));  // empty positions, exceptions, overflow
+    uint32_t* d_range_start = (uint32_t*)c->ranges.p;
+    uint32_t* d_max_load = d_range_start + 65540;
+    {
+        KernelSpan sp(c, "k_pm_prepare_sort");
+        qmcp::launch_pm_prepare_sort(st, run.d_starts, run.d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
+                                     n_contigs, run.range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
+                                     (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, d_stats,
+                                     run.mask_cleared ? nullptr : (unsigned long long*)run.d_mask, filter,
+                                     filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n));
+    }
+    {
+        KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+        qmcp::launch_exclusive_scan(st, (const uint32_t*)c->hist2.p, 256u * qmcp::pm_pitch(n), (uint32_t*)c->hist2.p,
+                                    (uint32_t*)c->spine2.p, true);
+        qmcp::launch_pm_range_table(st, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
+    }
+    {
+        KernelSpan sp(c, "k_pm_offsets");
+        qmcp::launch_pm_offsets(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n,
+                                (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, (uint32_t*)c->boff.p, d_stats + 3);
+    }
+    HIP_TRY(hipGetLastError());
+    run.nu_filter = filter;
+    return QMCP_OK;
+}
+
+// The near-uniform route's half of the tail (kernels/near_uniform.inc.hip).  Called when the call's spans differ.
+// done = true: the keep mask is written (sweep, ranking and the selected exceptions); false: the caller takes the
+// mixed-span route (nothing has touched the mask).  The head's producer may already have filtered on c->nu_ell
+// (run.nu_filter); otherwise the reads are counted first and, if the longest span is the dominant one, the head's
+// stages are queued again with the filter on.
+int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uint32_t max_load, uint32_t* d_iters, bool& done) {
+    done = false;
+    SolveRun& run = c->run;
+    const Problem& pr = run.pr;
+    qmcp_hip_stats& local = run.local;
+    const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot, n_contigs = run.n_contigs, M = run.M;
+    if (const char* e = std::getenv("QMCP_HIP_NEAR"))
+        if (e[0] == '0') return QMCP_OK;
+    const uint32_t ell = max_span;
+    const double depth = (double)n * (double)ell / ((double)ltot * (double)(M ? M : 1));
+    const bool dbg = std::getenv("QMCP_HIP_NEAR_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[near] pm %d may_rank %d kid %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
+                     (int)run.may_rank, (int)c->is_kid, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
+    if (!run.pm || !run.may_rank || c->is_kid || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
+        depth < kNuMinDepth || min_span == 0)
+        return QMCP_OK;
+    hipStream_t st = c->stream;
+    const uint32_t cap = nu_cap_for(n);
+    uint32_t n_exc = 0;
+    uint32_t* d_stats = (uint32_t*)c->stats.p;
+    if (run.nu_filter == ell) {
+        n_exc = c->h_head[5];  // (read back beside the statistics)
+        if (c->h_head[6] != 0) { c->nu_ell = 0; return QMCP_OK; }  // a pass held more exceptions than it can stage
+    } else {
+        // how many reads have the longest span?  (one pass over the spans; the host waits for the count)
+        TRY(ensure_near_uniform(c, n, ltot, n_contigs));
+        HIP_TRY(hipMemsetAsync(d_stats + 6, 0, sizeof(uint32_t), st));
+        qmcp::launch_nu_count_span(st, run.d_starts, run.d_ends, n, ell, d_stats + 6);
+        HIP_TRY(hipMemcpyAsync(c->h_nu, d_stats + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_exc = n - c->h_nu[0];
+        if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
+        if (n_exc > cap - 4096u) { c->nu_ell = 0; return QMCP_OK; }
+        // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
+        c->nu_ell = ell;
+        TRY(queue_pm_head(c, st, ell));
+        uint32_t* d_max_load = (uint32_t*)c->ranges.p + 65540;
+        HIP_TRY(hipMemcpyAsync(c->h_nu, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(c->h_nu + 1, d_stats + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        max_load = c->h_nu[0];
+        if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; return QMCP_OK; }  // (a pass held more than it can stage)
+    }
+    local.near_uniform_exceptions = n_exc;
+    if (n_exc == 0 || n_exc > cap - 4096u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
+        if (n_exc > cap - 4096u) c->nu_ell = 0;
+        return QMCP_OK;
+    }
+    // scratch of the event-driven sweep (launch_uniform_sweep)
+    TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ell, n_contigs + 768)));
+    TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ell, n_contigs + 768)));
+    const uint32_t* boff = (const uint32_t*)c->boff.p;
+    const uint64_t* poff = (const uint64_t*)c->poff.p;
+    uint32_t* selend = (uint32_t*)c->selend.p;
+    uint32_t* exc = (uint32_t*)c->nu_exc.p;
+    const uint32_t* d_count = d_stats + 4;
+    int32_t* nadj = (int32_t*)c->nu_nadj.p;
+    uint32_t* state = (uint32_t*)c->nu_state.p;
+    unsigned long long* viol_key = (unsigned long long*)((char*)c->nu_state.p + 64);
+    uint32_t* viol_idx = (uint32_t*)(viol_key + n_contigs);
+    uint32_t* sweep_from[2] = {viol_idx + n_contigs, viol_idx + 2 * (size_t)n_contigs};  // this round's, the next round's
+    TRY(ensure(c, c->nu_ckpt, qmcp::sweep_ev_ckpt_bytes(ltot, ell, n_contigs + 768)));
+    HIP_TRY(hipMemsetAsync(sweep_from[0], 0, (size_t)n_contigs * sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], st));
+    HIP_TRY(hipEventRecord(c->ev[EV_SORT], st));
+    {
+        KernelSpan sp(c, "near-uniform setup (exception coverage, need, pre-selection)");
+        qmcp::launch_nu_setup(st, exc, cap, d_count, n_exc, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
+                              nadj, state);
+    }
+    uint32_t rounds = 0;
+    bool settled = false;
+    while (rounds < kNuMaxRounds) {
+        ++rounds;
+        {
+            KernelSpan sp(c, "k_sweep_pack", st);
+            qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (uint32_t*)c->evpk.p, nadj);
+        }
+        {
+            KernelSpan sp(c, "k_sweep_uniform_ev", st);
+            qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->evpk.p,
+                                        (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p, d_iters, nadj, (uint32_t*)c->nu_ckpt.p,
+                                        sweep_from[0]);
+        }
+        {
+            KernelSpan sp(c, "k_sweep_expand", st);
+            qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->cstart.p,
+                                         (const uint32_t*)c->evlast.p, selend);
+        }
+        {
+            KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
+            qmcp::launch_nu_round(st, exc, cap, d_count, n_exc, boff, selend, nadj, poff, n_contigs, ell, M,
+                                  (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
+            std::swap(sweep_from[0], sweep_from[1]);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_nu, state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (dbg) {
+            fprintf(stderr, "[near] round %u: selected %u, flags %u, selected in all %u, suspects %u; next sweeps from block", rounds,
+                    c->h_nu[1], c->h_nu[2], c->h_nu[3], c->h_nu[4]);
+            std::vector<uint32_t> from(n_contigs);
+            (void)hipMemcpy(from.data(), sweep_from[0], (size_t)n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            for (uint32_t k = 0; k < n_contigs && k < 16; ++k) fprintf(stderr, " %d", (int)from[k]);
+            fprintf(stderr, "\n");
+        }
+        if (c->h_nu[2] != 0) break;                   // a run the replay does not model, or too many suspects
+        if (c->h_nu[1] == 0) { settled = true; break; }  // no exception is wanted: the sweep's counts are the greedy's
+    }
+    local.near_uniform_rounds = rounds;
+    local.near_uniform_selected = c->h_nu[3];
+    if (!settled) return QMCP_OK;
+    HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], st));
+    {
+        KernelSpan sp(c, "k_pm_rank_mark");
+        qmcp::launch_pm_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p, (const uint32_t*)c->hist2.p,
+                                  (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, boff, selend,
+                                  (unsigned long long*)run.d_mask, (unsigned long long*)c->scalars.p, c->rankamb.p,
+                                  qmcp::rank_scratch_by_records(run.range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
+    }
+    {
+        KernelSpan sp(c, "k_nu_mark_selected");
+        qmcp::launch_nu_mark_selected(st, exc, cap, d_count, n_exc, (unsigned long long*)run.d_mask, run.mask_bit0,
+                                      (unsigned long long*)c->scalars.p);
+    }
+    HIP_TRY(hipGetLastError());
+    done = true;
     return QMCP_OK;
 }
 
@@ -862,7 +1059,28 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
                             n_contigs, (uint32_t*)c->vals[1].p);
         have_gstart = true;
     };
-    if (!uniform) {
+    bool sweep_done = false, ranked = false;
+    uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
+    bool near_done = false;
+    uint32_t max_load_now = max_load;
+    if (uniform && run.nu_filter != 0 && run.nu_filter != max_span) {
+        // the head listed every read as an exception to the last call's span: its stages again, unfiltered
+        c->nu_ell = 0;
+        TRY(queue_pm_head(c, c->stream, 0));
+        HIP_TRY(hipMemcpyAsync(c->h_nu, (uint32_t*)c->ranges.p + 65540, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        max_load_now = c->h_nu[0];
+    }
+    if (!uniform && !speculate && max_span <= qmcp::kMaxUniformSpan) {
+        HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
+        TRY(near_uniform_tail(c, min_span, max_span, max_load, d_iters, near_done));
+        if (near_done) {
+            local.path = QMCP_PATH_NEAR_UNIFORM;
+            sweep_done = ranked = true;
+            run.assumed_ranked = true;
+        }
+    }
+    if (!uniform && !near_done) {
         need_gstart();
         span_bits = bit_width(max_span - min_span);
         wide = pos_bits + span_bits > 32;
@@ -880,17 +1098,15 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         TRY(scan_counts(c, c->ecnt, c->eoff, ltot));
         d_key32 = (const uint32_t*)c->vals[0].p;
     }
-    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
+    if (!near_done) HIP_TRY(hipEventRecord(c->ev[EV_SCAN], c->stream));
     // Uniform span, large call: neither the sweep nor the keep mask needs a full sort.  One stable
     // partition of {start, index} records by position range, per-range LDS counts, the sweep, and
     // a per-range ordered ranking against S(p) -- see "range-ranked uniform path" in the kernels.
     // The heaviest range's load is read back on the second stream while the partition runs; if
     // one range holds too much (its ranking is one wave's serial walk), the keep mask comes from
     // the radix sort instead (the counts and the sweep done here stay valid).
-    bool sweep_done = false, ranked = false;
-    uint32_t* d_iters = (uint32_t*)((char*)c->scalars.p + 16);
     bool mixed_whole_contigs = false;
-    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
+    if (!near_done) HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
     if (uniform && may_rank) {
         hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
         HIP_TRY(hipGetLastError());
@@ -899,7 +1115,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
         sweep_done = true;
-        ranked = (uint64_t)max_load * kRankBalance <= (uint64_t)n;
+        ranked = (uint64_t)max_load_now * kRankBalance <= (uint64_t)n;
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
         run.assumed_ranked = ranked;
         if (ranked && run.pm) {
@@ -1570,7 +1786,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->pm_rows, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->pm_rows, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -1591,6 +1807,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_go) (void)hipEventDestroy(c->ev_go);
     if (c->h_head) (void)hipHostFree(c->h_head);
     if (c->h_pm_rows) (void)hipHostFree(c->h_pm_rows);
+    if (c->h_nu) (void)hipHostFree(c->h_nu);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) c->stream = c->own_stream;  // (a group context's `stream` may stand for its parent's)
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -83,10 +83,13 @@ size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk);
+                          uint32_t* pk, const int32_t* nadj = nullptr);
 bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats);
+                           const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats,
+                           const int32_t* nadj = nullptr, uint32_t* ckpt = nullptr /* sweep_ev_ckpt_bytes */,
+                           const uint32_t* restart = nullptr /* per stretch: first block to sweep (multiple of 64) */);
+size_t sweep_ev_ckpt_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
                             const uint32_t* sev, const uint32_t* lastns, uint32_t* selend);
@@ -183,7 +186,8 @@ uint32_t pm_pass();                // reads per pass
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
-                            uint32_t* stats, unsigned long long* zero_mask);
+                            uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg = 0, uint32_t* exc = nullptr,
+                            uint32_t exc_cap = 0);
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load);
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
                        const uint32_t* rows /* [2][256]: first and one-past-last pass of every range's row */, uint32_t shift,
@@ -193,6 +197,22 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
                          const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
                          uint32_t* chunk_cursor, uint32_t mask_bit0);
+
+
+// near-uniform route (kernels/near_uniform.inc.hip): one dominant span, a few shorter reads as listed exceptions
+size_t nu_exc_bytes(uint32_t cap);  // the exception list: start, end, index (k_pm_prepare_sort), selection time, event key
+void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out);
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                     const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
+                     uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state /* 8 words */);
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
+                     uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
+                     unsigned long long* viol_key, uint32_t* viol_idx,
+                     const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,
+                     uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */);
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+                             unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total);
 
 }  // namespace qmcp
 #endif

@@ -28,6 +28,8 @@
 //   mark_and_next_rows       keep-mask emission for the sort-based routes, coverage probes, FILTER,
 //                            pair compaction / completion
 //   launchers                host-side launch wrappers declared in qmcp_kernels.h
+//   near_uniform             one dominant span + a few shorter reads: the one-span sweep over the regular reads, the
+//                            exceptions verified against it and selected one event at a time (included last)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,5 +58,6 @@ static constexpr uint32_t kInf = 0x40000000u;
 #include "kernels/mark_and_next_rows.inc.hip"
 #include "kernels/launchers.inc.hip"
 #include "kernels/pass_major.inc.hip"
+#include "kernels/near_uniform.inc.hip"
 
 }  // namespace qmcp

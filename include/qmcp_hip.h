@@ -58,7 +58,9 @@ enum {
 enum {
     QMCP_PATH_NONE = 0,
     QMCP_PATH_UNIFORM = 1, /* all reads of the call have one span: block-parallel sweep            */
-    QMCP_PATH_GENERAL = 2  /* mixed spans: event-driven priority sweep                             */
+    QMCP_PATH_GENERAL = 2, /* mixed spans: event-driven priority sweep                             */
+    QMCP_PATH_NEAR_UNIFORM = 3 /* one dominant span and a few shorter reads on deep data: the one-span sweep
+                                  over the regular reads, the others selected as verified exceptions       */
 };
 
 /* Opaque solver context: owns one HIP stream and a reusable device arena.  Mirrors the
@@ -102,6 +104,10 @@ typedef struct qmcp_hip_stats {
                                  next groups' bandwidth-bound stages)                                 */
     uint32_t arena_grown_mid_solve; /* device buffers that had to grow after the solve's first launch (a
                                  stall on queued work); 0 from the second call of a shape on         */
+    uint32_t near_uniform_exceptions; /* QMCP_PATH_NEAR_UNIFORM (also when the route was tried and given up for
+                                 the mixed-span one): reads shorter than the dominant span            */
+    uint32_t near_uniform_selected;   /* ... of those, kept                                              */
+    uint32_t near_uniform_rounds;     /* ... sweeps it took (1 = no exception was wanted by the sweep)   */
 } qmcp_hip_stats;
 
 int qmcp_hip_abi_version(void);

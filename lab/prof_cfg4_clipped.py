@@ -24,3 +24,4 @@ st = sv.last_stats.as_dict()
 print("clipped fraction", frac, "ms_total %.2f" % st["ms_total"], "path", st["path"], "spans", st["min_span"], st["max_span"], "stretches", st["sweep_stretches"])
 for name, (n, ms) in sorted(sv.kernel_times().items(), key=lambda kv: -kv[1][1]):
     print("   %-45s %3d x %9.4f ms" % (name, n, ms / n))
+print({k: st[k] for k in ("near_uniform_exceptions", "near_uniform_rounds", "near_uniform_selected", "ms_prepare", "ms_scan", "ms_sort", "ms_sweep", "ms_mark")})

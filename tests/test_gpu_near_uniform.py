@@ -1,0 +1,127 @@
+"""The near-uniform route (csrc/kernels/near_uniform.inc.hip): deep calls whose reads have one dominant span and a
+small share of shorter ones (soft clips, insertions -- BamApi takes a read's span from its CIGAR,
+libs/bam-api/src/read.cpp:11-13) keep the one-span machinery: the shorter reads are listed as exceptions, the sweep
+runs over the regular reads, and every exception the greedy would take is found from the sweep's counts and selected,
+one event per contig and round.  The keep mask must be the oracle's bit for bit whichever route a call ends on;
+tests/test_near_uniform_model.py checks the scheme itself on the CPU."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(rng, n, L, span, fraction, max_clip, longer=0):
+    s = rng.integers(0, L - span + 1, size=n).astype(np.int64)
+    e = s + span - 1
+    pick = rng.random(n) < fraction
+    clip = rng.integers(1, max_clip + 1, size=n)
+    front = rng.random(n) < 0.5
+    s = np.where(pick & front, s + clip, s)
+    e = np.where(pick & ~front, e - clip, e)
+    if longer:
+        j = rng.choice(n, size=longer, replace=False)
+        ok = e[j] + 2 < L
+        e[j[ok]] += 2
+    return s.astype(np.uint32), e.astype(np.uint32)
+
+
+def _contigs(rng, lengths, counts, span, fraction, max_clip, longer=0):
+    ss, ee = [], []
+    for L, k in zip(lengths, counts):
+        a, b = _reads(rng, int(k), int(L), span, fraction, max_clip, longer)
+        ss.append(a); ee.append(b)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    return np.concatenate(ss), np.concatenate(ee), offs
+
+
+CASES = [
+    # lengths, reads per contig, span, M, fraction, max clip
+    ([60_000], [500_000], 150, 100, 0.01, 50),
+    ([40_000, 25_000, 70_001, 12_345], [330_000, 210_000, 580_000, 100_000], 150, 100, 0.02, 50),
+    ([50_000], [400_000], 100, 60, 0.01, 99),           # clips down to one base
+    ([80_000, 80_000], [420_000, 900_000], 151, 64, 0.03, 20),   # one contig twice as deep as the other
+    ([30_000, 30_000, 30_000], [260_000, 0, 260_000], 150, 100, 0.005, 30),   # a contig without reads
+]
+
+
+@pytest.mark.parametrize("lengths,counts,span,M,fraction,max_clip", CASES)
+def test_near_uniform_equals_the_oracle(pkg, oracle, solver, lengths, counts, span, M, fraction, max_clip):
+    rng = np.random.default_rng(sum(counts) % 9973 + span)
+    lengths = np.array(lengths, np.uint32)
+    s, e, offs = _contigs(rng, lengths, counts, span, fraction, max_clip)
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    st = solver.last_stats
+    want = oracle.solve(s, e, lengths, M, offs)
+    assert np.array_equal(got, want), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM, st.as_dict()
+    assert st.near_uniform_exceptions == int(((e - s + 1) != span).sum())
+    assert st.near_uniform_rounds >= 1 and st.n_kept == int(sum(bin(int(w)).count("1") for w in want))
+    # the same call again: the head filters on the remembered span at once -- same mask
+    again = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    assert np.array_equal(again, want) and solver.last_stats.path == pkg.PATH_NEAR_UNIFORM
+
+
+def test_route_switches_between_calls(pkg, oracle, solver):
+    """near-uniform, then one span that differs from the remembered one (the filtered head listed every read as an
+    exception: its stages run again), then the remembered span with no exception at all, then a mix without a dominant
+    span -- every mask the oracle's"""
+    rng = np.random.default_rng(5)
+    L, n = 50_000, 400_000
+    lengths = np.array([L], np.uint32)
+    s, e, _ = _contigs(rng, [L], [n], 150, 0.01, 40)
+    assert np.array_equal(solver.solve(s, e, lengths, 100), oracle.solve(s, e, lengths, 100))
+    assert solver.last_stats.path == pkg.PATH_NEAR_UNIFORM
+    s2, e2, _ = _contigs(rng, [L], [n], 120, 0.0, 1)
+    assert np.array_equal(solver.solve(s2, e2, lengths, 100), oracle.solve(s2, e2, lengths, 100))
+    assert solver.last_stats.path == pkg.PATH_UNIFORM
+    assert np.array_equal(solver.solve(s, e, lengths, 100), oracle.solve(s, e, lengths, 100))
+    assert solver.last_stats.path == pkg.PATH_NEAR_UNIFORM
+    s3, e3, _ = _contigs(rng, [L], [n], 150, 0.0, 1)
+    assert np.array_equal(solver.solve(s3, e3, lengths, 100), oracle.solve(s3, e3, lengths, 100))
+    assert solver.last_stats.path == pkg.PATH_UNIFORM
+    span = rng.integers(100, 151, size=n)
+    s4 = rng.integers(0, L - 150, size=n).astype(np.uint32)
+    e4 = (s4 + span - 1).astype(np.uint32)
+    assert np.array_equal(solver.solve(s4, e4, lengths, 100), oracle.solve(s4, e4, lengths, 100))
+    assert solver.last_stats.path == pkg.PATH_GENERAL
+
+
+def test_gives_way_to_the_mixed_route(pkg, oracle, solver):
+    """what the route does not model goes the mixed-span way, same mask: reads LONGER than the dominant span, more
+    exceptions than a sixteenth of the reads, data too shallow for it"""
+    rng = np.random.default_rng(11)
+    L, n = 40_000, 330_000
+    lengths = np.array([L], np.uint32)
+    for kwargs, M in ((dict(fraction=0.01, max_clip=30, longer=5), 100), (dict(fraction=0.2, max_clip=30), 100),
+                      (dict(fraction=0.01, max_clip=30), 400)):
+        s, e, _ = _contigs(rng, [L], [n], 150, **kwargs)
+        got = solver.solve(s, e, lengths, M)
+        assert np.array_equal(got, oracle.solve(s, e, lengths, M)), (kwargs, M, solver.last_stats.as_dict())
+        assert solver.last_stats.path == pkg.PATH_GENERAL, (kwargs, M, solver.last_stats.as_dict())
+
+
+def test_many_wanted_exceptions(pkg, oracle, solver):
+    """5 % exceptions at a moderate depth: dozens are wanted, one round each per contig -- or the route gives up
+    at its budget; either way the oracle's mask"""
+    rng = np.random.default_rng(17)
+    lengths = np.array([30_000, 30_000], np.uint32)
+    s, e, offs = _contigs(rng, lengths, [200_000, 200_000], 150, 0.05, 50)
+    got = solver.solve(s, e, lengths, 100, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 100, offs)), st.as_dict()
+    assert st.path in (pkg.PATH_NEAR_UNIFORM, pkg.PATH_GENERAL)
+
+
+def test_env_switch_off(pkg, oracle, solver):
+    rng = np.random.default_rng(23)
+    lengths = np.array([60_000], np.uint32)
+    s, e, _ = _contigs(rng, [60_000], [500_000], 150, 0.01, 50)
+    os.environ["QMCP_HIP_NEAR"] = "0"
+    try:
+        got = solver.solve(s, e, lengths, 100)
+    finally:
+        del os.environ["QMCP_HIP_NEAR"]
+    assert solver.last_stats.path == pkg.PATH_GENERAL
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 100))
