@@ -232,13 +232,13 @@ size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg) {
     }
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk, const int32_t* nadj) {
+                          uint32_t* pk, const int32_t* nadj, const uint32_t* from) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
 #define QMCP_CALL(EE)                                                                                      \
     hipLaunchKernelGGL(k_sweep_pack<EE>, dim3((pieces + 3) / 4), dim3(256), 0, st, boff, d_poff, n_wg, ell, \
-                       M, ltot, seg, pieces, pk, nadj);
+                       M, ltot, seg, pieces, pk, nadj, from);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;
@@ -261,13 +261,13 @@ bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t*
 }
 bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend) {
+                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend, const uint32_t* from) {
     if (!sweep_uniform_ev_supported(ell, M)) return false;
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t pieces = sweep_ev_pieces(ltot, ell, n_wg);
 #define QMCP_CALL(EE)                                                                                    \
     hipLaunchKernelGGL(k_sweep_expand<EE>, dim3(pieces), dim3(256), 0, st, boff, d_poff, n_wg, ell, ltot, \
-                       seg, pieces, sev, lastns, selend);
+                       seg, pieces, sev, lastns, selend, from);
     QMCP_EV_DISPATCH((ell + 63) / 64, QMCP_CALL)
 #undef QMCP_CALL
     return true;

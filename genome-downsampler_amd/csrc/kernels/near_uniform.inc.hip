@@ -32,11 +32,16 @@
 static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
 static constexpr unsigned long long kNuNoKey = ~0ull;
 
-struct NuExc {  // the exception list: three arrays of cap words + the route's own two
+struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 64
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
-    const uint32_t* count; uint32_t cap;
+    const uint32_t* cnt;   // how many of a group's slots hold an exception (k_pm_prepare_sort: one group per wave and pass)
+    uint32_t cap;
+    uint32_t* goff;        // exclusive scan of cnt
+    uint32_t* dense;       // the filled slots, in list order (what the per-round kernels walk)
+    uint32_t n_dense;      // how many there are (the host's count)
 };
-__device__ __forceinline__ uint32_t nu_count(const NuExc& x) { return min(*x.count, x.cap); }
+__device__ __forceinline__ uint32_t nu_count(const NuExc& x) { return x.cap; }
+__device__ __forceinline__ bool nu_valid(const NuExc& x, uint32_t i) { return (i & 63u) < x.cnt[i >> 6]; }
 
 __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
                                                        uint32_t n, uint32_t span, uint32_t* __restrict__ out) {
@@ -51,6 +56,9 @@ __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restric
 __global__ __launch_bounds__(256) void k_nu_exc_diff(NuExc x, uint32_t* __restrict__ diff) {
     const uint32_t n = nu_count(x);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!nu_valid(x, i)) continue;
+        const uint32_t at = x.goff[i >> 6] + (i & 63u);
+        if (at < x.n_dense) x.dense[at] = i;
         atomicAdd(&diff[x.gs[i]], 1u);
         atomicAdd(&diff[x.ge[i] + 1u], 0xFFFFFFFFu);
         x.pick[i] = kNuUnpicked;
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(256) void k_nu_prepick(NuExc x, const uint32_t* __r
                                                     uint32_t* __restrict__ state) {
     const uint32_t n = nu_count(x);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!nu_valid(x, i)) continue;
         const uint32_t s = x.gs[i], e = x.ge[i];
         if (nu_cov_regular(boff, s, ell) + ce[s + 1] <= M) {
             x.pick[i] = s;
@@ -110,8 +119,9 @@ __device__ __forceinline__ bool nu_exhausted(const NuView& v, int32_t u, int32_t
 __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                    uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ swept_from /* per contig: the first block this round swept */) {
-    const uint32_t n = nu_count(x);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (state[7] == 0u) return;  // (no contig was swept this round: every one is settled)
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
+        const uint32_t i = x.dense[j];
         if (x.pick[i] != kNuUnpicked) continue;
         const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
         const int32_t b = e - (int32_t)v.ell + 1;
@@ -233,9 +243,14 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
 
 __global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
                                                         uint32_t* __restrict__ viol_idx, uint32_t* __restrict__ sweep_from_next,
-                                                        uint32_t n_contigs) {
+                                                        uint32_t n_contigs, uint32_t first_round) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { state[1] = 0; state[4] = 0; }
+    if (i == 0) {
+        state[7] = first_round | state[1];  // contigs this round's sweep covered: those that selected in the round before
+        state[6] += state[1] != 0u ? 1u : 0u;  // rounds that selected something
+        state[1] = 0;
+        state[4] = 0;
+    }
     if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
 }
 __global__ __launch_bounds__(256) void k_nu_select(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
@@ -272,9 +287,9 @@ __global__ __launch_bounds__(256) void k_nu_apply(NuExc x, const uint2* __restri
 
 __global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long long* __restrict__ mask, uint32_t mask_bit0,
                                                           unsigned long long* __restrict__ kept_total) {
-    const uint32_t n = nu_count(x);
     uint32_t kept = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
+        const uint32_t i = x.dense[j];
         if (x.pick[i] == kNuUnpicked) continue;
         const uint64_t bit = (uint64_t)x.idx[i] + mask_bit0;
         atomicOr(&mask[bit >> 6], 1ull << (bit & 63));
@@ -285,47 +300,56 @@ __global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long
 }
 
 // ---- launchers.  Device layout of the route's own buffers (all sized by the host):
-//   exc      5 * cap words + 2 * cap words: gs, ge, idx (written by k_pm_prepare_sort), pick, then key (64-bit, cap entries)
-//   state    8 words: [1] exceptions selected this round, [2] give-up flags, [3] selected in all, [4] suspects
-static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, const uint32_t* count) {
+//   exc      gs, ge, idx (cap words each, written by k_pm_prepare_sort), pick (cap words), key (64-bit, cap entries), then the
+//            groups' counts (cap / 64 words, also the producer's)
+//   state    8 words: [1] exceptions selected this round, [2] give-up flags, [3] selected in all, [4] suspects,
+//            [6] earlier rounds that selected something
+static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense) {
     NuExc x;
     x.gs = exc; x.ge = exc + cap; x.idx = exc + 2 * (size_t)cap; x.pick = exc + 3 * (size_t)cap;
     x.key = reinterpret_cast<unsigned long long*>(exc + 4 * (size_t)cap);
-    x.count = count; x.cap = cap;
+    x.cnt = exc + 6 * (size_t)cap;
+    x.cap = cap;
+    x.goff = exc + 6 * (size_t)cap + cap / 64 + 4;
+    x.dense = x.goff + cap / 64 + 4;
+    x.n_dense = n_dense;
     return x;
 }
-size_t nu_exc_bytes(uint32_t cap) { return (size_t)cap * 6 * sizeof(uint32_t) + 16; }
+uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap) { return exc + 6 * (size_t)cap; }
+size_t nu_exc_bytes(uint32_t cap) { return ((size_t)cap * 7 + 2 * (cap / 64 + 4) + 8) * sizeof(uint32_t); }
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out) {
     hipLaunchKernelGGL(k_nu_count_span, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, span, out);
 }
-void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
                      const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
                      uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state) {
-    const NuExc x = nu_exc_view(exc, cap, count);
+    const NuExc x = nu_exc_view(exc, cap, n_exc);
     (void)hipMemsetAsync(ce, 0, ((size_t)ltot + 3) * sizeof(uint32_t), st);
     (void)hipMemsetAsync(state, 0, 8 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_nu_exc_diff, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, ce);
+    launch_exclusive_scan(st, x.cnt, cap / 64, x.goff, spine, false);
+    hipLaunchKernelGGL(k_nu_exc_diff, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, ce);
     launch_exclusive_scan(st, ce, ltot + 2, ce, spine, false);
     hipLaunchKernelGGL(k_nu_need_adjust, dim3(grid_for((uint64_t)ltot + 1, 256)), dim3(256), 0, st, boff, ce, ltot, ell, M, nadj);
-    hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
+    hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
 }
-void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next) {
-    const NuExc x = nu_exc_view(exc, cap, count);
+    const NuExc x = nu_exc_view(exc, cap, n_exc);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
-    hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs);
-    hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
+    hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs,
+                       first_round ? 1u : 0u);
+    hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from);
     hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key);
     hipLaunchKernelGGL(k_nu_select, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx);
     hipLaunchKernelGGL(k_nu_apply, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx, nadj, d_poff, ell,
                        sweep_from_next);
 }
-void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
                              unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total) {
-    const NuExc x = nu_exc_view(exc, cap, count);
-    hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(est_count ? est_count : 1, 256)), dim3(256), 0, st, x, mask, mask_bit0, kept_total);
+    const NuExc x = nu_exc_view(exc, cap, n_exc);
+    hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, mask, mask_bit0, kept_total);
 }

@@ -30,8 +30,8 @@ static constexpr int kPmThreads = 512;           // 8 waves: wave w owns records
 static constexpr int kPmWaves = kPmThreads / 64;
 static constexpr int kPmPassesPerWg = 4;         // a workgroup's passes leave their table entries as 16-byte runs
 static constexpr uint32_t kPmMaxRow = 3072;      // passes of a range's row the consumers hold in LDS (2 x 12 KiB): 25 M reads over the contigs a range overlaps
-static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + 4) * sizeof(uint32_t);
-static constexpr uint32_t kPmExcPerPass = kPmPass / 3;  // exception records ({start, end, index}) a pass can stage
+static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 64) * sizeof(uint32_t);
+static constexpr uint32_t kPmExcPerWave = 64;  // list slots per wave and pass: a sixteenth of the wave's 1 024 reads
 
 #ifndef QMCP_PM_MIN_WAVES
 #define QMCP_PM_MIN_WAVES 4  // waves per SIMD the register allocation aims at (6 -- three workgroups per CU -- spills: 0.42 against 0.29 ms)
@@ -43,9 +43,12 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ lst_tab, uint32_t pitch /* multiple of 4 */,
     uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask,
     // near-uniform route (kernels/near_uniform.inc.hip): reads whose span is not ell_reg are left out of the sorted
-    // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words, in any
-    // order; stats[4] counts them (beyond exc_cap they are counted, not listed).  ell_reg == 0: every read is regular.
-    uint32_t ell_reg, uint32_t* __restrict__ exc, uint32_t exc_cap) {
+    // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words.  Every wave
+    // of every pass owns kPmExcPerWave slots of the list (pass P, wave w: from (8 P + w) * 64) and says how many it
+    // filled in exc_cnt[8 P + w]: no counter is shared (24 k same-address atomics, one per wave, took longer than
+    // the whole kernel: 0.32 -> 0.69 ms); k_pm_count_exceptions adds the groups up into stats[4] afterwards.  stats[5]
+    // is set if a wave met more than its slots hold (the list is then incomplete).  ell_reg == 0: every read is regular.
+    uint32_t ell_reg, uint32_t* __restrict__ exc, uint32_t exc_cap, uint32_t* __restrict__ exc_cnt) {
     extern __shared__ uint32_t s_pm[];
     uint32_t* s_stage = s_pm;                           // [8192] a pass's records, sorted: key | index in pass << 16
     uint32_t* s_cnt = s_stage + kPmPass;                // [8][256] per-wave digit counts, then offsets
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* s_wave = s_gbase + 256;                   // [16]
     uint32_t* s_tabc = s_wave + 16;                     // [4][256] the workgroup's table entries
     uint32_t* s_tabl = s_tabc + kPmPassesPerWg * 256;   // [4][256]
-    uint32_t* s_xc = s_tabl + kPmPassesPerWg * 256;     // [2] exceptions of the pass (staged in s_stage), their place in the list
+    uint32_t* s_exc = s_tabl + kPmPassesPerWg * 256;    // [8][64][3] every wave's exceptions of the pass, until the pass is written out
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
     auto contig_of = [&](uint32_t i) {
@@ -64,13 +67,12 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         }
         return lo;
     };
-    if (threadIdx.x == 0) s_xc[0] = 0;
-    __syncthreads();
     for (int g = 0; g < kPmPassesPerWg; ++g) {
         const uint32_t P = blockIdx.x * kPmPassesPerWg + g;
         const uint64_t base64 = (uint64_t)P * kPmPass;
         if (base64 >= n) {  // (uniform) a pass beyond the reads: zero table entries, the scan runs over the padding too
             if (threadIdx.x < 256) { s_tabc[g * 256 + threadIdx.x] = 0; s_tabl[g * 256 + threadIdx.x] = 0; }
+            if (ell_reg != 0u && lane == 0 && P < pitch) exc_cnt[P * kPmWaves + w] = 0;
             continue;
         }
         const uint32_t base = (uint32_t)base64;
@@ -98,6 +100,25 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             if (d_hi == d_lo) match_bits = 0;
         }
         uint32_t skip = 0;  // bit k: the thread's k-th read is an exception (near-uniform route)
+        uint32_t filled = 0;  // (uniform) exceptions of the pass this wave has met
+        // An exception is put aside the moment it is recognised (its end is then dead: kept until later, the sixteen
+        // ends cost sixteen registers and the kernel spilled), in the wave's own corner of LDS, and goes to the list
+        // when the pass is written out -- a store to memory here would have to be drained at the next barrier.
+        // (an LDS-qualified pointer: through a generic one the three stores become flat_ stores, which wait for the
+        //  pass's thirty-two loads in flight -- 1 us per wave-round that holds an exception, 0.32 -> 0.69 ms)
+        typedef __attribute__((address_space(3))) uint32_t LdsWord;
+        LdsWord* const mine = (LdsWord*)(s_exc + w * (3 * kPmExcPerWave));
+        auto put_aside = [&, mine](int k, bool isx, uint32_t gs, uint32_t ge, uint32_t i) {
+            const uint64_t m = __ballot(isx);
+            if (m != 0ull) {  // (uniform)
+                const uint32_t slot = filled + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (isx) {
+                    skip |= 1u << k;
+                    if (slot < kPmExcPerWave) { mine[3u * slot] = gs; mine[3u * slot + 1u] = ge; mine[3u * slot + 2u] = i; }
+                }
+                filled += (uint32_t)__popcll(m);
+            }
+        };
         // validate, span range, global start (a start beyond its contig -- the call fails -- is taken as the
         // contig's last position, so that its digit lies inside the pass's digit interval)
         if (c_first == c_last) {
@@ -108,19 +129,23 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             for (int k = 0; k < kSortItems; ++k) {
                 const uint32_t i = wbase + k * 64 + lane;
                 const uint32_t s = rec[k].key, e = rec[k].val;
+                bool isx = false;
                 if (i < n) {
                     bad |= (s > e || e >= len) ? 1u : 0u;
                     const uint32_t span = e - s + 1;
                     mn = min(mn, span);
                     mx = max(mx, span);
-                    if (ell_reg != 0u && span != ell_reg) { skip |= 1u << k; rec[k].val = p0 + min(e, last); }
+                    isx = span != ell_reg;
                 }
                 rec[k].key = p0 + min(s, last);
+                if (ell_reg != 0u) put_aside(k, isx, rec[k].key, p0 + min(e, last), i);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < kSortItems; ++k) {
                 const uint32_t i = wbase + k * 64 + lane;
+                bool isx = false;
+                uint32_t ge = 0;
                 if (i < n) {
                     const uint32_t cc = contig_of(i);
                     const uint32_t p0 = (uint32_t)contig_pos_off[cc];
@@ -131,37 +156,13 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                     mn = min(mn, span);
                     mx = max(mx, span);
                     rec[k].key = p0 + min(s, len ? len - 1u : 0u);
-                    if (ell_reg != 0u && span != ell_reg) { skip |= 1u << k; rec[k].val = p0 + min(e, len ? len - 1u : 0u); }
+                    isx = span != ell_reg;
+                    ge = p0 + min(e, len ? len - 1u : 0u);
                 }
+                if (ell_reg != 0u) put_aside(k, isx, rec[k].key, ge, i);
             }
         }
-        if (ell_reg != 0u) {
-            // the pass's exceptions: staged in s_stage (free until the sorted records are placed), one LDS counter
-            // update per wave and round that has any; one update of the list's global counter per pass, below
-#pragma unroll
-            for (int k = 0; k < kSortItems; ++k) {
-                const bool isx = (skip >> k) & 1u;
-                const uint64_t m = __ballot(isx);
-                if (m != 0ull) {  // (uniform)
-                    const int first = __ffsll((long long)m) - 1;
-                    uint32_t slot0 = 0;
-                    if (lane == first) slot0 = atomicAdd(&s_xc[0], (uint32_t)__popcll(m));
-                    slot0 = (uint32_t)__builtin_amdgcn_readlane((int)slot0, first);
-                    const uint32_t slot = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (isx && slot < kPmExcPerPass) {
-                        s_stage[3u * slot] = rec[k].key;
-                        s_stage[3u * slot + 1u] = rec[k].val;
-                        s_stage[3u * slot + 2u] = wbase + k * 64 + lane;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // (counters cleared; the pass's exceptions are staged)
-        if (ell_reg != 0u && threadIdx.x == 0) {
-            const uint32_t cnt = s_xc[0];
-            s_xc[1] = cnt ? atomicAdd(&stats[4], cnt) : 0u;
-            if (cnt > kPmExcPerPass) atomicOr(&stats[5], 1u);  // more than a pass can stage: the list is incomplete
-        }
+        __syncthreads();  // (counters cleared)
         uint32_t rank[kSortItems];
         {
             uint32_t* const s_cnt_w = s_cnt + w * 256;
@@ -179,16 +180,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             }
         }
         __syncthreads();
-        if (ell_reg != 0u) {
-            const uint32_t cnt = min(s_xc[0], kPmExcPerPass), base_x = s_xc[1];
-            for (uint32_t r = threadIdx.x; r < cnt; r += kPmThreads) {
-                if (base_x + r < exc_cap) {
-                    exc[base_x + r] = s_stage[3u * r];
-                    exc[exc_cap + base_x + r] = s_stage[3u * r + 1u];
-                    exc[2 * (size_t)exc_cap + base_x + r] = s_stage[3u * r + 2u];
-                }
-            }
-        }
         if (threadIdx.x < 256) {
             // digit d = threadIdx.x: its total over the waves, then (below) where it begins inside the pass
             const uint32_t d = threadIdx.x;
@@ -233,7 +224,20 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                 *reinterpret_cast<uint32_t*>(idx16 + (size_t)P * kPmStride + j) = (v0 >> 16) | (v1 & 0xFFFF0000u);
             }
         }
-        if (threadIdx.x == 0) s_xc[0] = 0;
+#ifndef QMCP_LAB_NO_EXC_OUT
+        if (ell_reg != 0u) {
+            const size_t slot0 = ((size_t)P * kPmWaves + w) * kPmExcPerWave;
+            if ((uint32_t)lane < min(filled, kPmExcPerWave)) {
+                exc[slot0 + lane] = mine[3u * lane];
+                exc[exc_cap + slot0 + lane] = mine[3u * lane + 1u];
+                exc[2 * (size_t)exc_cap + slot0 + lane] = mine[3u * lane + 2u];
+            }
+            if (lane == 0) {
+                exc_cnt[P * kPmWaves + w] = min(filled, kPmExcPerWave);
+                if (filled > kPmExcPerWave) atomicOr(&stats[5], 1u);
+            }
+        }
+#endif
         __syncthreads();  // (the next pass clears the counters and re-fills the stage)
     }
     __syncthreads();
@@ -261,6 +265,15 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         if (mx > __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats[1], mx);
         if (bad) atomicOr(&stats[2], 1u);
     }
+}
+
+// stats[4] = exceptions listed (the sum of the groups' counts)
+__global__ __launch_bounds__(256) void k_pm_count_exceptions(const uint32_t* __restrict__ exc_cnt, uint32_t n_groups,
+                                                             uint32_t* __restrict__ stats) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += gridDim.x * blockDim.x) acc += exc_cnt[i];
+    acc = wave_sum_u32(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0u) atomicAdd(&stats[4], acc);
 }
 
 // where every range begins in flat coordinates (257 entries) and the heaviest range's load, from the scanned table
@@ -668,17 +681,20 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
 uint32_t pm_pitch(uint32_t n) { return part_pass_pitch(n); }  // passes of the call, rounded up to a multiple of 4
 uint32_t pm_max_row() { return kPmMaxRow; }
 uint32_t pm_pass() { return (uint32_t)kPmPass; }
+uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave; }  // the exception list's slots (64 per wave and pass)
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
                             uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg, uint32_t* exc,
-                            uint32_t exc_cap) {
+                            uint32_t exc_cap, uint32_t* exc_cnt) {
     const uint32_t pitch = pm_pitch(n);
     if (pitch == 0) return;
     (void)hipFuncSetAttribute((const void*)k_pm_prepare_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPmSortLds);
     hipLaunchKernelGGL(k_pm_prepare_sort, dim3(pitch / kPmPassesPerWg), dim3(kPmThreads), kPmSortLds, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, shift, keys16, idx16, cnt_tab, lst_tab, pitch, stats, zero_mask,
-                       exc != nullptr ? ell_reg : 0u, exc, exc_cap);
+                       exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
+    if (exc != nullptr && ell_reg != 0u)
+        hipLaunchKernelGGL(k_pm_count_exceptions, dim3(32), dim3(256), 0, st, exc_cnt, pitch * kPmWaves, stats);
 }
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load) {
     hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, T, pm_pitch(n), n, range_start, max_load);

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
                                                     uint32_t ell, uint32_t M, uint32_t ltot,
                                                     const uint32_t* __restrict__ seg, uint32_t n_pieces_max,
                                                     uint32_t* __restrict__ pk,
-                                                    const int32_t* __restrict__ nadj /* near-uniform route: need(p) += nadj[p]; else null */) {
+                                                    const int32_t* __restrict__ nadj /* near-uniform route: need(p) += nadj[p]; else null */,
+                                                    const uint32_t* __restrict__ from /* per stretch: first block the chain will sweep, or null */) {
     using P = EvPack<E>;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void k_sweep_pack(const uint32_t* __restrict__
     uint32_t idx;
     if (!ev_find(contig_pos_off, seg, n_wg, ell, w, g, idx)) return;
     const uint32_t q = w - g.piece_base;
+    if (from != nullptr && (uint64_t)4u * q + 3u < (uint64_t)from[idx]) return;  // (what changed lies at or beyond the chain's first block)
     uint32_t out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(256) void k_sweep_expand(const uint32_t* __restrict
                                                       uint32_t ell, uint32_t ltot, const uint32_t* __restrict__ seg,
                                                       uint32_t n_pieces_max, const uint32_t* __restrict__ sev,
                                                       const uint32_t* __restrict__ lastns,
-                                                      uint32_t* __restrict__ selend) {
+                                                      uint32_t* __restrict__ selend,
+                                                      const uint32_t* __restrict__ from /* per stretch: first block the chain swept, or null */) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t gb = blockIdx.x * 4 + (threadIdx.x >> 6);  // global block slot
     const uint32_t w = gb >> 2;
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(256) void k_sweep_expand(const uint32_t* __restrict
     if (!ev_find(contig_pos_off, seg, n_wg, ell, w, g, idx)) return;
     const uint32_t k = gb - 4 * g.piece_base;
     if (k >= g.n_blocks) return;
+    if (from != nullptr && (uint64_t)k + 1u < (uint64_t)from[idx]) return;  // (the chain's first block may hand back into the one before)
     const uint32_t kk = lastns[gb];
     const uint32_t back = (k - kk) * ell;
 #pragma unroll

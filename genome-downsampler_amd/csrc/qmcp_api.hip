@@ -563,7 +563,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
 constexpr uint32_t kNuSuspects = 1u << 16;
 constexpr uint32_t kNuMaxRounds = 24;
 constexpr double kNuMinDepth = 6.0;  // mean coverage / M below which too many exceptions are wanted for the route to pay
-uint32_t nu_cap_for(uint32_t n) { return ((n >> 4) + 4096u) & ~1u; }
+uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 64 slots per wave and pass: a sixteenth of the reads
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
     TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
@@ -673,7 +673,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         if (n >= rank_min_reads() && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
         TRY(ensure(c, c->stats, 8 * sizeof(uint32_t)));
-        if (c->nu_ell != 0) TRY(ensure_near_uniform(c, n, ltot, n_contigs));
+        // (the near-uniform route's buffers: a context that has met mixed spans may look at the route on any call)
+        if (c->nu_ell != 0 || c->mixed_seen) TRY(ensure_near_uniform(c, n, ltot, n_contigs));
         // The mixed-span route's own arrays.  Which route a call takes is known only after its first kernel,
         // so a context that has taken the mixed route once sizes them for every later call up front: growing
         // them after the partition has been queued would stall on it (ensure() waits for the streams).
@@ -734,7 +735,8 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
                                              n_contigs, range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
                                              (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->stats.p,
                                              mask_cleared ? nullptr : (unsigned long long*)d_mask,
-                                             run.nu_filter, run.nu_filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n));
+                                             run.nu_filter, run.nu_filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
+                                             run.nu_filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
@@ -832,7 +834,8 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
                                      n_contigs, run.range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
                                      (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, d_stats,
                                      run.mask_cleared ? nullptr : (unsigned long long*)run.d_mask, filter,
-                                     filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n));
+                                     filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
+                                     filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
     }
     {
         KernelSpan sp(c, "scan_radix_hist(3 kernels)");
@@ -887,7 +890,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         HIP_TRY(hipStreamSynchronize(st));
         n_exc = n - c->h_nu[0];
         if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
-        if (n_exc > cap - 4096u) { c->nu_ell = 0; return QMCP_OK; }
+        if (n_exc > n / 16u) { c->nu_ell = 0; return QMCP_OK; }
         // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
         c->nu_ell = ell;
         TRY(queue_pm_head(c, st, ell));
@@ -899,8 +902,8 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; return QMCP_OK; }  // (a pass held more than it can stage)
     }
     local.near_uniform_exceptions = n_exc;
-    if (n_exc == 0 || n_exc > cap - 4096u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
-        if (n_exc > cap - 4096u) c->nu_ell = 0;
+    if (n_exc == 0 || n_exc > n / 16u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
+        if (n_exc > n / 16u) c->nu_ell = 0;
         return QMCP_OK;
     }
     // scratch of the event-driven sweep (launch_uniform_sweep)
@@ -910,7 +913,6 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const uint64_t* poff = (const uint64_t*)c->poff.p;
     uint32_t* selend = (uint32_t*)c->selend.p;
     uint32_t* exc = (uint32_t*)c->nu_exc.p;
-    const uint32_t* d_count = d_stats + 4;
     int32_t* nadj = (int32_t*)c->nu_nadj.p;
     uint32_t* state = (uint32_t*)c->nu_state.p;
     unsigned long long* viol_key = (unsigned long long*)((char*)c->nu_state.p + 64);
@@ -922,48 +924,56 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     HIP_TRY(hipEventRecord(c->ev[EV_SORT], st));
     {
         KernelSpan sp(c, "near-uniform setup (exception coverage, need, pre-selection)");
-        qmcp::launch_nu_setup(st, exc, cap, d_count, n_exc, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
+        qmcp::launch_nu_setup(st, exc, cap, n_exc, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
                               nadj, state);
     }
+    // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
+    // all settled is eight launches that return at once (the chain sweeps nothing, the verification skips every
+    // exception: ~0.1 ms), about what one more host round trip costs; measured at cfg4 with 1 % clipped reads (7 rounds),
+    // batches of 1 / 2 / 2 + 4 + 4: 4.62 / 4.5 / 4.60 ms.
     uint32_t rounds = 0;
     bool settled = false;
-    while (rounds < kNuMaxRounds) {
-        ++rounds;
-        {
-            KernelSpan sp(c, "k_sweep_pack", st);
-            qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (uint32_t*)c->evpk.p, nadj);
-        }
-        {
-            KernelSpan sp(c, "k_sweep_uniform_ev", st);
-            qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->evpk.p,
-                                        (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p, d_iters, nadj, (uint32_t*)c->nu_ckpt.p,
-                                        sweep_from[0]);
-        }
-        {
-            KernelSpan sp(c, "k_sweep_expand", st);
-            qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->cstart.p,
-                                         (const uint32_t*)c->evlast.p, selend);
-        }
-        {
-            KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
-            qmcp::launch_nu_round(st, exc, cap, d_count, n_exc, boff, selend, nadj, poff, n_contigs, ell, M,
-                                  (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
-            std::swap(sweep_from[0], sweep_from[1]);
+    while (rounds < kNuMaxRounds && !settled) {
+        const uint32_t batch = 2u;
+        for (uint32_t r = 0; r < batch; ++r) {
+            ++rounds;
+            {
+                KernelSpan sp(c, "k_sweep_pack", st);
+                qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (uint32_t*)c->evpk.p, nadj, sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "k_sweep_uniform_ev", st);
+                qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->evpk.p,
+                                            (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p, d_iters, nadj, (uint32_t*)c->nu_ckpt.p,
+                                            sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "k_sweep_expand", st);
+                qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->cstart.p,
+                                             (const uint32_t*)c->evlast.p, selend, sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
+                qmcp::launch_nu_round(st, exc, cap, n_exc, rounds == 1, boff, selend, nadj, poff, n_contigs, ell, M,
+                                      (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
+                std::swap(sweep_from[0], sweep_from[1]);
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_nu, state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (dbg) {
-            fprintf(stderr, "[near] round %u: selected %u, flags %u, selected in all %u, suspects %u; next sweeps from block", rounds,
-                    c->h_nu[1], c->h_nu[2], c->h_nu[3], c->h_nu[4]);
+            fprintf(stderr, "[near] after %u rounds: last round selected %u, flags %u, selected in all %u, suspects %u, rounds that selected %u; next sweeps from block",
+                    rounds, c->h_nu[1], c->h_nu[2], c->h_nu[3], c->h_nu[4], c->h_nu[6]);
             std::vector<uint32_t> from(n_contigs);
             (void)hipMemcpy(from.data(), sweep_from[0], (size_t)n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost);
             for (uint32_t k = 0; k < n_contigs && k < 16; ++k) fprintf(stderr, " %d", (int)from[k]);
             fprintf(stderr, "\n");
         }
-        if (c->h_nu[2] != 0) break;                   // a run the replay does not model, or too many suspects
-        if (c->h_nu[1] == 0) { settled = true; break; }  // no exception is wanted: the sweep's counts are the greedy's
+        if (c->h_nu[2] != 0) break;          // a run the replay does not model, or too many suspects
+        settled = c->h_nu[1] == 0;           // the last round wanted no exception: the sweep's counts are the greedy's
     }
+    if (settled) rounds = c->h_nu[6] + 1;    // (the rounds that did something, and the one that found nothing left)
     local.near_uniform_rounds = rounds;
     local.near_uniform_selected = c->h_nu[3];
     if (!settled) return QMCP_OK;
@@ -977,7 +987,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     }
     {
         KernelSpan sp(c, "k_nu_mark_selected");
-        qmcp::launch_nu_mark_selected(st, exc, cap, d_count, n_exc, (unsigned long long*)run.d_mask, run.mask_bit0,
+        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, (unsigned long long*)run.d_mask, run.mask_bit0,
                                       (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());
@@ -1071,6 +1081,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         max_load_now = c->h_nu[0];
     }
+    if (!uniform) c->mixed_seen = true;
     if (!uniform && !speculate && max_span <= qmcp::kMaxUniformSpan) {
         HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
         TRY(near_uniform_tail(c, min_span, max_span, max_load, d_iters, near_done));

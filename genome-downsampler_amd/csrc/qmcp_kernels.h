@@ -83,7 +83,7 @@ size_t sweep_ev_pack_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 size_t sweep_ev_last_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 bool launch_sweep_ev_pack(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                           uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                          uint32_t* pk, const int32_t* nadj = nullptr);
+                          uint32_t* pk, const int32_t* nadj = nullptr, const uint32_t* from = nullptr);
 bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                            uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
                            const uint32_t* pk, uint32_t* sev, uint32_t* lastns, uint32_t* iter_stats,
@@ -92,7 +92,7 @@ bool launch_sweep_ev_chain(hipStream_t st, const uint32_t* boff, const uint64_t*
 size_t sweep_ev_ckpt_bytes(uint32_t ltot, uint32_t ell, uint32_t n_wg);
 bool launch_sweep_ev_expand(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t ell, uint32_t M, uint32_t ltot, const uint32_t* seg, uint32_t n_seg_max,
-                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend);
+                            const uint32_t* sev, const uint32_t* lastns, uint32_t* selend, const uint32_t* from = nullptr);
 bool launch_sweep_uniform(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                           uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                           uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
@@ -187,7 +187,8 @@ void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
                             uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg = 0, uint32_t* exc = nullptr,
-                            uint32_t exc_cap = 0);
+                            uint32_t exc_cap = 0, uint32_t* exc_cnt = nullptr);
+uint32_t pm_exc_slots(uint32_t n);  // slots of the near-uniform route's exception list (groups of 64, one per wave and pass)
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load);
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
                        const uint32_t* rows /* [2][256]: first and one-past-last pass of every range's row */, uint32_t shift,
@@ -200,18 +201,19 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
 
 
 // near-uniform route (kernels/near_uniform.inc.hip): one dominant span, a few shorter reads as listed exceptions
-size_t nu_exc_bytes(uint32_t cap);  // the exception list: start, end, index (k_pm_prepare_sort), selection time, event key
+size_t nu_exc_bytes(uint32_t cap);
+uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap);  // the groups' counts inside the list's buffer  // the exception list: start, end, index (k_pm_prepare_sort), selection time, event key, group counts
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out);
-void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
                      const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
                      uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state /* 8 words */);
-void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx,
                      const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,
                      uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */);
-void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, const uint32_t* count, uint32_t est_count,
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
                              unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total);
 
 }  // namespace qmcp

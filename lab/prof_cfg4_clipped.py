@@ -25,3 +25,13 @@ print("clipped fraction", frac, "ms_total %.2f" % st["ms_total"], "path", st["pa
 for name, (n, ms) in sorted(sv.kernel_times().items(), key=lambda kv: -kv[1][1]):
     print("   %-45s %3d x %9.4f ms" % (name, n, ms / n))
 print({k: st[k] for k in ("near_uniform_exceptions", "near_uniform_rounds", "near_uniform_selected", "ms_prepare", "ms_scan", "ms_sort", "ms_sweep", "ms_mark")})
+# the same reads, none clipped, through a head that still filters on the remembered span: what the filter itself costs
+S0 = np.concatenate(ss); E0 = np.concatenate(ee)
+dS.copy_(torch.from_numpy(S0.view(np.int32))); dE.copy_(torch.from_numpy(E0.view(np.int32)))
+sv.set_profiling(0)
+sv.solve_device(dS.data_ptr(), dE.data_ptr(), S0.size, lengths, 100, dM.data_ptr(), contig_read_offsets=offs)
+sv.set_profiling(1)
+sv.solve_device(dS.data_ptr(), dE.data_ptr(), S0.size, lengths, 100, dM.data_ptr(), contig_read_offsets=offs)
+print("one length, filtering head: ms_total %.3f path %d" % (sv.last_stats.ms_total, sv.last_stats.path))
+for name, (n, ms) in sorted(sv.kernel_times().items(), key=lambda kv: -kv[1][1])[:4]:
+    print("   %-45s %3d x %9.4f ms" % (name, n, ms / n))

@@ -112,7 +112,8 @@ def test_host_entry_sends_one_column_when_every_span_is_the_same(pkg, oracle, so
     e2 = e.copy()
     e2[-1] -= 5                                                          # the very last read is shorter
     assert np.array_equal(solver.solve(s, e2, L, M), oracle.solve(s, e2, L, M))
-    assert solver.last_stats.columns_sent == 2 and solver.last_stats.path == 2
+    # (one shorter read on deep data: the near-uniform route, or the mixed-span one -- not the one-span route)
+    assert solver.last_stats.columns_sent == 2 and solver.last_stats.path in (pkg.PATH_GENERAL, pkg.PATH_NEAR_UNIFORM)
     k = 1 << 19                                                          # below the threshold: both columns
     assert np.array_equal(solver.solve(s[:k], e[:k], L, M), oracle.solve(s[:k], e[:k], L, M))
     assert solver.last_stats.columns_sent == 2
