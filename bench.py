@@ -124,14 +124,27 @@ def clipped_configs(pkg, torch, dev, solver, stream, d_starts, d_ends, n_reads, 
     d_e = torch.from_numpy(e2.view(np.int32)).to(dev)
     d_m = torch.zeros(pkg.mask_words(n_reads), dtype=torch.int64, device=dev)
     ms = []
-    for _ in range(2):
+    for _ in range(3):
         st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n_reads, lengths, M, d_m.data_ptr(),
                                  contig_read_offsets=offs, stream=stream)
         ms.append(float(st.ms_total))
+    kept_near = int(st.n_kept)
     out["cfg4_1pct_clipped"] = {"device_ms": round(min(ms), 3), "path": int(st.path), "min_span": int(st.min_span),
                                 "max_span": int(st.max_span), "stretches": int(st.sweep_stretches),
-                                "kept": int(st.n_kept),
-                                "note": "cfg4 with 1 % of the reads shortened by 1...50 bases: mixed-span event sweep"}
+                                "kept": kept_near, "exceptions": int(st.near_uniform_exceptions),
+                                "exceptions_kept": int(st.near_uniform_selected), "sweeps": int(st.near_uniform_rounds),
+                                "note": "cfg4 with 1 % of the reads shortened by 1...50 bases: near-uniform route (path 3: "
+                                        "the one-span sweep over the regular reads, the short ones verified against it "
+                                        "and selected one event per contig and sweep); mixed_route_device_ms is the same "
+                                        "call on the mixed-span event sweep (QMCP_HIP_NEAR=0), same kept set"}
+    os.environ["QMCP_HIP_NEAR"] = "0"
+    try:
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n_reads, lengths, M, d_m.data_ptr(),
+                                 contig_read_offsets=offs, stream=stream)
+    finally:
+        del os.environ["QMCP_HIP_NEAR"]
+    out["cfg4_1pct_clipped"]["mixed_route_device_ms"] = round(float(st.ms_total), 3)
+    out["cfg4_1pct_clipped"]["mixed_route_kept"] = int(st.n_kept)
     del d_s, d_e, d_m
     # cfg3's shape: 30 M amplicon reads, one length vs 85 / 15 mix
     a, b, _, _, _ = synthetic.amplicon_reads(15_000_000)

@@ -24,7 +24,7 @@
 //     k_nu_replay       one wave per suspect: the sweep's time-resolved picks over the run of exhausted buckets
 //                       around s, rebuilt from final counts (below the run's anchor nothing is picked late), give the
 //                       first time the demand exceeds what the buckets above x still offer
-//     k_nu_select / k_nu_apply   per contig the earliest such event (highest priority first) is exact -- before it
+//     k_nu_select_apply          per contig the earliest such event (highest priority first) is exact -- before it
 //                       greedy and sweep agree -- so that exception is selected at that time: nadj -= 1 on [t, e] ]
 //   repeated until no exception is wanted; then k_pm_rank_mark for the regular reads and k_nu_mark_selected.
 // The host gives up (and takes the mixed-span route) when a suspect's run is longer than the window, when the loop
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             const int32_t ct = C(t);
             if (t > b) avail += ct;
             if (t >= s && d > avail) {
-                // earlier time first, then the larger end, the larger start (the index is settled by k_nu_select)
+                // earlier time first, then the larger end, the larger start (the index is settled by k_nu_select_apply)
                 key = ((unsigned long long)(uint32_t)t << 18) | ((unsigned long long)(511 - (e - t)) << 9) |
                       (unsigned long long)(t - s);
                 break;
@@ -253,26 +253,25 @@ __global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ s
     }
     if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
 }
-__global__ __launch_bounds__(256) void k_nu_select(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
-                                                   const uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
-                                                   uint32_t* __restrict__ viol_idx) {
+// One workgroup: per contig the winning event's smallest read index (suspects with the contig's earliest key), then the
+// winner is selected -- its time recorded, nadj lowered by one on [t, e], the contig's next sweep placed.
+__global__ __launch_bounds__(1024) void k_nu_select_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                          uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
+                                                          uint32_t* __restrict__ viol_idx, int32_t* __restrict__ nadj,
+                                                          const uint64_t* __restrict__ poff, uint32_t ell,
+                                                          uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
     const uint32_t n_sus = min(state[4], suspects_cap);
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+    for (uint32_t q = threadIdx.x; q < n_sus; q += blockDim.x) {
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
         if (k != kNuNoKey && k == viol_key[su.y]) atomicMin(&viol_idx[su.y], x.idx[su.x]);
     }
-}
-__global__ __launch_bounds__(256) void k_nu_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
-                                                  uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
-                                                  const uint32_t* __restrict__ viol_idx, int32_t* __restrict__ nadj,
-                                                  const uint64_t* __restrict__ poff, uint32_t ell,
-                                                  uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
-    const uint32_t n_sus = min(state[4], suspects_cap);
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < n_sus; q += blockDim.x) {
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
-        if (k == kNuNoKey || k != viol_key[su.y] || x.idx[su.x] != viol_idx[su.y]) continue;
+        if (k == kNuNoKey || k != viol_key[su.y]) continue;
+        if (x.idx[su.x] != __hip_atomic_load(&viol_idx[su.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
         const uint32_t t = (uint32_t)(k >> 18), e = x.ge[su.x];
         x.pick[su.x] = t;
         for (uint32_t p = t; p <= e; ++p) nadj[p] -= 1;  // (one exception per contig and round: no two writers meet)
@@ -344,8 +343,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from);
     hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key);
-    hipLaunchKernelGGL(k_nu_select, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx);
-    hipLaunchKernelGGL(k_nu_apply, dim3(16), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx, nadj, d_poff, ell,
+    hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx, nadj, d_poff, ell,
                        sweep_from_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
