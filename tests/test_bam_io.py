@@ -262,3 +262,42 @@ def test_inflating_on_several_threads_reads_the_same_file(tmp_path, monkeypatch)
     header, recs, _ = bam_py.parse(path)
     want, filtered = bam_py.pair_like_the_reference(recs)
     assert many["bam_ids"].tolist() == [r["bam_id"] for r in want] and many["filtered_out"].tolist() == filtered
+
+
+@pytest.mark.gpu
+def test_file_with_soft_clipped_reads_takes_the_near_uniform_route(tmp_path):
+    """a BAM as aligners write them -- one read length, a few per cent of the records soft-clipped (their reference
+    span is shorter: read.cpp:11-13) -- downsampled file to file: the output holds the oracle's kept pairs, and the
+    solve behind it ran on the near-uniform route (kernels/near_uniform.inc.hip), not the mixed-span walk"""
+    import oracle_py
+    pkg = importlib.import_module("genome-downsampler_amd")
+    rng = np.random.default_rng(31)
+    n_pairs, L, M = 100_000, 20_000, 100
+    n = 2 * n_pairs
+    names = np.repeat(np.arange(n_pairs), 2)
+    flags = np.where(np.tile([True, False], n_pairs), 0x41, 0x81).astype(np.uint16)
+    clip = np.where(rng.random(n) < 0.02, rng.integers(1, 40, size=n), 0)
+    match = 150 - clip                                   # 150-base reads: <clip>S<150 - clip>M
+    zeros = np.zeros(n, np.int64)
+    pos = rng.integers(0, L - 150, size=n)
+    mapq = rng.integers(20, 61, size=n)
+    order = rng.permutation(n)
+    cols = [a[order] for a in (names, flags, pos, mapq, clip, match, zeros, zeros)]
+    path = tmp_path / "clipped.bam"
+    pkg.write_synthetic_bam(path, L, *cols)
+    header, recs, _ = bam_py.parse(path)
+    reads = pkg.read_bam(path)
+    assert reads["starts"].size == n and int((reads["ends"] - reads["starts"] + 1 != 150).sum()) == int((clip > 0).sum())
+    out = tmp_path / "out.bam"
+    written = pkg.downsample_bam("quasi-mcp-hip", path, out, M)
+    keep = oracle_py.solve(reads["starts"], reads["ends"], L, M)
+    mask = oracle_py.find_pairs(keep, n)
+    kept_ids = np.sort(reads["bam_ids"][pkg.mask_to_indices(mask, n).astype(np.int64)])
+    oh, orecs, _ = bam_py.parse(out)
+    assert written == kept_ids.size == len(orecs) and oh == header
+    assert [r["raw"] for r in orecs] == [recs[i]["raw"] for i in kept_ids.tolist()]
+    with pkg.Solver(0) as sv:                            # the same columns through the C ABI: which route, which stats
+        got = sv.solve(reads["starts"], reads["ends"], L, M)
+        st = sv.last_stats
+    assert np.array_equal(got, keep)
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int((clip > 0).sum()), st.as_dict()
