@@ -32,7 +32,7 @@
 static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
 static constexpr unsigned long long kNuNoKey = ~0ull;
 
-struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 64
+struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 128
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
     const uint32_t* cnt;   // how many of a group's slots hold an exception (k_pm_prepare_sort: one group per wave and pass)
     uint32_t cap;
@@ -41,7 +41,8 @@ struct NuExc {  // the exception list: three arrays of cap slots + the route's o
     uint32_t n_dense;      // how many there are (the host's count)
 };
 __device__ __forceinline__ uint32_t nu_count(const NuExc& x) { return x.cap; }
-__device__ __forceinline__ bool nu_valid(const NuExc& x, uint32_t i) { return (i & 63u) < x.cnt[i >> 6]; }
+static constexpr uint32_t kNuGroup = kPmExcPerWave;  // slots per group (a power of two)
+__device__ __forceinline__ bool nu_valid(const NuExc& x, uint32_t i) { return (i & (kNuGroup - 1u)) < x.cnt[i / kNuGroup]; }
 
 __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
                                                        uint32_t n, uint32_t span, uint32_t* __restrict__ out) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_nu_exc_diff(NuExc x, uint32_t* __restri
     const uint32_t n = nu_count(x);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!nu_valid(x, i)) continue;
-        const uint32_t at = x.goff[i >> 6] + (i & 63u);
+        const uint32_t at = x.goff[i / kNuGroup] + (i & (kNuGroup - 1u));
         if (at < x.n_dense) x.dense[at] = i;
         atomicAdd(&diff[x.gs[i]], 1u);
         atomicAdd(&diff[x.ge[i] + 1u], 0xFFFFFFFFu);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long
 
 // ---- launchers.  Device layout of the route's own buffers (all sized by the host):
 //   exc      gs, ge, idx (cap words each, written by k_pm_prepare_sort), pick (cap words), key (64-bit, cap entries), then the
-//            groups' counts (cap / 64 words, also the producer's)
+//            groups' counts (cap / 128 words, also the producer's), their scan, and the filled slots' indices (cap words)
 //   state    8 words: [1] exceptions selected this round, [2] give-up flags, [3] selected in all, [4] suspects,
 //            [6] earlier rounds that selected something
 static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense) {
@@ -309,13 +310,13 @@ static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense) {
     x.key = reinterpret_cast<unsigned long long*>(exc + 4 * (size_t)cap);
     x.cnt = exc + 6 * (size_t)cap;
     x.cap = cap;
-    x.goff = exc + 6 * (size_t)cap + cap / 64 + 4;
-    x.dense = x.goff + cap / 64 + 4;
+    x.goff = exc + 6 * (size_t)cap + cap / kNuGroup + 4;
+    x.dense = x.goff + cap / kNuGroup + 4;
     x.n_dense = n_dense;
     return x;
 }
 uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap) { return exc + 6 * (size_t)cap; }
-size_t nu_exc_bytes(uint32_t cap) { return ((size_t)cap * 7 + 2 * (cap / 64 + 4) + 8) * sizeof(uint32_t); }
+size_t nu_exc_bytes(uint32_t cap) { return ((size_t)cap * 7 + 2 * (cap / kNuGroup + 4) + 8) * sizeof(uint32_t); }
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out) {
     hipLaunchKernelGGL(k_nu_count_span, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, span, out);
 }
@@ -325,7 +326,7 @@ void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     const NuExc x = nu_exc_view(exc, cap, n_exc);
     (void)hipMemsetAsync(ce, 0, ((size_t)ltot + 3) * sizeof(uint32_t), st);
     (void)hipMemsetAsync(state, 0, 8 * sizeof(uint32_t), st);
-    launch_exclusive_scan(st, x.cnt, cap / 64, x.goff, spine, false);
+    launch_exclusive_scan(st, x.cnt, cap / kNuGroup, x.goff, spine, false);
     hipLaunchKernelGGL(k_nu_exc_diff, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, ce);
     launch_exclusive_scan(st, ce, ltot + 2, ce, spine, false);
     hipLaunchKernelGGL(k_nu_need_adjust, dim3(grid_for((uint64_t)ltot + 1, 256)), dim3(256), 0, st, boff, ce, ltot, ell, M, nadj);

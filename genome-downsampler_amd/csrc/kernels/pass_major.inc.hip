@@ -30,8 +30,8 @@ static constexpr int kPmThreads = 512;           // 8 waves: wave w owns records
 static constexpr int kPmWaves = kPmThreads / 64;
 static constexpr int kPmPassesPerWg = 4;         // a workgroup's passes leave their table entries as 16-byte runs
 static constexpr uint32_t kPmMaxRow = 3072;      // passes of a range's row the consumers hold in LDS (2 x 12 KiB): 25 M reads over the contigs a range overlaps
-static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 64) * sizeof(uint32_t);
-static constexpr uint32_t kPmExcPerWave = 64;  // list slots per wave and pass: a sixteenth of the wave's 1 024 reads
+static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 128) * sizeof(uint32_t);
+static constexpr uint32_t kPmExcPerWave = 128;  // list slots per wave and pass: an eighth of the wave's 1 024 reads
 
 #ifndef QMCP_PM_MIN_WAVES
 #define QMCP_PM_MIN_WAVES 4  // waves per SIMD the register allocation aims at (6 -- three workgroups per CU -- spills: 0.42 against 0.29 ms)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask,
     // near-uniform route (kernels/near_uniform.inc.hip): reads whose span is not ell_reg are left out of the sorted
     // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words.  Every wave
-    // of every pass owns kPmExcPerWave slots of the list (pass P, wave w: from (8 P + w) * 64) and says how many it
+    // of every pass owns kPmExcPerWave slots of the list (pass P, wave w: from (8 P + w) * 128) and says how many it
     // filled in exc_cnt[8 P + w]: no counter is shared (24 k same-address atomics, one per wave, took longer than
     // the whole kernel: 0.32 -> 0.69 ms); k_pm_count_exceptions adds the groups up into stats[4] afterwards.  stats[5]
     // is set if a wave met more than its slots hold (the list is then incomplete).  ell_reg == 0: every read is regular.
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* s_wave = s_gbase + 256;                   // [16]
     uint32_t* s_tabc = s_wave + 16;                     // [4][256] the workgroup's table entries
     uint32_t* s_tabl = s_tabc + kPmPassesPerWg * 256;   // [4][256]
-    uint32_t* s_exc = s_tabl + kPmPassesPerWg * 256;    // [8][64][3] every wave's exceptions of the pass, until the pass is written out
+    uint32_t* s_exc = s_tabl + kPmPassesPerWg * 256;    // [8][128][3] every wave's exceptions of the pass, until the pass is written out
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
     auto contig_of = [&](uint32_t i) {
@@ -227,10 +227,10 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
 #ifndef QMCP_LAB_NO_EXC_OUT
         if (ell_reg != 0u) {
             const size_t slot0 = ((size_t)P * kPmWaves + w) * kPmExcPerWave;
-            if ((uint32_t)lane < min(filled, kPmExcPerWave)) {
-                exc[slot0 + lane] = mine[3u * lane];
-                exc[exc_cap + slot0 + lane] = mine[3u * lane + 1u];
-                exc[2 * (size_t)exc_cap + slot0 + lane] = mine[3u * lane + 2u];
+            for (uint32_t r = (uint32_t)lane; r < min(filled, kPmExcPerWave); r += 64u) {
+                exc[slot0 + r] = mine[3u * r];
+                exc[exc_cap + slot0 + r] = mine[3u * r + 1u];
+                exc[2 * (size_t)exc_cap + slot0 + r] = mine[3u * r + 2u];
             }
             if (lane == 0) {
                 exc_cnt[P * kPmWaves + w] = min(filled, kPmExcPerWave);
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
 uint32_t pm_pitch(uint32_t n) { return part_pass_pitch(n); }  // passes of the call, rounded up to a multiple of 4
 uint32_t pm_max_row() { return kPmMaxRow; }
 uint32_t pm_pass() { return (uint32_t)kPmPass; }
-uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave; }  // the exception list's slots (64 per wave and pass)
+uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave; }  // the exception list's slots (128 per wave and pass)
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,

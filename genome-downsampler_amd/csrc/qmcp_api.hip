@@ -558,12 +558,24 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     return QMCP_OK;
 }
 
-// Near-uniform route: sizes.  Exceptions beyond a sixteenth of the reads are not worth the route (every one the sweep
-// wants costs a sweep of its own); the list holds that many.
+// Near-uniform route: sizes.  Exceptions beyond a tenth of the reads are not worth the route (every one the sweep
+// wants costs a sweep of its own); the list holds an eighth of every wave's reads.
 constexpr uint32_t kNuSuspects = 1u << 16;
-constexpr uint32_t kNuMaxRounds = 24;
+// Rounds the route may take before it gives way to the mixed-span walk: that walk is one serial chain per contig at
+// ~0.07 us per position (79.8 ms for cfg4's 10^6-position contigs), a round is ~0.1 ms + what it sweeps again (at most
+// a contig: 0.5 ms per 10^6 positions); the route may spend up to about half of what the walk would take.
+constexpr uint32_t kNuMinRounds = 8, kNuMaxRoundsCap = 160;
+uint32_t nu_round_budget(const uint32_t* lengths, uint32_t n_contigs) {
+    if (const char* e = std::getenv("QMCP_HIP_NEAR_ROUNDS")) return (uint32_t)std::strtoul(e, nullptr, 10);
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < n_contigs; ++k) longest = lengths[k] > longest ? lengths[k] : longest;
+    const double walk_ms = 0.07e-3 * (double)longest;
+    const double round_ms = 0.1 + 0.5e-6 * (double)longest;
+    const double r = 0.5 * walk_ms / round_ms;
+    return r < kNuMinRounds ? kNuMinRounds : r > kNuMaxRoundsCap ? kNuMaxRoundsCap : (uint32_t)r;
+}
 constexpr double kNuMinDepth = 6.0;  // mean coverage / M below which too many exceptions are wanted for the route to pay
-uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 64 slots per wave and pass: a sixteenth of the reads
+uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 128 slots per wave and pass: an eighth of the reads
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
     TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
@@ -890,7 +902,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         HIP_TRY(hipStreamSynchronize(st));
         n_exc = n - c->h_nu[0];
         if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
-        if (n_exc > n / 16u) { c->nu_ell = 0; return QMCP_OK; }
+        if (n_exc > n / 10u) { c->nu_ell = 0; return QMCP_OK; }
         // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
         c->nu_ell = ell;
         TRY(queue_pm_head(c, st, ell));
@@ -902,8 +914,8 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; return QMCP_OK; }  // (a pass held more than it can stage)
     }
     local.near_uniform_exceptions = n_exc;
-    if (n_exc == 0 || n_exc > n / 16u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
-        if (n_exc > n / 16u) c->nu_ell = 0;
+    if (n_exc == 0 || n_exc > n / 10u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
+        if (n_exc > n / 10u) c->nu_ell = 0;
         return QMCP_OK;
     }
     // scratch of the event-driven sweep (launch_uniform_sweep)
@@ -933,7 +945,8 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     // batches of 1 / 2 / 2 + 4 + 4: 4.62 / 4.5 / 4.60 ms.
     uint32_t rounds = 0;
     bool settled = false;
-    while (rounds < kNuMaxRounds && !settled) {
+    const uint32_t budget = nu_round_budget(run.lengths, n_contigs);
+    while (rounds < budget && !settled) {
         const uint32_t batch = 2u;
         for (uint32_t r = 0; r < batch; ++r) {
             ++rounds;
