@@ -574,7 +574,10 @@ uint32_t nu_round_budget(const uint32_t* lengths, uint32_t n_contigs) {
     const double r = 0.5 * walk_ms / round_ms;
     return r < kNuMinRounds ? kNuMinRounds : r > kNuMaxRoundsCap ? kNuMaxRoundsCap : (uint32_t)r;
 }
-constexpr double kNuMinDepth = 6.0;  // mean coverage / M below which too many exceptions are wanted for the route to pay
+// mean coverage / M below which the route is not tried: the shallower the data, the more exceptions are wanted (cfg4's
+// reads with 1 % clipped, lab/near_uniform_depths.py, near-uniform / mixed-span ms: 12.5 x M 8 / 105; 9.4 x M 11 / 290;
+// 6.3 x M 27 / 399; 4.7 x M 49 / 503; 3.75 x M 75 / 662 -- 51 sweeps of a budget of 58)
+constexpr double kNuMinDepth = 3.5;
 uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 128 slots per wave and pass: an eighth of the reads
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
@@ -883,8 +886,10 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const bool dbg = std::getenv("QMCP_HIP_NEAR_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[near] pm %d may_rank %d kid %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
                      (int)run.may_rank, (int)c->is_kid, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
+    double min_depth = kNuMinDepth;
+    if (const char* e = std::getenv("QMCP_HIP_NEAR_MIN_DEPTH")) min_depth = std::strtod(e, nullptr);  // (lab)
     if (!run.pm || !run.may_rank || c->is_kid || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
-        depth < kNuMinDepth || min_span == 0)
+        depth < min_depth || min_span == 0)
         return QMCP_OK;
     hipStream_t st = c->stream;
     const uint32_t cap = nu_cap_for(n);
