@@ -31,6 +31,7 @@
 // does not settle within its budget, or when any read is LONGER than the dominant span.
 static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
 static constexpr unsigned long long kNuNoKey = ~0ull;
+static constexpr unsigned long long kNuUnresolvedLow = 0x3FFFFull;  // low 18 bits no event key has (t - s < 256)
 
 struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 128
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
@@ -182,7 +183,19 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         int32_t u1 = b + 1;
         while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < ell) --u1;
         if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
-            if (lane == 0) atomicOr(&state[2], 1u);  // ell exhausted buckets in a row below the read: not modelled
+            // ell exhausted buckets in a row below the read: not modelled.  That only matters if nothing EARLIER in the
+            // contig is wanted: behind a wanted exception the sweep ran on a need it could not meet, and what it left
+            // there (often every bucket used up) is replaced by the next round's sweep anyway.  So the read enters the
+            // contig's contest with a key of its own -- its release time, lowest priority -- and the route gives up
+            // only if that key wins.
+            if (lane == 0) {
+                const unsigned long long k = ((unsigned long long)(uint32_t)s << 18) | kNuUnresolvedLow;
+                x.key[i] = k;
+                atomicMin(&viol_key[contig], k);
+                state[5] = x.idx[i];  // (which read: for the host's debug line)
+                state[8] = (uint32_t)s; state[9] = (uint32_t)u1; state[10] = (uint32_t)S(u1 - 1); state[11] = (uint32_t)C(u1 - 1);
+                state[12] = (uint32_t)b; state[13] = (uint32_t)c0;
+            }
             continue;
         }
         u1 = max(u1, c0);
@@ -272,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_nu_select_apply(NuExc x, const uint2* 
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
         if (k == kNuNoKey || k != viol_key[su.y]) continue;
+        if ((k & 0x3FFFFull) == kNuUnresolvedLow) { atomicOr(&state[2], 1u); continue; }  // the contig's earliest open question has no answer
         if (x.idx[su.x] != __hip_atomic_load(&viol_idx[su.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
         const uint32_t t = (uint32_t)(k >> 18), e = x.ge[su.x];
         x.pick[su.x] = t;

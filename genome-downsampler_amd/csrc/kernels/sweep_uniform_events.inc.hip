@@ -397,8 +397,12 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
                 int32_t need_p = (int32_t)min(a1 - b1, M);
                 int32_t need_m = (int32_t)min(a0 - b0, M);
                 if (nadj != nullptr) {
-                    need_p += nadj[min(p, ltot)];
-                    need_m += nadj[p > 0 ? p - 1 : 0u];
+                    // (capped at what the swept reads can give: where the other reads are needed to reach the need --
+                    //  a contig's last positions -- the demand could not be met, and what cannot be met is handed back
+                    //  through the whole block before, beyond the positions that could have served it; the near-uniform
+                    //  route's verification works on the uncapped need and selects those other reads)
+                    need_p = min(need_p + nadj[min(p, ltot)], (int32_t)(a1 - b1));
+                    need_m = min(need_m + nadj[p > 0 ? p - 1 : 0u], (int32_t)(a0 - b0));
                 }
                 if (pos == 0 && contig_start) need_m = 0;
                 c[r] = valid ? a1 - a0 : 0u;

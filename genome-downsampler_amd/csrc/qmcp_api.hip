@@ -981,8 +981,11 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         HIP_TRY(hipMemcpyAsync(c->h_nu, state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (dbg) {
-            fprintf(stderr, "[near] after %u rounds: last round selected %u, flags %u, selected in all %u, suspects %u, rounds that selected %u; next sweeps from block",
-                    rounds, c->h_nu[1], c->h_nu[2], c->h_nu[3], c->h_nu[4], c->h_nu[6]);
+            uint32_t more[8];
+            (void)hipMemcpy(more, state + 8, sizeof(more), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[near] open question: s %u u1 %u S(u1-1) %u C(u1-1) %u b %u c0 %u\n", more[0], more[1], more[2], more[3], more[4], more[5]);
+            fprintf(stderr, "[near] after %u rounds: last round selected %u, flags %u (read %u), selected in all %u, suspects %u, rounds that selected %u; next sweeps from block",
+                    rounds, c->h_nu[1], c->h_nu[2], c->h_nu[5], c->h_nu[3], c->h_nu[4], c->h_nu[6]);
             std::vector<uint32_t> from(n_contigs);
             (void)hipMemcpy(from.data(), sweep_from[0], (size_t)n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost);
             for (uint32_t k = 0; k < n_contigs && k < 16; ++k) fprintf(stderr, " %d", (int)from[k]);

@@ -77,7 +77,13 @@ def verify(c, S, need, ell, exc_s, exc_e, exc_idx, unpicked):
         while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < ell:
             u1 -= 1
         if u1 - 1 >= 0 and exhausted(u1 - 1):
-            return "unresolved"
+            # ell used-up buckets in a row below the read: not modelled.  It only matters if nothing earlier is wanted
+            # (behind a wanted exception the sweep ran on a need it could not meet): the read enters the contest with
+            # its release time and the lowest priority, and the model gives up only if that wins.
+            key = (s, 1 << 40, 0, 0)
+            if best is None or key < best[0]:
+                best = (key, "unresolved")
+            continue
         u1 = max(u1, 0)
         # replay from the anchor u1 - 1 (the bucket below the run: never exhausted, so nothing below it is picked
         # at or after its own time, and the final counts below it are what every later window sees).  The replayed
@@ -113,6 +119,8 @@ def verify(c, S, need, ell, exc_s, exc_e, exc_idx, unpicked):
             if t >= s and not exhausted(t):
                 break      # bucket t keeps members for good: x is never reached later
             t += 1
+    if best is not None and best[1] == "unresolved":
+        return "unresolved"
     return None if best is None else (best[0][0], best[1])
 
 
