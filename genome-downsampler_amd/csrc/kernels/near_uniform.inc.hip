@@ -31,7 +31,13 @@
 // does not settle within its budget, or when any read is LONGER than the dominant span.
 static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
 static constexpr unsigned long long kNuNoKey = ~0ull;
-static constexpr unsigned long long kNuUnresolvedLow = 0x3FFFFull;  // low 18 bits no event key has (t - s < 256)
+// An open question's key: time << 19 | (511 - (end - time)) << 10 | (time - start) << 1 | kind -- earlier time first,
+// then the larger end, the larger start; kind 0: the exception is wanted (select it at that time), 1: a selected
+// exception is not wanted at its time (unselect it).  kNuUnresolvedLow: the low 19 bits of a read whose run has no
+// anchor (no event key has them: time - start < 256).
+static constexpr unsigned long long kNuUnresolvedLow = 0x7FFFFull;
+static constexpr int kNuKeyShift = 19;
+static constexpr int kNuOthers = 256;  // exceptions of one contig whose lives overlap a suspect's (more: the route gives up)
 
 struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 128
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
@@ -124,18 +130,20 @@ __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __r
     if (state[7] == 0u) return;  // (no contig was swept this round: every one is settled)
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
         const uint32_t i = x.dense[j];
-        if (x.pick[i] != kNuUnpicked) continue;
         const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
         const int32_t b = e - (int32_t)v.ell + 1;
         const uint32_t contig = nu_contig_of(v, (uint32_t)s);
         const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
-        // what an earlier round cleared stays cleared: nothing at or below e has changed if the round swept only
-        // from a later block on (a contig that is settled sweeps nothing)
+        // what an earlier round settled stays settled: nothing at or below e has changed if the round swept only from
+        // a later block on (a contig that is settled sweeps nothing).  One span of slack: an exception listed for its
+        // own sake needs the ones whose lives overlap its own beside it, and those may end a span earlier.
         const uint32_t from = swept_from[contig];
-        if (from == 0xFFFFFFFFu || (uint64_t)(uint32_t)(e - c0) < (uint64_t)from * v.ell) continue;
-        bool reach = true;
-        for (int32_t u = s; u > b && reach; --u) reach = nu_exhausted(v, u, c0);
-        if (!reach) continue;
+        if (from == 0xFFFFFFFFu || (uint64_t)(uint32_t)(e - c0) + v.ell < (uint64_t)from * v.ell) continue;
+        if (x.pick[i] == kNuUnpicked) {  // (a selected exception is always listed: its selection is checked)
+            bool reach = true;
+            for (int32_t u = s; u > b && reach; --u) reach = nu_exhausted(v, u, c0);
+            if (!reach) continue;
+        }
         const uint32_t slot = atomicAdd(&state[4], 1u);
         if (slot < suspects_cap) suspects[slot] = make_uint2(i, contig);
         else atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
@@ -152,6 +160,8 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
                                                   uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key) {
     __shared__ uint32_t s_b[kNuStage], s_e[kNuStage];
     __shared__ int32_t s_a[kNuStage], s_cur[kNuCur], s_stack[kNuCur];
+    __shared__ int32_t o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers], o_above[kNuOthers];
+    __shared__ uint32_t o_n;
     const int32_t lane = (int32_t)threadIdx.x;
     const uint32_t n_sus = min(state[4], suspects_cap);
     const int32_t ell = (int32_t)v.ell;
@@ -170,7 +180,30 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             s_a[k] = v.nadj[r0 + k];
         }
         for (int32_t k = lane; k < kNuCur; k += 64) s_cur[k] = 0;
+        if (lane == 0) o_n = 0;
         __syncthreads();
+        // the other listed exceptions of the contig whose lives overlap this one's: {start, end, selection time or -1,
+        // outranks this one}
+        const uint32_t my_idx = x.idx[i];
+        const int32_t sel = x.pick[i] == kNuUnpicked ? -1 : (int32_t)x.pick[i];
+        for (uint32_t j = (uint32_t)lane; j < n_sus; j += 64u) {
+            const uint2 z = suspects[j];
+            if (z.y != contig || z.x == i) continue;
+            const int32_t zs = (int32_t)x.gs[z.x], ze = (int32_t)x.ge[z.x];
+            if (ze < s || zs > e) continue;
+            const uint32_t slot = atomicAdd(&o_n, 1u);
+            if (slot < (uint32_t)kNuOthers) {
+                o_s[slot] = zs; o_e[slot] = ze;
+                o_t[slot] = x.pick[z.x] == kNuUnpicked ? -1 : (int32_t)x.pick[z.x];
+                o_above[slot] = (ze > e || (ze == e && (zs > s || (zs == s && x.idx[z.x] < my_idx)))) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        const int32_t n_others = (int32_t)min(o_n, (uint32_t)kNuOthers);
+        if (o_n > (uint32_t)kNuOthers) {
+            if (lane == 0) atomicOr(&state[2], 4u);  // more neighbours than the list holds: the route gives up
+            continue;
+        }
         auto C = [&](int32_t u) { return (int32_t)(s_b[u + 1 - r0] - s_b[u - r0]); };
         auto S = [&](int32_t u) { return (int32_t)(s_e[u - r0] - s_b[u - r0]); };
         auto exhausted = [&](int32_t u) { return u < c0 || S(u) == C(u); };
@@ -189,7 +222,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             // contig's contest with a key of its own -- its release time, lowest priority -- and the route gives up
             // only if that key wins.
             if (lane == 0) {
-                const unsigned long long k = ((unsigned long long)(uint32_t)s << 18) | kNuUnresolvedLow;
+                const unsigned long long k = ((unsigned long long)(uint32_t)s << kNuKeyShift) | kNuUnresolvedLow;
                 x.key[i] = k;
                 atomicMin(&viol_key[contig], k);
                 state[5] = x.idx[i];  // (which read: for the host's debug line)
@@ -221,15 +254,34 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         int32_t fixed = wave_sum_S(max(u1 - ell + 1, 0), base);
         int32_t avail = 0;   // what the regular members of the buckets (b, t] still offer
         unsigned long long key = kNuNoKey;
-        for (int32_t t = u1; t <= e; ++t) {
-            int32_t d = max(need(t) - fixed - repl, 0);
+        // A selected exception is checked up to its time (wanted there, and not before); an unselected one over its life.
+        // Wanted at t:  raw(t) + k(t) > avail(t) + r(t)  -- raw: the sweep's own demand, before the clamp at zero (a
+        // selection that was not needed leaves a surplus); k: exceptions selected at exactly t (their unit is back in the
+        // demand the greedy saw); r: listed exceptions above this one that are candidates at t.
+        const int32_t last = sel >= 0 ? sel : e;
+        for (int32_t t = u1; t <= last; ++t) {
+            const int32_t raw = need(t) - fixed - repl;
+            int32_t d = max(raw, 0);
             const int32_t ct = C(t);
             if (t > b) avail += ct;
-            if (t >= s && d > avail) {
-                // earlier time first, then the larger end, the larger start (the index is settled by k_nu_select_apply)
-                key = ((unsigned long long)(uint32_t)t << 18) | ((unsigned long long)(511 - (e - t)) << 9) |
-                      (unsigned long long)(t - s);
-                break;
+            if (t >= s) {
+                int32_t k = sel == t ? 1 : 0, r = 0;
+                if (n_others > 0) {  // (uniform)
+                    int32_t kk = 0, rr = 0;
+                    for (int32_t j = lane; j < n_others; j += 64) {
+                        kk += o_t[j] == t ? 1 : 0;
+                        rr += (o_above[j] != 0 && o_s[j] <= t && t <= o_e[j] && (o_t[j] < 0 || o_t[j] >= t)) ? 1 : 0;
+                    }
+                    k += (int32_t)wave_sum_u32((uint32_t)kk);
+                    r = (int32_t)wave_sum_u32((uint32_t)rr);
+                }
+                const bool wanted = raw + k > avail + r;
+                const bool is_open = (sel < 0 || t < sel) ? wanted : !wanted;
+                if (is_open) {
+                    key = ((unsigned long long)(uint32_t)t << kNuKeyShift) | ((unsigned long long)(511 - (e - t)) << 10) |
+                          ((unsigned long long)(t - s) << 1) | ((sel < 0 || t < sel) ? 0ull : 1ull);
+                    break;
+                }
             }
             avail -= min(d, avail);
             if (ct > 0 && n_stack < kNuCur) s_stack[n_stack++] = t;
@@ -242,7 +294,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
                 d -= k;
                 if (k == have) --n_stack;
             }
-            if (t >= s && !exhausted(t)) break;  // bucket t keeps members for good: x is never reached later
+            if (sel < 0 && t >= s && !exhausted(t)) break;  // bucket t keeps members for good: x is never reached later
             // the window moves on: bucket t - ell + 1 leaves it
             const int32_t out = t - ell + 1;
             if (out >= base) repl -= s_cur[out - base];
@@ -267,35 +319,43 @@ __global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ s
     }
     if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
 }
-// One workgroup: per contig the winning event's smallest read index (suspects with the contig's earliest key), then the
-// winner is selected -- its time recorded, nadj lowered by one on [t, e], the contig's next sweep placed.
+// One workgroup settles every open question of the round: an exception the sweep wants is selected at that time (or
+// earlier than it was), one that is not wanted at its time is unselected; nadj follows, and every contig's next sweep
+// starts two blocks before its earliest change.  Only a contig's EARLIEST question (then the highest priority) is known
+// to be settled for good -- everything before it is certified -- the others are settled tentatively and checked again
+// by the next round (tests/near_uniform_model.py: solve_near_uniform_batched).  A contig whose earliest question is a
+// read without an anchor ends the attempt.
 __global__ __launch_bounds__(1024) void k_nu_select_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                           uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
-                                                          uint32_t* __restrict__ viol_idx, int32_t* __restrict__ nadj,
+                                                          int32_t* __restrict__ nadj,
                                                           const uint64_t* __restrict__ poff, uint32_t ell,
                                                           uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
     const uint32_t n_sus = min(state[4], suspects_cap);
     for (uint32_t q = threadIdx.x; q < n_sus; q += blockDim.x) {
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
-        if (k != kNuNoKey && k == viol_key[su.y]) atomicMin(&viol_idx[su.y], x.idx[su.x]);
-    }
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < n_sus; q += blockDim.x) {
-        const uint2 su = suspects[q];
-        const unsigned long long k = x.key[su.x];
-        if (k == kNuNoKey || k != viol_key[su.y]) continue;
-        if ((k & 0x3FFFFull) == kNuUnresolvedLow) { atomicOr(&state[2], 1u); continue; }  // the contig's earliest open question has no answer
-        if (x.idx[su.x] != __hip_atomic_load(&viol_idx[su.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-        const uint32_t t = (uint32_t)(k >> 18), e = x.ge[su.x];
-        x.pick[su.x] = t;
-        for (uint32_t p = t; p <= e; ++p) nadj[p] -= 1;  // (one exception per contig and round: no two writers meet)
+        if (k == kNuNoKey) continue;
+        if ((k & kNuUnresolvedLow) == kNuUnresolvedLow) {
+            if (k == viol_key[su.y]) atomicOr(&state[2], 1u);  // the contig's earliest open question has no answer
+            continue;
+        }
+        const uint32_t t = (uint32_t)(k >> kNuKeyShift), e = x.ge[su.x];
+        const uint32_t old = x.pick[su.x];
+        if ((k & 1ull) == 0ull) {  // wanted at t: select it there (it may have been selected later)
+            const uint32_t hi = old != kNuUnpicked ? old - 1u : e;
+            for (uint32_t p = t; p <= hi; ++p) atomicSub(&nadj[p], 1);
+            x.pick[su.x] = t;
+            if (old == kNuUnpicked) atomicAdd(&state[3], 1u);
+        } else {                   // selected at `old`, not wanted there
+            for (uint32_t p = old; p <= e; ++p) atomicAdd(&nadj[p], 1);
+            x.pick[su.x] = kNuUnpicked;
+            atomicSub(&state[3], 1u);
+        }
         // the next sweep of this contig: what happens from t on changes buckets above t - ell only, so the state
         // entering the block two before t's is still the chain's (the chain keeps it at every 64th block)
         const uint32_t kt = (t - (uint32_t)poff[su.y]) / ell;
-        sweep_from[su.y] = (kt >= 2u ? kt - 2u : 0u) & ~63u;
+        atomicMin(&sweep_from[su.y], (kt >= 2u ? kt - 2u : 0u) & ~63u);
         atomicAdd(&state[1], 1u);
-        atomicAdd(&state[3], 1u);
     }
 }
 
@@ -358,7 +418,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from);
     hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key);
-    hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, viol_idx, nadj, d_poff, ell,
+    hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
                        sweep_from_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,

@@ -49,6 +49,10 @@ with pkg.Solver(0) as sv:
         paths[int(st.path)] += 1
         if st.path == pkg.PATH_NEAR_UNIFORM:
             rounds[int(st.near_uniform_rounds)] += 1; selected += int(st.near_uniform_selected)
+            bits = np.unpackbits(want.view(np.uint8), bitorder="little")[:s.size].astype(bool)
+            exc_kept = int((bits & ((e - s + 1) != ell)).sum())
+            if exc_kept != int(st.near_uniform_selected):
+                print("STAT case", seed0 + case, "exceptions kept", exc_kept, "stats say", int(st.near_uniform_selected), flush=True)
         if not np.array_equal(got, want):
             wrong += 1
             print("MISMATCH case", seed0 + case, dict(n_contigs=n_contigs, ell=ell, M=M, depth=depth, frac=frac, style=str(style)), st.as_dict(), flush=True)

@@ -159,3 +159,137 @@ def solve_near_uniform(starts, ends, L, M, ell, max_iter=64):
     for p in np.flatnonzero(S):
         keep[rs[first[p]:first[p] + S[p]]] = True
     return keep, it
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Batched rounds (round 3, second form): every exception the sweep is seen to want is selected in the SAME round --
+# tentatively -- and every selection is then certified against the next sweep: y is wanted at time t iff
+#       d'(t) + k(t)  >  A_y(t) + r_y(t)
+# with d' the sweep's own demand at t (its need already lowered by every selection), k(t) the exceptions selected at
+# exactly t, A_y what the regular members of the buckets above y's still offer and r_y the exceptions above y that are
+# candidates at t (released, alive, not selected before t).  A selected y must be wanted at its time and not before,
+# an unselected one never.  Per contig the earliest open question (then the highest priority) is settled exactly --
+# everything before it is certified -- and never changes again; the others are settled tentatively.
+def _priority(e, s, idx):
+    return (-e, -s, idx)
+
+
+def _walk(c, S, need, ell, s, e, others, sel_time, L):
+    """the replay of one exception (s, e, its selection time or -1) against the sweep's final counts: returns the
+    first (time, kind) at which the sweep and the selection disagree, kind in {"select", "unselect"}; None; or
+    "unresolved".  others = [(s, e, idx, sel_time, above?)] exceptions of the same contig whose lives overlap."""
+    v = e - ell + 1
+
+    def exhausted(u):
+        return u < 0 or S[u] == c[u]
+    u1 = v + 1
+    while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < ell:
+        u1 -= 1
+    if u1 - 1 >= 0 and exhausted(u1 - 1):
+        return "unresolved"
+    u1 = max(u1, 0)
+    anchor = u1 - 1
+    base = anchor if anchor >= 0 else 0
+    cur = np.zeros(e - base + 2, np.int64)
+    avail = 0
+    if anchor >= 0:
+        lo = max(0, anchor - ell + 1)
+        d = int(need[anchor]) - int(S[lo:anchor].sum())
+        cur[0] = min(max(d, 0), int(c[anchor]))
+    t = u1
+    last = e if sel_time < 0 else sel_time
+    while t <= last and t < L:
+        lo = max(0, t - ell + 1)
+        fixed = int(S[lo:base].sum()) if base > lo else 0
+        repl = int(cur[max(lo, base) - base:t - base].sum())
+        raw = int(need[t]) - fixed - repl      # (may be negative: a selection that was not needed leaves a surplus)
+        d = max(raw, 0)
+        if t > v:
+            avail += int(c[t])
+        if t >= s:
+            k = sum(1 for (zs, ze, zi, zt, above) in others if zt == t) + (1 if sel_time == t else 0)
+            r = sum(1 for (zs, ze, zi, zt, above) in others if above and zs <= t <= ze and (zt < 0 or zt >= t))
+            wanted = raw + k > avail + r
+            if sel_time < 0 or t < sel_time:
+                if wanted:
+                    return (t, "select")
+            elif not wanted:
+                return (t, "unselect")
+        avail -= min(d, avail)
+        u = t
+        while d > 0 and u >= base:
+            kk = min(d, int(c[u]) - int(cur[u - base]))
+            cur[u - base] += kk
+            d -= kk
+            u -= 1
+        if sel_time < 0 and t >= s and not exhausted(t):
+            break
+        t += 1
+    return None
+
+
+def solve_near_uniform_batched(starts, ends, L, M, ell, max_rounds=200):
+    starts = starts.astype(np.int64)
+    ends = ends.astype(np.int64)
+    reg, exc = split_reads(starts, ends, ell)
+    c = np.bincount(starts[reg], minlength=L).astype(np.int64)
+    cov_all = coverage(starts, ends, L)
+    base_need = np.minimum(cov_all, M).astype(np.int64)
+    xs, xe = starts[exc], ends[exc]
+    sel = np.full(exc.size, -1, np.int64)
+    for x in range(exc.size):
+        if cov_all[xs[x]] <= M:
+            sel[x] = xs[x]
+    rounds = 0
+    while True:
+        rounds += 1
+        need = base_need.copy()
+        for x in np.flatnonzero(sel >= 0):
+            need[sel[x]:xe[x] + 1] -= 1
+        need_capped = need   # (the host model's sweep drops what it cannot meet: same as the device's cap)
+        S, _ = regular_sweep(c, need_capped, ell)
+        # the list: unselected exceptions the quick look does not clear, and every selected one
+        listed = []
+        for x in range(exc.size):
+            if sel[x] >= 0:
+                listed.append(x)
+                continue
+            s, e = int(xs[x]), int(xe[x])
+            v = e - ell + 1
+            if all((u < 0 or S[u] == c[u]) for u in range(s, v, -1)):
+                listed.append(x)
+        open_q = []
+        for x in listed:
+            s, e = int(xs[x]), int(xe[x])
+            px = _priority(e, s, int(exc[x]))
+            others = []
+            for z in listed:
+                if z == x or xe[z] < s or xs[z] > e:
+                    continue
+                others.append((int(xs[z]), int(xe[z]), int(exc[z]), int(sel[z]), _priority(int(xe[z]), int(xs[z]), int(exc[z])) < px))
+            r = _walk(c, S, need, ell, s, e, others, int(sel[x]), L)
+            if r == "unresolved":
+                open_q.append(((s, (1 << 40, 0, 0)), x, "unresolved"))
+            elif r is not None:
+                open_q.append(((r[0], px), x, r[1]))
+        if not open_q:
+            break
+        if rounds >= max_rounds:
+            return None
+        open_q.sort(key=lambda q: q[0])
+        if open_q[0][2] == "unresolved":
+            return None
+        # the earliest is exact; the rest are settled the same way, tentatively (one per exception)
+        for (key, x, kind) in open_q:
+            if kind == "select":
+                sel[x] = key[0]
+            elif kind == "unselect":
+                sel[x] = -1
+    keep = np.zeros(starts.size, bool)
+    keep[exc[sel >= 0]] = True
+    order = np.argsort(starts[reg], kind="stable")
+    rs = reg[order]
+    first = np.concatenate([[0], np.cumsum(c)])
+    for p in np.flatnonzero(S):
+        keep[rs[first[p]:first[p] + S[p]]] = True
+    return keep, rounds

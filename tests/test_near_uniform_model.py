@@ -54,3 +54,44 @@ def test_random_shapes(oracle):
         assert np.array_equal(r[0], _bits(oracle.solve(s, e, [L], M), s.size)), seed
         resolved += 1
     assert resolved >= 15
+
+
+@pytest.mark.parametrize("depth,frac", [(3, 0.05), (4, 0.2), (6, 0.1), (12, 0.2)])
+def test_batched_rounds_equal_the_oracle(oracle, depth, frac):
+    """the second form: every exception the sweep is seen to want is selected in the same round, tentatively, and every
+    selection is certified against the next sweep (wanted at its time, not before; an unselected one never) -- the same
+    kept set in far fewer sweeps"""
+    resolved, rounds_b, rounds_s = 0, 0, 0
+    for seed in range(5):
+        L, ell, M = 1200, 24, 8
+        s, e = _instance(seed * 5 + 2, L, ell, M, depth, frac, 10)
+        r = nu.solve_near_uniform_batched(s, e, L, M, ell)
+        if r is None:
+            continue
+        want = _bits(oracle.solve(s, e, [L], M), s.size)
+        assert np.array_equal(r[0], want), (depth, frac, seed)
+        resolved += 1
+        rounds_b += r[1]
+        q = nu.solve_near_uniform(s, e, L, M, ell, max_iter=400)
+        rounds_s += (q[1] + 1) if q is not None else 0
+    assert resolved >= 3
+    assert rounds_b <= rounds_s or rounds_s == 0
+
+
+def test_batched_rounds_on_identical_exceptions(oracle):
+    """groups of exceptions with one (start, end): the read index decides among them, as r (the candidates above) does"""
+    for seed in range(6):
+        rng = np.random.default_rng(50 + seed)
+        L, ell, M = 900, 20, 6
+        n = int(5 * M * L / ell)
+        s = rng.integers(0, L - ell + 1, size=n)
+        e = s + ell - 1
+        j = rng.choice(n, size=n // 20, replace=False)
+        for g in range(0, j.size - 3, 3):
+            s[j[g + 1]] = s[j[g + 2]] = s[j[g]]
+        e = s + ell - 1
+        clip = np.repeat(rng.integers(1, 8, size=j.size // 3 + 1), 3)[:j.size]
+        e[j] -= clip
+        r = nu.solve_near_uniform_batched(s.astype(np.uint32), e.astype(np.uint32), L, M, ell)
+        if r is not None:
+            assert np.array_equal(r[0], _bits(oracle.solve(s.astype(np.uint32), e.astype(np.uint32), [L], M), n)), seed
