@@ -134,8 +134,8 @@ def clipped_configs(pkg, torch, dev, solver, stream, d_starts, d_ends, n_reads, 
                                 "kept": kept_near, "exceptions": int(st.near_uniform_exceptions),
                                 "exceptions_kept": int(st.near_uniform_selected), "sweeps": int(st.near_uniform_rounds),
                                 "note": "cfg4 with 1 % of the reads shortened by 1...50 bases: near-uniform route (path 3: "
-                                        "the one-span sweep over the regular reads, the short ones verified against it "
-                                        "and selected one event per contig and sweep); mixed_route_device_ms is the same "
+                                        "the one-span sweep over the regular reads, the short ones it is seen to want "
+                                        "selected and certified against the next sweep); mixed_route_device_ms is the same "
                                         "call on the mixed-span event sweep (QMCP_HIP_NEAR=0), same kept set"}
     os.environ["QMCP_HIP_NEAR"] = "0"
     try:

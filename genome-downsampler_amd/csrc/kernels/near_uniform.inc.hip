@@ -18,17 +18,22 @@
 //   k_nu_exc_diff + scan + k_nu_need_adjust   coverage of the exceptions -> nadj[p] = need'(p) - min(cov_regular(p), M);
 //   k_nu_prepick        an exception that starts where everything is kept (cov_all <= M) is selected when released;
 //   [ k_sweep_pack / k_sweep_uniform_ev / k_sweep_expand with nadj  ->  S(p) of the regular reads
-//     k_nu_verify       every unselected exception x = (v, s, e): it can only be reached at a time t in [s, e] if all
-//                       regular members of the buckets (v, t] are selected by then, hence in the sweep's FINAL counts:
-//                       one look at bucket s clears nearly all; the rest are listed as suspects
-//     k_nu_replay       one wave per suspect: the sweep's time-resolved picks over the run of exhausted buckets
-//                       around s, rebuilt from final counts (below the run's anchor nothing is picked late), give the
-//                       first time the demand exceeds what the buckets above x still offer
-//     k_nu_select_apply          per contig the earliest such event (highest priority first) is exact -- before it
-//                       greedy and sweep agree -- so that exception is selected at that time: nadj -= 1 on [t, e] ]
-//   repeated until no exception is wanted; then k_pm_rank_mark for the regular reads and k_nu_mark_selected.
-// The host gives up (and takes the mixed-span route) when a suspect's run is longer than the window, when the loop
-// does not settle within its budget, or when any read is LONGER than the dominant span.
+//     k_nu_verify       lists the exceptions that need a look: every selected one, and every unselected x = (v, s, e)
+//                       that can be reached at all -- that needs the regular members of the buckets (v, s] used up in
+//                       the sweep's FINAL counts: one look at bucket s clears nearly all
+//     k_nu_replay       one wave per listed exception: the sweep's time-resolved picks over the run of used-up buckets
+//                       around s, rebuilt from final counts (below the run's anchor nothing is picked late), and with
+//                       them the test "wanted at t:  raw(t) + k(t) > A(t) + r(t)" -- the sweep's demand before its clamp,
+//                       the exceptions selected at exactly t, what the buckets above x still offer, the listed
+//                       exceptions above x that are candidates at t.  A selected exception must be wanted at its time
+//                       and not before, an unselected one never: the first time that fails is its open question
+//     k_nu_select_apply settles every open question (select at that time / move earlier / unselect): nadj follows ]
+//   repeated until a round leaves no open question -- then the selection is the greedy's (per contig the
+//   earliest question is settled for good each round, the others tentatively and nearly always rightly) -- then
+//   k_pm_rank_mark for the regular reads and k_nu_mark_selected.
+// The host gives up (and takes the mixed-span route) when a listed exception has no anchor within ell buckets and
+// nothing earlier in its contig is open, when the rounds outrun their budget, when more than a tenth of the reads are
+// exceptions, or when any read is LONGER than the dominant span.
 static constexpr uint32_t kNuUnpicked = 0xFFFFFFFFu;
 static constexpr unsigned long long kNuNoKey = ~0ull;
 // An open question's key: time << 19 | (511 - (end - time)) << 10 | (time - start) << 1 | kind -- earlier time first,
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __r
 static constexpr int kNuStage = 3 * 256 + 16;  // ell <= 256 (the event-driven sweep's limit)
 static constexpr int kNuCur = 2 * 256 + 8;
 __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2* __restrict__ suspects, uint32_t suspects_cap,
-                                                  uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key) {
+                                                  uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
+                                                  const uint32_t* __restrict__ swept_from) {
     __shared__ uint32_t s_b[kNuStage], s_e[kNuStage];
     __shared__ int32_t s_a[kNuStage], s_cur[kNuCur], s_stack[kNuCur];
     __shared__ int32_t o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers], o_above[kNuOthers];
@@ -171,6 +177,9 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
         const int32_t b = e - ell + 1;
         const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
+        // listed for the others' sake only (it ends before what the round swept: its own questions were settled by an
+        // earlier round, on counts that have not changed since)
+        if ((uint64_t)(uint32_t)(e - c0) < (uint64_t)swept_from[contig] * v.ell) continue;
         const int32_t r0 = max(s - 2 * ell, 0);
         const int32_t count = e + 1 - r0 + 1;  // <= 3 ell + 1
         __syncthreads();  // (the previous suspect's reads of the stage are done)
@@ -417,7 +426,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                        first_round ? 1u : 0u);
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from);
-    hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key);
+    hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key, swept_from);
     hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
                        sweep_from_next);
 }
