@@ -574,10 +574,11 @@ uint32_t nu_round_budget(const uint32_t* lengths, uint32_t n_contigs) {
     const double r = 0.5 * walk_ms / round_ms;
     return r < kNuMinRounds ? kNuMinRounds : r > kNuMaxRoundsCap ? kNuMaxRoundsCap : (uint32_t)r;
 }
-// mean coverage / M below which the route is not tried: the shallower the data, the more exceptions are wanted (cfg4's
-// reads with 1 % clipped, lab/near_uniform_depths.py, near-uniform / mixed-span ms: 12.5 x M 8 / 105; 9.4 x M 11 / 290;
-// 6.3 x M 27 / 399; 4.7 x M 49 / 503; 3.75 x M 75 / 662 -- 51 sweeps of a budget of 58)
-constexpr double kNuMinDepth = 3.5;
+// mean coverage / M below which the route is not tried: the shallower the data, the more exceptions are wanted and the
+// longer the runs of used-up buckets (cfg4's reads with 1 % clipped, lab/near_uniform_depths.py, near-uniform /
+// mixed-span ms: 12.5 x M 2.9 / 105; 6.3 x M 6.0 / 401; 4.7 x M 5.5 / 503; 3.75 x M 6.4 / 659; with 40 % of the reads:
+// 5 x M 12.4 / 579; 3 x M 15.7 / 710; 2.1 x M and 1.5 x M: the route gives up after four sweeps, 644 / 625 and 637 / 601)
+constexpr double kNuMinDepth = 2.5;
 uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 128 slots per wave and pass: an eighth of the reads
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));

@@ -92,10 +92,11 @@ def test_gives_way_to_the_mixed_route(pkg, oracle, solver):
     """what the route does not model goes the mixed-span way, same mask: reads LONGER than the dominant span, more
     exceptions than a sixteenth of the reads, data too shallow for it"""
     rng = np.random.default_rng(11)
-    L, n = 40_000, 330_000
+    L = 40_000
     lengths = np.array([L], np.uint32)
-    for kwargs, M in ((dict(fraction=0.01, max_clip=30, longer=5), 100), (dict(fraction=0.2, max_clip=30), 100),
-                      (dict(fraction=0.01, max_clip=30), 400)):
+    for kwargs, M, n in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000),
+                         (dict(fraction=0.2, max_clip=30), 100, 330_000),
+                         (dict(fraction=0.01, max_clip=30), 400, 200_000)):     # 1.9 x M
         s, e, _ = _contigs(rng, [L], [n], 150, **kwargs)
         got = solver.solve(s, e, lengths, M)
         assert np.array_equal(got, oracle.solve(s, e, lengths, M)), (kwargs, M, solver.last_stats.as_dict())
