@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_nu_prepick(NuExc x, const uint32_t* __r
 
 struct NuView {  // what verify and replay read of the sweep's result
     const uint32_t* boff; const uint32_t* selend; const int32_t* nadj; const uint64_t* poff; uint32_t n_contigs, ell, M;
+    const uint32_t* ce;  // exclusive scan of the exceptions' coverage differences: exceptions covering p = ce[p + 1]
 };
 __device__ __forceinline__ uint32_t nu_c(const NuView& v, uint32_t u) { return v.boff[u + 1] - v.boff[u]; }
 __device__ __forceinline__ uint32_t nu_S(const NuView& v, uint32_t u) { return v.selend[u] - v.boff[u]; }
@@ -160,11 +161,11 @@ __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __r
 // [s - 2 ell, e + 1] -- is staged in LDS first (a trip to memory per replayed position would make an exception in a
 // contig's last ell positions, where every bucket is empty and the run is as long as the read, cost half a millisecond).
 static constexpr int kNuStage = 3 * 256 + 16;  // ell <= 256 (the event-driven sweep's limit)
-static constexpr int kNuCur = 2 * 256 + 8;
+static constexpr int kNuCur = 3 * 256 + 8;  // replayed buckets: from an anchor < 2 ell, from a cut point < 3 ell
 __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                   uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
                                                   const uint32_t* __restrict__ swept_from) {
-    __shared__ uint32_t s_b[kNuStage], s_e[kNuStage];
+    __shared__ uint32_t s_b[kNuStage], s_e[kNuStage], s_x[kNuStage];
     __shared__ int32_t s_a[kNuStage], s_cur[kNuCur], s_stack[kNuCur];
     __shared__ int32_t o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers], o_above[kNuOthers];
     __shared__ uint32_t o_n;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             s_b[k] = v.boff[r0 + k];
             s_e[k] = v.selend[r0 + k];
             s_a[k] = v.nadj[r0 + k];
+            s_x[k] = v.ce[r0 + k + 1];
         }
         for (int32_t k = lane; k < kNuCur; k += 64) s_cur[k] = 0;
         if (lane == 0) o_n = 0;
@@ -224,7 +226,16 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         // good (or lies before the contig): nothing below it is picked at or after its own time
         int32_t u1 = b + 1;
         while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < ell) --u1;
+        // No anchor within ell buckets: a CUT POINT does as well.  At a position p with cov_all(p) <= M every read
+        // covering it is kept, so at time p every bucket in (p - ell, p] is used up -- a known state to start from.
+        int32_t cut = -1;
         if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
+            for (int32_t p = s - 1; p > s - ell && p >= c0; --p) {
+                const uint32_t cov_reg = s_b[p + 1 - r0] - s_b[max(p + 1 - ell, 0) - r0];
+                if (cov_reg + s_x[p - r0] <= v.M) { cut = p; break; }
+            }
+        }
+        if (cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) {
             // ell exhausted buckets in a row below the read: not modelled.  That only matters if nothing EARLIER in the
             // contig is wanted: behind a wanted exception the sweep ran on a need it could not meet, and what it left
             // there (often every bucket used up) is replaced by the next round's sweep anyway.  So the read enters the
@@ -240,10 +251,11 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             }
             continue;
         }
-        u1 = max(u1, c0);
+        u1 = cut >= 0 ? cut + 1 : max(u1, c0);
         const int32_t anchor = u1 - 1;
-        const bool has_anchor = anchor >= c0;
-        const int32_t base = has_anchor ? anchor : c0;  // replayed buckets [base, t) keep time-resolved counts in s_cur
+        const bool has_anchor = cut < 0 && anchor >= c0;
+        // replayed buckets [base, t) keep time-resolved counts in s_cur
+        const int32_t base = cut >= 0 ? max(cut - ell + 1, c0) : has_anchor ? anchor : c0;
         auto wave_sum_S = [&](int32_t lo, int32_t hi) {  // final counts of buckets [lo, hi)
             int32_t acc = 0;
             for (int32_t u = lo + lane; u < hi; u += 64) acc += S(u);
@@ -260,7 +272,18 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             s_cur[0] = repl;
             s_stack[n_stack++] = anchor;  // (never used up: that is what makes it the anchor)
         }
-        int32_t fixed = wave_sum_S(max(u1 - ell + 1, 0), base);
+        int32_t fixed = cut >= 0 ? 0 : wave_sum_S(max(u1 - ell + 1, 0), base);
+        if (cut >= 0) {
+            // behind a cut: every bucket of (cut - ell, cut] is used up, nothing older is in any later window
+            int32_t acc = 0;
+            for (int32_t u = base + lane; u <= cut; u += 64) {
+                const int32_t cu = C(u);
+                s_cur[u - base] = cu;
+                if (u > cut + 1 - ell) acc += cu;     // the window of time cut + 1: (cut + 1 - ell, cut + 1)
+            }
+            repl = (int32_t)wave_sum_u32((uint32_t)acc);
+            __syncthreads();
+        }
         int32_t avail = 0;   // what the regular members of the buckets (b, t] still offer
         unsigned long long key = kNuNoKey;
         // A selected exception is checked up to its time (wanted there, and not before); an unselected one over its life.
@@ -307,7 +330,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             // the window moves on: bucket t - ell + 1 leaves it
             const int32_t out = t - ell + 1;
             if (out >= base) repl -= s_cur[out - base];
-            else if (out >= 0) fixed -= S(out);
+            else if (out >= 0 && cut < 0) fixed -= S(out);
         }
         if (lane == 0) {
             x.key[i] = key;
@@ -416,12 +439,13 @@ void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
 }
 void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
-                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
+                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next) {
     const NuExc x = nu_exc_view(exc, cap, n_exc);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
+    v.ce = ce;
     hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs,
                        first_round ? 1u : 0u);
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,

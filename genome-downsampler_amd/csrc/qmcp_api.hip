@@ -577,8 +577,10 @@ uint32_t nu_round_budget(const uint32_t* lengths, uint32_t n_contigs) {
 // mean coverage / M below which the route is not tried: the shallower the data, the more exceptions are wanted and the
 // longer the runs of used-up buckets (cfg4's reads with 1 % clipped, lab/near_uniform_depths.py, near-uniform /
 // mixed-span ms: 12.5 x M 2.9 / 105; 6.3 x M 6.0 / 401; 4.7 x M 5.5 / 503; 3.75 x M 6.4 / 659; with 40 % of the reads:
-// 5 x M 12.4 / 579; 3 x M 15.7 / 710; 2.1 x M and 1.5 x M: the route gives up after four sweeps, 644 / 625 and 637 / 601)
-constexpr double kNuMinDepth = 2.5;
+// 5 x M 12.4 / 579; 3 x M 15.7 / 710; 2.1 x M: gives up after four sweeps, 648 / 627 -- runs of used-up buckets with
+// neither an anchor nor a cut point --; 1.5 x M 41.9 / 600, from cut points).  Below 1.3 x M nearly every window of the
+// mixed-span sweep has a real cut point and that sweep is quick.
+constexpr double kNuMinDepth = 1.3;
 uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 128 slots per wave and pass: an eighth of the reads
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
@@ -973,7 +975,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             }
             {
                 KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
-                qmcp::launch_nu_round(st, exc, cap, n_exc, rounds == 1, boff, selend, nadj, poff, n_contigs, ell, M,
+                qmcp::launch_nu_round(st, exc, cap, n_exc, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
                                       (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
                 std::swap(sweep_from[0], sweep_from[1]);
             }

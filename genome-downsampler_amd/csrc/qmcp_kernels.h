@@ -208,7 +208,8 @@ void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                      const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
                      uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state /* 8 words */);
 void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
-                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint64_t* d_poff, uint32_t n_contigs,
+                     const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce /* launch_nu_setup's */,
+                     const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx,
                      const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,

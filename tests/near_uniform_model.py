@@ -174,7 +174,7 @@ def _priority(e, s, idx):
     return (-e, -s, idx)
 
 
-def _walk(c, S, need, ell, s, e, others, sel_time, L):
+def _walk(c, S, need, ell, s, e, others, sel_time, L, cov_all=None, M=None):
     """the replay of one exception (s, e, its selection time or -1) against the sweep's final counts: returns the
     first (time, kind) at which the sweep and the selection disagree, kind in {"select", "unselect"}; None; or
     "unresolved".  others = [(s, e, idx, sel_time, above?)] exceptions of the same contig whose lives overlap."""
@@ -185,22 +185,38 @@ def _walk(c, S, need, ell, s, e, others, sel_time, L):
     u1 = v + 1
     while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < ell:
         u1 -= 1
+    cut = None
     if u1 - 1 >= 0 and exhausted(u1 - 1):
-        return "unresolved"
-    u1 = max(u1, 0)
-    anchor = u1 - 1
-    base = anchor if anchor >= 0 else 0
-    cur = np.zeros(e - base + 2, np.int64)
+        # no anchor within ell buckets.  A CUT POINT does as well: at a position p* with cov_all(p*) <= M every read
+        # covering it is kept, so at time p* every bucket in (p* - ell, p*] is used up -- a known state to start from
+        if cov_all is not None:
+            for p in range(s - 1, max(s - ell, -1), -1):
+                if cov_all[p] <= M:
+                    cut = p
+                    break
+        if cut is None:
+            return "unresolved"
+    if cut is not None:
+        base = max(cut - ell + 1, 0)
+        cur = np.zeros(e - base + 2, np.int64)
+        cur[:cut - base + 1] = c[base:cut + 1]
+        u1 = cut + 1
+        anchor = -1
+    else:
+        u1 = max(u1, 0)
+        anchor = u1 - 1
+        base = anchor if anchor >= 0 else 0
+        cur = np.zeros(e - base + 2, np.int64)
+        if anchor >= 0:
+            lo = max(0, anchor - ell + 1)
+            d = int(need[anchor]) - int(S[lo:anchor].sum())
+            cur[0] = min(max(d, 0), int(c[anchor]))
     avail = 0
-    if anchor >= 0:
-        lo = max(0, anchor - ell + 1)
-        d = int(need[anchor]) - int(S[lo:anchor].sum())
-        cur[0] = min(max(d, 0), int(c[anchor]))
     t = u1
     last = e if sel_time < 0 else sel_time
     while t <= last and t < L:
         lo = max(0, t - ell + 1)
-        fixed = int(S[lo:base].sum()) if base > lo else 0
+        fixed = int(S[lo:base].sum()) if (base > lo and cut is None) else 0   # (behind a cut nothing older matters)
         repl = int(cur[max(lo, base) - base:t - base].sum())
         raw = int(need[t]) - fixed - repl      # (may be negative: a selection that was not needed leaves a surplus)
         d = max(raw, 0)
@@ -267,7 +283,7 @@ def solve_near_uniform_batched(starts, ends, L, M, ell, max_rounds=200):
                 if z == x or xe[z] < s or xs[z] > e:
                     continue
                 others.append((int(xs[z]), int(xe[z]), int(exc[z]), int(sel[z]), _priority(int(xe[z]), int(xs[z]), int(exc[z])) < px))
-            r = _walk(c, S, need, ell, s, e, others, int(sel[x]), L)
+            r = _walk(c, S, need, ell, s, e, others, int(sel[x]), L, cov_all, M)
             if r == "unresolved":
                 open_q.append(((s, (1 << 40, 0, 0)), x, "unresolved"))
             elif r is not None:

@@ -96,7 +96,7 @@ def test_gives_way_to_the_mixed_route(pkg, oracle, solver):
     lengths = np.array([L], np.uint32)
     for kwargs, M, n in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000),
                          (dict(fraction=0.2, max_clip=30), 100, 330_000),
-                         (dict(fraction=0.01, max_clip=30), 400, 200_000)):     # 1.9 x M
+                         (dict(fraction=0.01, max_clip=30), 400, 135_000)):     # 1.27 x M
         s, e, _ = _contigs(rng, [L], [n], 150, **kwargs)
         got = solver.solve(s, e, lengths, M)
         assert np.array_equal(got, oracle.solve(s, e, lengths, M)), (kwargs, M, solver.last_stats.as_dict())
@@ -113,6 +113,19 @@ def test_many_wanted_exceptions(pkg, oracle, solver):
     st = solver.last_stats
     assert np.array_equal(got, oracle.solve(s, e, lengths, 100, offs)), st.as_dict()
     assert st.path in (pkg.PATH_NEAR_UNIFORM, pkg.PATH_GENERAL)
+
+
+def test_shallow_data_starts_from_cut_points(pkg, oracle, solver):
+    """1.5 - 2 x M: runs of used-up buckets longer than a span; the replays start from cut points (cov_all <= M) where
+    there is no anchor -- or the route gives way; the oracle's mask either way"""
+    rng = np.random.default_rng(29)
+    lengths = np.array([60_000, 45_000], np.uint32)
+    for M in (250, 330):
+        s, e, offs = _contigs(rng, lengths, [300_000, 230_000], 150, 0.02, 40)
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        st = solver.last_stats
+        assert np.array_equal(got, oracle.solve(s, e, lengths, M, offs)), (M, st.as_dict())
+        assert st.path in (pkg.PATH_NEAR_UNIFORM, pkg.PATH_GENERAL)
 
 
 def test_env_switch_off(pkg, oracle, solver):
