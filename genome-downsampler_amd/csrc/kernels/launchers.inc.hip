@@ -16,9 +16,11 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                     const uint64_t* keep_mask, uint32_t* gstart, uint32_t* cstart,
                     uint32_t* stats, uint32_t part_shift, uint32_t* part_hist,
-                    uint32_t* digit0_hist, uint32_t* global_digit_hist, unsigned long long* zero_mask) {
+                    uint32_t* digit0_hist, uint32_t* global_digit_hist, unsigned long long* zero_mask,
+                    uint32_t ell_reg, uint32_t* exc, uint32_t exc_cap, uint32_t* exc_cnt) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
+    if (exc == nullptr) ell_reg = 0;
     uint32_t g = tiles_per_block_for(n_tiles);
     // the partition table has one entry per pass (a pair of tiles) and rows padded to part_pass_pitch(n):
     // a workgroup takes whole passes, and the workgroups cover the padding too (empty tiles: zero counts)
@@ -26,8 +28,12 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
     const uint32_t covered = part_hist ? 2u * part_pass_pitch(n) : n_tiles;
     hipLaunchKernelGGL(k_prepare, dim3((covered + g - 1) / g), dim3(256), 0, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, keep_mask, gstart, cstart, stats, n_tiles, g,
-                       part_shift, part_hist, part_pass_pitch(n), digit0_hist, global_digit_hist, zero_mask);
+                       part_shift, part_hist, part_pass_pitch(n), digit0_hist, global_digit_hist, zero_mask,
+                       ell_reg, exc, exc_cap, exc_cnt);
+    if (ell_reg != 0u)  // stats[4] = exceptions listed
+        hipLaunchKernelGGL(k_nu_count_groups, dim3(32), dim3(256), 0, st, exc_cnt, n_tiles * 4u, stats);
 }
+uint32_t prepare_exc_slots(uint32_t n) { return sort_tiles(n) * 4u * 128u; }  // the list's slots on this form (128 per wave and tile)
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
@@ -488,18 +494,20 @@ static void launch_partition_t(hipStream_t st, dim3 grid, const uint32_t* keys, 
                                SegTables seg, const uint64_t* d_roff, const uint64_t* d_poff,
                                uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles,
                                const uint32_t* offs, uint16_t* k16, uint32_t* idx, Rec* out_rec,
-                               uint32_t* range_start, uint32_t* max_load) {
+                               uint32_t* range_start, uint32_t* max_load, const uint32_t* ends = nullptr,
+                               uint32_t ell_reg = 0) {
     (void)hipFuncSetAttribute((const void*)k_range_partition<MODE, OUT_REC>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLds);
     hipLaunchKernelGGL((k_range_partition<MODE, OUT_REC>), grid, dim3(kPartThreads), kPartLds, st, keys,
                        recs_in, seg, d_roff, d_poff, n_contigs, n, shift, n_tiles, offs, k16, idx, out_rec,
-                       range_start, max_load);
+                       range_start, max_load, ends, ends != nullptr ? ell_reg : 0u);
 }
 
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
-                            uint32_t* idx_out, uint32_t* range_start, uint32_t* max_load) {
+                            uint32_t* idx_out, uint32_t* range_start, uint32_t* max_load, const uint32_t* ends,
+                            uint32_t ell_reg) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles);
@@ -509,7 +517,7 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
                                      part_pass_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
     else
         launch_partition_t<1, false>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift,
-                                     part_pass_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load);
+                                     part_pass_pitch(n), offs, keys16_out, idx_out, nullptr, range_start, max_load, ends, ell_reg);
 }
 
 // Two-level route.  Level 1: stable partition of the reads into <= 256 super-ranges of 2^(shift+8)
@@ -517,14 +525,14 @@ void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, cons
 void launch_partition_level1(hipStream_t st, const uint32_t* starts, const uint64_t* d_roff,
                              const uint64_t* d_poff, uint32_t n_contigs, uint32_t n, uint32_t shift_hi,
                              const uint32_t* offs, void* recs_out, uint32_t* super_start,
-                             uint32_t* max_super_load) {
+                             uint32_t* max_super_load, const uint32_t* ends, uint32_t ell_reg) {
     const uint32_t n_tiles = sort_tiles(n);
     if (n_tiles == 0) return;
     const dim3 grid((n_tiles + kPartTiles - 1) / kPartTiles);
     const SegTables none{nullptr, nullptr, nullptr};
     launch_partition_t<1, true>(st, grid, starts, nullptr, none, d_roff, d_poff, n_contigs, n, shift_hi,
                                 part_pass_pitch(n), offs, nullptr, nullptr, (Rec*)recs_out, super_start,
-                                max_super_load);
+                                max_super_load, ends, ell_reg);
 }
 // Level 2: every super-range is partitioned on its own into its (<= 256) final ranges.
 // tables: [0,257) super_start  [257,514) tile_base  [514,771) pass_base (written here)

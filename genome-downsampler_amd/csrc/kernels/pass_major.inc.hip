@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words.  Every wave
     // of every pass owns kPmExcPerWave slots of the list (pass P, wave w: from (8 P + w) * 128) and says how many it
     // filled in exc_cnt[8 P + w]: no counter is shared (24 k same-address atomics, one per wave, took longer than
-    // the whole kernel: 0.32 -> 0.69 ms); k_pm_count_exceptions adds the groups up into stats[4] afterwards.  stats[5]
+    // the whole kernel: 0.32 -> 0.69 ms); k_nu_count_groups adds the groups up into stats[4] afterwards.  stats[5]
     // is set if a wave met more than its slots hold (the list is then incomplete).  ell_reg == 0: every read is regular.
     uint32_t ell_reg, uint32_t* __restrict__ exc, uint32_t exc_cap, uint32_t* __restrict__ exc_cnt) {
     extern __shared__ uint32_t s_pm[];
@@ -265,15 +265,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         if (mx > __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats[1], mx);
         if (bad) atomicOr(&stats[2], 1u);
     }
-}
-
-// stats[4] = exceptions listed (the sum of the groups' counts)
-__global__ __launch_bounds__(256) void k_pm_count_exceptions(const uint32_t* __restrict__ exc_cnt, uint32_t n_groups,
-                                                             uint32_t* __restrict__ stats) {
-    uint32_t acc = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += gridDim.x * blockDim.x) acc += exc_cnt[i];
-    acc = wave_sum_u32(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0u) atomicAdd(&stats[4], acc);
 }
 
 // where every range begins in flat coordinates (257 entries) and the heaviest range's load, from the scanned table
@@ -694,7 +685,7 @@ void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32
                        d_roff, d_poff, n_contigs, shift, keys16, idx16, cnt_tab, lst_tab, pitch, stats, zero_mask,
                        exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
     if (exc != nullptr && ell_reg != 0u)
-        hipLaunchKernelGGL(k_pm_count_exceptions, dim3(32), dim3(256), 0, st, exc_cnt, pitch * kPmWaves, stats);
+        hipLaunchKernelGGL(k_nu_count_groups, dim3(32), dim3(256), 0, st, exc_cnt, pitch * kPmWaves, stats);
 }
 void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load) {
     hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, T, pm_pitch(n), n, range_start, max_load);

@@ -20,7 +20,15 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                                                  uint32_t* __restrict__ part_hist, uint32_t part_pitch,
                                                  uint32_t* __restrict__ digit0_hist,
                                                  uint32_t* __restrict__ global_digit_hist,
-                                                 unsigned long long* __restrict__ zero_mask) {
+                                                 unsigned long long* __restrict__ zero_mask,
+                                                 // near-uniform route (kernels/near_uniform.inc.hip) on the range-major
+                                                 // form: reads whose span is not ell_reg are left out of the partition
+                                                 // histogram (the partition skips them too) and listed -- every wave
+                                                 // of every tile owns 128 slots of the list (tile t, wave w: from
+                                                 // (4 t + w) * 128) and writes how many it filled; stats[5] is set if a
+                                                 // wave met more.  ell_reg == 0: every read is regular.
+                                                 uint32_t ell_reg, uint32_t* __restrict__ exc, uint32_t exc_cap,
+                                                 uint32_t* __restrict__ exc_cnt) {
     __shared__ uint32_t s_gh[4][256];  // whole-call digit histograms of the start key (all 4 bytes)
     if (global_digit_hist) {
         for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_gh[0][0])[i] = 0;
@@ -34,6 +42,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
     // worth of evicted lines (that cost 8x the table's size in HBM writes)
     __shared__ uint32_t s_ph[4][256];
     __shared__ uint32_t s_h0[256];
+    __shared__ uint32_t s_fill[4];  // near-uniform route, tiles off the lean path: exceptions a wave has listed
     if (part_hist)
         for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&s_ph[0][0])[i] = 0;
     const uint32_t nc = min(n_contigs, 64u);
@@ -97,6 +106,21 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             tile_len = (uint32_t)(p1 - p0);
         }
         const uint32_t tile_last = tile_len ? tile_len - 1u : 0u;
+        uint32_t filled = 0;  // (uniform over the wave) exceptions of this tile the wave has listed
+        if (ell_reg != 0u && (threadIdx.x & 63u) == 0u) s_fill[threadIdx.x >> 6] = 0;
+        const size_t slot0 = ((size_t)tile * 4u + (threadIdx.x >> 6)) * 128u;
+        auto list_exception = [&](bool isx, uint32_t gs, uint32_t ge, uint32_t i) {
+            const uint64_t m = __ballot(isx);
+            if (m != 0ull) {  // (uniform)
+                const uint32_t slot = filled + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (isx && slot < 128u) {
+                    exc[slot0 + slot] = gs;
+                    exc[exc_cap + slot0 + slot] = ge;
+                    exc[2 * (size_t)exc_cap + slot0 + slot] = i;
+                }
+                filled += (uint32_t)__popcll(m);
+            }
+        };
         // the ranked route's whole tiles inside one contig (all but a handful): validate, span range and
         // the partition digit, nothing else and no branch per read (an invalid read makes the call fail;
         // what its span adds to the statistics is then never looked at)
@@ -117,8 +141,10 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 // (a start beyond the contig -- the call will fail -- is counted at the contig's last position,
                 //  as the partition queued behind this kernel will place it: k_range_partition)
                 const uint32_t d = ((tile_p0 + min(s, tile_last)) >> part_shift) & 255u;
+                const bool isx = ell_reg != 0u && span != ell_reg;
+                if (ell_reg != 0u) list_exception(isx, tile_p0 + min(s, tile_last), tile_p0 + min(e, tile_last), tbase + k * 256u + threadIdx.x);
                 if (few_digits) {
-                    uint64_t rest = ~0ull;  // (every lane holds a read: the tile is whole)
+                    uint64_t rest = ~__ballot(isx);  // (every lane holds a read: the tile is whole; exceptions are not counted)
                     for (int round = 0; round < 4 && rest != 0; ++round) {
                         const int first = __ffsll((long long)rest) - 1;
                         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                     }
                     // (an invalid start can fall outside the contig's digits: whatever is left goes one by one)
                     if ((rest >> (threadIdx.x & 63u)) & 1ull) atomicAdd(&s_h[d], 1u);
-                } else {
+                } else if (!isx) {
                     atomicAdd(&s_h[d], 1u);
                 }
             }
@@ -161,7 +187,17 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             mn = min(mn, span);
             mx = max(mx, span);
             if (gstart_out) gstart_out[i] = gs;
-            if (part_hist) {
+            const bool isx = ell_reg != 0u && span != ell_reg;
+            if (isx) {
+                // (tiles off the lean path are a handful: a slot per exception from the wave's LDS counter)
+                const uint32_t slot = atomicAdd(&s_fill[threadIdx.x >> 6], 1u);
+                if (slot < 128u) {
+                    exc[slot0 + slot] = gs;
+                    exc[exc_cap + slot0 + slot] = pos0 + e;
+                    exc[2 * (size_t)exc_cap + slot0 + slot] = i;
+                }
+            }
+            if (part_hist && !isx) {
                 atomicAdd(&s_h[(gs >> part_shift) & 255u], 1u);
                 if (digit0_hist) atomicAdd(&s_h0[gs & 255u], 1u);
             }
@@ -176,6 +212,13 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                 bool on = true;
                 if (keep_mask) on = (keep_mask[i >> 6] >> (i & 63)) & 1ull;
                 if (on) atomicAdd(&cstart[gs], 1u);
+            }
+        }
+        if (ell_reg != 0u) {
+            if (!lean) filled = s_fill[threadIdx.x >> 6];
+            if ((threadIdx.x & 63u) == 0u) {
+                exc_cnt[tile * 4u + (threadIdx.x >> 6)] = min(filled, 128u);
+                if (filled > 128u) atomicOr(&stats[5], 1u);
             }
         }
         if (part_hist && digit0_hist) {
@@ -227,6 +270,15 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             atomicMax(&stats[1], mx);
         if (bad) atomicOr(&stats[2], 1u);
     }
+}
+
+// stats[4] = exceptions listed (the sum of the groups' counts)
+__global__ __launch_bounds__(256) void k_nu_count_groups(const uint32_t* __restrict__ exc_cnt, uint32_t n_groups,
+                                                             uint32_t* __restrict__ stats) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += gridDim.x * blockDim.x) acc += exc_cnt[i];
+    acc = wave_sum_u32(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0u) atomicAdd(&stats[4], acc);
 }
 
 // Mixed-span path: per-position end counts and the composite bucketing key

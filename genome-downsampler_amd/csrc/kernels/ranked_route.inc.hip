@@ -89,7 +89,10 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     uint32_t n_contigs, uint32_t n, uint32_t shift, uint32_t n_tiles /* row pitch of offs (MODE 0/1: in passes) */,
     const uint32_t* __restrict__ offs,
     uint16_t* __restrict__ out_key, uint32_t* __restrict__ out_idx, Rec* __restrict__ out_rec,
-    uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
+    uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load,
+    // near-uniform route (MODE 1): reads whose span is not ell_reg are left out, as k_prepare left them out of the
+    // table (which then holds the listed records' total behind its last row: the scan's total)
+    const uint32_t* __restrict__ ends, uint32_t ell_reg) {
     extern __shared__ uint32_t s_part[];
     Rec* s_rec = reinterpret_cast<Rec*>(s_part);                       // [kPartRecs]
     uint32_t* s_cnt = s_part + 2 * kPartRecs;                          // [kPartWaves][256]
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     const uint32_t wbase = base + w * (kSortItems * 64);
     Rec rec[kSortItems];
     uint32_t rank[kSortItems];
+    uint32_t skip = 0;  // bit k: the thread's k-th read is an exception (left out)
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         } else {
             rec[k].key = i < bound ? keys[i] : 0u;
             rec[k].val = i;
+            if (MODE == 1 && ell_reg != 0u && i < bound && ends[i] - rec[k].key + 1u != ell_reg) skip |= 1u << k;
         }
     }
     for (int i = threadIdx.x; i < kPartWaves * 256; i += kPartThreads) s_cnt[i] = 0;
@@ -145,10 +150,12 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
         uint32_t load = 0;
         if (threadIdx.x < 256) {
             const uint32_t d = threadIdx.x;
+            // (behind the last row: the scan's total -- the records listed, fewer than n on the near-uniform route)
+            const uint32_t total = ell_reg != 0u ? offs[256u * n_tiles] : n;
             const uint32_t r_lo = offs[d * n_tiles];
-            const uint32_t r_hi = d + 1 < 256 ? offs[(d + 1) * n_tiles] : n;
+            const uint32_t r_hi = d + 1 < 256 ? offs[(d + 1) * n_tiles] : total;
             range_start[d] = r_lo;
-            if (d == 255) range_start[256] = n;
+            if (d == 255) range_start[256] = total;
             load = r_hi - r_lo;
         }
         load = wave_max_u32(load);
@@ -210,15 +217,15 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
     {
         uint32_t* const s_cnt_w = s_cnt + w * 256;
         switch (match_bits) {  // uniform
-            case 0: part_rank_rounds<0>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 1: part_rank_rounds<1>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 2: part_rank_rounds<2>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 3: part_rank_rounds<3>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 4: part_rank_rounds<4>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 5: part_rank_rounds<5>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 6: part_rank_rounds<6>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            case 7: part_rank_rounds<7>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
-            default: part_rank_rounds<8>(rec, rank, wbase, bound, shift, lane, s_cnt_w); break;
+            case 0: part_rank_rounds<0>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 1: part_rank_rounds<1>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 2: part_rank_rounds<2>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 3: part_rank_rounds<3>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 4: part_rank_rounds<4>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 5: part_rank_rounds<5>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 6: part_rank_rounds<6>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            case 7: part_rank_rounds<7>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
+            default: part_rank_rounds<8>(rec, rank, wbase, bound, shift, lane, s_cnt_w, skip); break;
         }
     }
     __syncthreads();
@@ -249,16 +256,18 @@ __global__ __launch_bounds__(kPartThreads) void k_range_partition(
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = wbase + k * 64 + lane;
-        if (i < bound) {
+        if (i < bound && !((skip >> k) & 1u)) {
             const uint32_t d = (rec[k].key >> shift) & 255u;
             s_rec[s_cnt[w * 256 + d] + rank[k]] = rec[k];
         }
     }
+    // records staged: the pass's, less the exceptions (the four waves' digit totals, from the scan above)
+    const uint32_t staged = (MODE == 1 && ell_reg != 0u) ? s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3] : count;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t j = k * kPartThreads + threadIdx.x;
-        if (j < count) {
+        if (j < staged) {
             const Rec r = s_rec[j];
             const uint32_t dst = s_gbase[(r.key >> shift) & 255u] + j;
             if (OUT_REC) {
@@ -330,7 +339,8 @@ __global__ __launch_bounds__(256) void k_seg_range_table(const uint32_t* __restr
     const uint32_t hi = d + 1 < 256 ? (t_h ? scanned[row + (d + 1) * t_h] : seg.super_start[h])
                                     : seg.super_start[h + 1];
     range_start[h * 256u + d] = lo;
-    if (h == 255 && d == 255) range_start[65536] = n;
+    if (h == 255 && d == 255) range_start[65536] = seg.super_start[256];  // (the records listed: n, or fewer on the near-uniform route)
+    (void)n;
     const uint32_t m = wave_max_u32(hi - lo);
     if ((d & 63) == 0) s_red[d >> 6] = m;
     __syncthreads();

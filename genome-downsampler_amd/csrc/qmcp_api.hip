@@ -581,7 +581,10 @@ uint32_t nu_round_budget(const uint32_t* lengths, uint32_t n_contigs) {
 // neither an anchor nor a cut point --; 1.5 x M 41.9 / 600, from cut points).  Below 1.3 x M nearly every window of the
 // mixed-span sweep has a real cut point and that sweep is quick.
 constexpr double kNuMinDepth = 1.3;
-uint32_t nu_cap_for(uint32_t n) { return qmcp::pm_exc_slots(n); }  // 128 slots per wave and pass: an eighth of the reads
+uint32_t nu_cap_for(uint32_t n) {  // 128 slots per wave and pass (or tile): an eighth of the reads, on either producer
+    const uint32_t a = qmcp::pm_exc_slots(n), b = qmcp::prepare_exc_slots(n);
+    return a > b ? a : b;
+}
 int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_contigs) {
     TRY(ensure(c, c->nu_exc, qmcp::nu_exc_bytes(nu_cap_for(n))));
     TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
@@ -592,6 +595,8 @@ int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_c
     if (!c->h_nu) HIP_TRY(hipHostMalloc((void**)&c->h_nu, 8 * sizeof(uint32_t), hipHostMallocDefault));
     return QMCP_OK;
 }
+
+int queue_rm_head(qmcp_hip_ctx* c, hipStream_t s1, uint32_t filter, bool clear_mask);
 
 // The pass-major form of the range-ranked route keeps, per range, the row of the passes that can hold its records
 // in LDS: those of the contigs whose positions overlap the range (kernels/pass_major.inc.hip: pm_relevant_passes,
@@ -740,7 +745,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         static const uint32_t init[8] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
         run.pm = !two_level && pm_rows_fit(roff, pr, range_shift, c->h_pm_rows);
-        run.nu_filter = run.pm && !c->is_kid ? c->nu_ell : 0u;
+        run.nu_filter = !c->is_kid ? c->nu_ell : 0u;
         hs[5] = hs[6] = 0;
         if (run.pm) {
             HIP_TRY(hipMemcpyAsync(c->pm_rows.p, c->h_pm_rows, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s1));
@@ -764,57 +769,16 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
                                             (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, true);
                 qmcp::launch_pm_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
             }
-        } else {
-        {
-            KernelSpan sp(c, "k_prepare");
-            qmcp::launch_prepare(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p,
-                                 (const uint64_t*)c->poff.p, n_contigs, nullptr, nullptr, nullptr,
-                                 (uint32_t*)c->stats.p, two_level ? range_shift + 8 : range_shift,
-                                 (uint32_t*)c->hist2.p, nullptr, nullptr,
-                                 mask_cleared ? nullptr : (unsigned long long*)d_mask);  // also clears the keep mask
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
-        {
-            KernelSpan sp(c, "scan_radix_hist(3 kernels)");
-            qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::part_pass_pitch(n),
-                                        (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, false);
-        }
-        }
-        if (run.pm) {
-            // (nothing: the pass-major form has no partition)
-        } else if (!two_level) {
-            KernelSpan sp(c, "k_range_partition");
-            qmcp::launch_range_partition(s1, nullptr, d_starts, (const uint64_t*)c->roff.p,
-                                         (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
-                                         (const uint32_t*)c->hist2.p, (uint16_t*)c->keys[0].p,
-                                         (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
-        } else {
-            // more than 256 ranges (genomes beyond 8.39 M positions): first into <= 256 super-ranges as
-            // {global start, index} records, then every super-range into its final ranges
+            HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
             {
-                KernelSpan sp(c, "k_range_partition(level 1)");
-                qmcp::launch_partition_level1(s1, d_starts, (const uint64_t*)c->roff.p,
-                                              (const uint64_t*)c->poff.p, n_contigs, n, range_shift + 8,
-                                              (const uint32_t*)c->hist2.p, c->keys[1].p, d_seg_tables, d_max_load);
+                KernelSpan sp(c, "k_pm_offsets");
+                qmcp::launch_pm_offsets(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p,
+                                        n, (const uint32_t*)c->pm_rows.p, range_shift, ltot,
+                                        (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
             }
-            KernelSpan sp(c, "partition level 2 (tables, hist, scan, scatter)");
-            qmcp::launch_partition_level2(s1, c->keys[1].p, n, range_shift, d_seg_tables, (uint32_t*)c->hist.p,
-                                          (uint32_t*)c->spine.p, (uint16_t*)c->keys[0].p,
-                                          (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
-        }
-        HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
-        if (run.pm) {
-            KernelSpan sp(c, "k_pm_offsets");
-            qmcp::launch_pm_offsets(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p,
-                                    n, (const uint32_t*)c->pm_rows.p, range_shift, ltot,
-                                    (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
         } else {
-            // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan; it also
-            // counts the positions that start no read (stats word 3: the host picks the sweep kernel by it)
-            KernelSpan sp(c, "k_range_offsets");
-            qmcp::launch_range_offsets(s1, (const uint16_t*)c->keys[0].p, d_range_start, range_shift, ltot,
-                                       (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
+            // the range-major form: k_prepare, scan, partition (one or two levels), bucket offsets
+            TRY(queue_rm_head(c, s1, run.nu_filter, !mask_cleared));
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_head, s1));  // a contig group's head: the next group's may start
@@ -833,6 +797,71 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         run.ranked_counted = true;
     }
     run.head_done = true;
+    return QMCP_OK;
+}
+
+// The range-major head's stages on `st`: k_prepare (span statistics, partition table; regular reads: span == filter, or
+// every read when filter == 0), scan, the partition (one level, or two for genomes beyond 8.39 M positions), bucket
+// offsets.  Used by enqueue_head and, for a call whose head ran with the wrong idea of the spans, again by the tail.
+int queue_rm_head(qmcp_hip_ctx* c, hipStream_t s1, uint32_t filter, bool clear_mask) {
+    SolveRun& run = c->run;
+    const uint32_t n = (uint32_t)run.pr.n, ltot = (uint32_t)run.pr.ltot, n_contigs = run.n_contigs;
+    const uint32_t range_shift = run.range_shift;
+    const bool two_level = run.two_level;
+    uint32_t* d_range_start = (uint32_t*)c->ranges.p;
+    uint32_t* d_max_load = d_range_start + 65540;
+    uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
+    uint32_t* exc = filter ? (uint32_t*)c->nu_exc.p : nullptr;
+    const uint32_t cap = nu_cap_for(n);
+    uint32_t* exc_cnt = filter ? qmcp::nu_exc_counts(exc, cap) : nullptr;
+    if (filter) HIP_TRY(hipMemsetAsync(exc_cnt, 0, ((size_t)cap / 128 + 4) * sizeof(uint32_t), s1));
+    {
+        KernelSpan sp(c, "k_prepare");
+        qmcp::launch_prepare(s1, run.d_starts, run.d_ends, n, (const uint64_t*)c->roff.p,
+                             (const uint64_t*)c->poff.p, n_contigs, nullptr, nullptr, nullptr,
+                             (uint32_t*)c->stats.p, two_level ? range_shift + 8 : range_shift,
+                             (uint32_t*)c->hist2.p, nullptr, nullptr,
+                             clear_mask ? (unsigned long long*)run.d_mask : nullptr,  // also clears the keep mask
+                             filter, exc, cap, exc_cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
+    {
+        KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+        qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::part_pass_pitch(n),
+                                    (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, true);
+    }
+    if (!two_level) {
+        KernelSpan sp(c, "k_range_partition");
+        qmcp::launch_range_partition(s1, nullptr, run.d_starts, (const uint64_t*)c->roff.p,
+                                     (const uint64_t*)c->poff.p, n_contigs, n, range_shift,
+                                     (const uint32_t*)c->hist2.p, (uint16_t*)c->keys[0].p,
+                                     (uint32_t*)c->vals[0].p, d_range_start, d_max_load, run.d_ends, filter);
+    } else {
+        // more than 256 ranges (genomes beyond 8.39 M positions): first into <= 256 super-ranges as
+        // {global start, index} records, then every super-range into its final ranges
+        {
+            KernelSpan sp(c, "k_range_partition(level 1)");
+            qmcp::launch_partition_level1(s1, run.d_starts, (const uint64_t*)c->roff.p,
+                                          (const uint64_t*)c->poff.p, n_contigs, n, range_shift + 8,
+                                          (const uint32_t*)c->hist2.p, c->keys[1].p, d_seg_tables, d_max_load,
+                                          run.d_ends, filter);
+        }
+        KernelSpan sp(c, "partition level 2 (tables, hist, scan, scatter)");
+        qmcp::launch_partition_level2(s1, c->keys[1].p, n, range_shift, d_seg_tables, (uint32_t*)c->hist.p,
+                                      (uint32_t*)c->spine.p, (uint16_t*)c->keys[0].p,
+                                      (uint32_t*)c->vals[0].p, d_range_start, d_max_load);
+    }
+    HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
+    {
+        // per-range LDS histogram scanned in place: bucket offsets without a genome-wide scan; it also
+        // counts the positions that start no read (stats word 3: the host picks the sweep kernel by it)
+        KernelSpan sp(c, "k_range_offsets");
+        qmcp::launch_range_offsets(s1, (const uint16_t*)c->keys[0].p, d_range_start, range_shift, ltot,
+                                   (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
+    }
+    HIP_TRY(hipGetLastError());
+    run.nu_filter = filter;
     return QMCP_OK;
 }
 
@@ -891,9 +920,17 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                      (int)run.may_rank, (int)c->is_kid, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
     double min_depth = kNuMinDepth;
     if (const char* e = std::getenv("QMCP_HIP_NEAR_MIN_DEPTH")) min_depth = std::strtod(e, nullptr);  // (lab)
-    if (!run.pm || !run.may_rank || c->is_kid || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
+    if (!run.may_rank || c->is_kid || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
         depth < min_depth || min_span == 0)
         return QMCP_OK;
+    {
+        // The route's sweep is one chain per contig (the event-driven form).  On data deeper than 11 x M that is what
+        // the one-span route runs too; shallower, the one-span and mixed-span routes split contigs into stretches, and a
+        // whole chain per round only pays while contigs are short (cfg4's 10^6 positions at 1.5 x M: 7 ms a sweep).
+        uint32_t longest = 0;
+        for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
+        if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;
+    }
     hipStream_t st = c->stream;
     const uint32_t cap = nu_cap_for(n);
     uint32_t n_exc = 0;
@@ -913,7 +950,8 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         if (n_exc > n / 10u) { c->nu_ell = 0; return QMCP_OK; }
         // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
         c->nu_ell = ell;
-        TRY(queue_pm_head(c, st, ell));
+        if (run.pm) TRY(queue_pm_head(c, st, ell));
+        else TRY(queue_rm_head(c, st, ell, !run.mask_cleared));
         uint32_t* d_max_load = (uint32_t*)c->ranges.p + 65540;
         HIP_TRY(hipMemcpyAsync(c->h_nu, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(c->h_nu + 1, d_stats + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1002,12 +1040,18 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     local.near_uniform_selected = c->h_nu[3];
     if (!settled) return QMCP_OK;
     HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], st));
-    {
+    if (run.pm) {
         KernelSpan sp(c, "k_pm_rank_mark");
         qmcp::launch_pm_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p, (const uint32_t*)c->hist2.p,
                                   (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, boff, selend,
                                   (unsigned long long*)run.d_mask, (unsigned long long*)c->scalars.p, c->rankamb.p,
                                   qmcp::rank_scratch_by_records(run.range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
+    } else {
+        KernelSpan sp(c, "k_rank_mark");
+        qmcp::launch_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->ranges.p,
+                               run.range_shift, ltot, boff, selend, (unsigned long long*)run.d_mask,
+                               (unsigned long long*)c->scalars.p, c->rankamb.p,
+                               qmcp::rank_scratch_by_records(run.range_shift, ltot, n), run.mask_bit0);
     }
     {
         KernelSpan sp(c, "k_nu_mark_selected");
@@ -1100,7 +1144,8 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
     if (uniform && run.nu_filter != 0 && run.nu_filter != max_span) {
         // the head listed every read as an exception to the last call's span: its stages again, unfiltered
         c->nu_ell = 0;
-        TRY(queue_pm_head(c, c->stream, 0));
+        if (run.pm) TRY(queue_pm_head(c, c->stream, 0));
+        else TRY(queue_rm_head(c, c->stream, 0, !run.mask_cleared));
         HIP_TRY(hipMemcpyAsync(c->h_nu, (uint32_t*)c->ranges.p + 65540, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         max_load_now = c->h_nu[0];

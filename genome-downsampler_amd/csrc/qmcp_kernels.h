@@ -20,7 +20,10 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
                     uint32_t* part_hist /* digit-major [256][tiles] of (gstart >> part_shift), or null */,
                     uint32_t* digit0_hist /* same shape, low byte of gstart; needs part_hist; or null */,
                     uint32_t* global_digit_hist /* [4][256] whole-call digit counts of gstart, or null */,
-                    unsigned long long* zero_mask /* keep mask to clear (ceil(n/64) words), or null */);
+                    unsigned long long* zero_mask /* keep mask to clear (ceil(n/64) words), or null */,
+                    uint32_t ell_reg = 0, uint32_t* exc = nullptr, uint32_t exc_cap = 0, uint32_t* exc_cnt = nullptr
+                    /* near-uniform route on the range-major form: see k_prepare */);
+uint32_t prepare_exc_slots(uint32_t n);  // slots of the exception list when k_prepare fills it (groups of 128 per wave and tile)
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,
                          const uint64_t* keep_mask, void* keys, uint32_t* ecnt,
@@ -157,7 +160,7 @@ uint32_t seg_tile_bound(uint32_t n);
 void launch_partition_level1(hipStream_t st, const uint32_t* starts, const uint64_t* d_roff,
                              const uint64_t* d_poff, uint32_t n_contigs, uint32_t n, uint32_t shift_hi,
                              const uint32_t* offs, void* recs_out, uint32_t* super_start,
-                             uint32_t* max_super_load);
+                             uint32_t* max_super_load, const uint32_t* ends = nullptr, uint32_t ell_reg = 0);
 void launch_partition_level2(hipStream_t st, const void* recs_in, uint32_t n, uint32_t shift,
                              uint32_t* tables /* 771 words */, uint32_t* hist, uint32_t* spine,
                              uint16_t* keys16_out, uint32_t* idx_out, uint32_t* range_start /* 65537 */,
@@ -165,7 +168,8 @@ void launch_partition_level2(hipStream_t st, const void* recs_in, uint32_t n, ui
 void launch_range_partition(hipStream_t st, const uint32_t* gstart_or_null, const uint32_t* starts,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs,
                             uint32_t n, uint32_t shift, const uint32_t* offs, uint16_t* keys16_out,
-                            uint32_t* idx_out, uint32_t* range_start /* [257] */, uint32_t* max_load);
+                            uint32_t* idx_out, uint32_t* range_start /* [257] */, uint32_t* max_load,
+                            const uint32_t* ends = nullptr, uint32_t ell_reg = 0 /* near-uniform route: leave out other spans */);
 void launch_gstart(hipStream_t st, const uint32_t* starts, uint32_t n, const uint64_t* d_roff,
                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t* gstart);
 void launch_fill_ends(hipStream_t st, const uint32_t* starts, uint32_t n, uint32_t span_minus_1, uint32_t* ends);

@@ -139,3 +139,29 @@ def test_env_switch_off(pkg, oracle, solver):
         del os.environ["QMCP_HIP_NEAR"]
     assert solver.last_stats.path == pkg.PATH_GENERAL
     assert np.array_equal(got, oracle.solve(s, e, lengths, 100))
+
+
+def test_range_major_form_and_long_genomes(pkg, oracle, solver):
+    """the same route behind the range-major producers (k_prepare lists the exceptions, the partition leaves them out):
+    forced with QMCP_HIP_PM=0 on a one-level genome, and taken by itself on a genome beyond 8.39 M positions (two
+    partition levels) -- the oracle's mask, on the near-uniform route"""
+    rng = np.random.default_rng(41)
+    lengths = np.array([50_000, 61_000], np.uint32)
+    s, e, offs = _contigs(rng, lengths, [400_000, 500_000], 150, 0.02, 40)
+    os.environ["QMCP_HIP_PM"] = "0"
+    try:
+        got = solver.solve(s, e, lengths, 100, contig_read_offsets=offs)
+        st = solver.last_stats
+    finally:
+        del os.environ["QMCP_HIP_PM"]
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 100, offs)), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int(((e - s + 1) != 150).sum()), st.as_dict()
+    # two levels: 9.2 M positions in three contigs, 12 x M deep at M = 12
+    lengths = np.array([4_000_000, 3_000_000, 2_200_000], np.uint32)
+    counts = [int(12 * 12 * int(L) / 150) for L in lengths]
+    s, e, offs = _contigs(rng, lengths, counts, 150, 0.01, 40)
+    got = solver.solve(s, e, lengths, 12, contig_read_offsets=offs)
+    st = solver.last_stats
+    want = np.concatenate([np.unpackbits(oracle.solve(s[int(offs[c]):int(offs[c + 1])], e[int(offs[c]):int(offs[c + 1])], int(lengths[c]), 12).view(np.uint8), bitorder="little")[:counts[c]] for c in range(3)])
+    assert np.array_equal(np.unpackbits(got.view(np.uint8), bitorder="little")[:want.size], want), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM, st.as_dict()
