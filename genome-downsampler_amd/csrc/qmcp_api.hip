@@ -126,6 +126,11 @@ struct qmcp_hip_ctx {
     bool spiky_known = false, pend_spiky = false;
     uint64_t spiky_n = 0, spiky_ltot = 0;
     uint32_t spiky_empty = 0;
+    // the mixed-span route's speculative boundaries disagreed nearly everywhere on the last call of this shape (data
+    // that forgets its state slowly: one dominant read length, deep): the next call of the shape does not speculate
+    uint64_t spec_hopeless_n = 0, spec_hopeless_ltot = 0;
+    uint32_t spec_hopeless_M = 0;
+    uint32_t pend_M = 0;
     DevBuf scalars;  // popcount + sweep iteration counters
     DevBuf segs;     // cut-point windows and the sweep's stretch table
     DevBuf rings;    // mixed spans beyond 16 383: the plain event sweep's rings, in global memory
@@ -1344,7 +1349,9 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
             // (the first tier starts lower than for one span: a walk is slow per position, so short stretches
             //  matter more, and the second tier is there)
             const uint32_t burn_blocks = std::getenv("QMCP_HIP_SPEC_BURN") ? spec_first_run_in(depth) : spec_first_run_in(depth) * 3u / 5u;
-            const bool speculate = spec_wanted(depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
+            const bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M &&
+                                  std::getenv("QMCP_HIP_SPEC") == nullptr && std::getenv("QMCP_HIP_SPEC_BURN") == nullptr;
+            const bool speculate = !hopeless && spec_wanted(depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
                                    (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {
                 TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(n_seg_max)));
@@ -1417,6 +1424,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         c->spiky_ltot = pr.ltot;
     }
     c->pend_stats = local;
+    c->pend_M = M;
     c->pend_whole_contig_chains = 0;
     if (mixed_whole_contigs)  // one wave per non-empty contig
         for (uint32_t k = 0; k < n_contigs; ++k) c->pend_whole_contig_chains += lengths[k] != 0 ? 1u : 0u;
@@ -1459,6 +1467,12 @@ int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     local.spec_mismatches = (uint32_t)(host_scalars[4] & 0xFFFFFFFFu);
     local.spec_boundaries = (uint32_t)(host_scalars[4] >> 32);
     local.spec_retry_mismatches = local.spec_mismatches ? (uint32_t)(host_scalars[5] & 0xFFFFFFFFu) : 0u;
+    if (local.path == QMCP_PATH_GENERAL && local.spec_boundaries >= 4 && 2u * local.spec_mismatches > local.spec_boundaries &&
+        std::getenv("QMCP_HIP_SPEC_BURN") == nullptr) {
+        // (three sweeps -- both tiers and the exact one -- where one would have done: 430 against 185 ms on cfg4's reads
+        //  with 1 % clipped at 7.5 x M, lab/mixed_spec_check.py)
+        c->spec_hopeless_n = local.n_reads; c->spec_hopeless_ltot = local.total_length; c->spec_hopeless_M = c->pend_M;
+    }
     local.ms_prepare = elapsed(c->ev[EV_BEGIN], c->ev[EV_PREP]);
     local.ms_scan = elapsed(c->ev[EV_PREP], c->ev[EV_SCAN]);
     local.ms_sort = elapsed(c->ev[EV_SCAN], c->ev[EV_SORT]);
