@@ -165,3 +165,29 @@ def test_range_major_form_and_long_genomes(pkg, oracle, solver):
     want = np.concatenate([np.unpackbits(oracle.solve(s[int(offs[c]):int(offs[c + 1])], e[int(offs[c]):int(offs[c + 1])], int(lengths[c]), 12).view(np.uint8), bitorder="little")[:counts[c]] for c in range(3)])
     assert np.array_equal(np.unpackbits(got.view(np.uint8), bitorder="little")[:want.size], want), st.as_dict()
     assert st.path == pkg.PATH_NEAR_UNIFORM, st.as_dict()
+
+
+def test_contigs_shorter_than_the_dominant_span(pkg, oracle, solver):
+    """a contig shorter than the dominant span holds exceptions only -- no regular read fits -- deeper than M: the
+    replays there start from the contig's first position with every bucket empty, and the selection among the
+    exceptions is the greedy's own (largest end, largest start, smallest index)"""
+    rng = np.random.default_rng(61)
+    lengths = np.array([50_000, 90, 40_000, 149], np.uint32)
+    big = [420_000, 330_000]
+    parts_s, parts_e, counts = [], [], []
+    for L, k in ((50_000, big[0]), (90, 400), (40_000, big[1]), (149, 700)):
+        if L >= 1000:
+            a, b = _reads(rng, k, L, 150, 0.01, 40)
+        else:
+            span = rng.integers(1, L + 1, size=k)
+            a = (rng.random(k) * (L - span + 1)).astype(np.int64)
+            b = a + span - 1
+            a, b = a.astype(np.uint32), b.astype(np.uint32)
+        parts_s.append(a); parts_e.append(b); counts.append(k)
+    s, e = np.concatenate(parts_s), np.concatenate(parts_e)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    for M in (100, 30):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+        st = solver.last_stats
+        assert np.array_equal(got, oracle.solve(s, e, lengths, M, offs)), (M, st.as_dict())
+        assert st.path in (pkg.PATH_NEAR_UNIFORM, pkg.PATH_GENERAL)
