@@ -33,7 +33,7 @@ void launch_prepare(hipStream_t st, const uint32_t* starts, const uint32_t* ends
     if (ell_reg != 0u)  // stats[4] = exceptions listed
         hipLaunchKernelGGL(k_nu_count_groups, dim3(32), dim3(256), 0, st, exc_cnt, n_tiles * 4u, stats);
 }
-uint32_t prepare_exc_slots(uint32_t n) { return sort_tiles(n) * 4u * 128u; }  // the list's slots on this form (128 per wave and tile)
+uint32_t prepare_exc_slots(uint32_t n) { return sort_tiles(n) * 4u * 128u + kNuOverflow; }  // the list's slots on this form: 128 per wave and tile, and the overflow region
 
 void launch_general_keys(hipStream_t st, bool wide, const uint32_t* gstart, const uint32_t* starts,
                          const uint32_t* ends, uint32_t n, uint32_t span_bits, uint32_t max_span,

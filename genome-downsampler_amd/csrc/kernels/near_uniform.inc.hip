@@ -42,19 +42,23 @@ static constexpr unsigned long long kNuNoKey = ~0ull;
 // anchor (no event key has them: time - start < 256).
 static constexpr unsigned long long kNuUnresolvedLow = 0x7FFFFull;
 static constexpr int kNuKeyShift = 19;
-static constexpr int kNuOthers = 256;  // exceptions of one contig whose lives overlap a suspect's (more: the route gives up)
+static constexpr int kNuOthers = 2048;  // exceptions of one contig whose lives overlap a suspect's (more: the route gives up)
 
 struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 128
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
     const uint32_t* cnt;   // how many of a group's slots hold an exception (k_pm_prepare_sort: one group per wave and pass)
-    uint32_t cap;
+    uint32_t cap;          // all slots: the groups' and, behind them, the overflow region's kNuOverflow
+    const uint32_t* n_over;  // entries of the overflow region (the producer's stats[6])
     uint32_t* goff;        // exclusive scan of cnt
     uint32_t* dense;       // the filled slots, in list order (what the per-round kernels walk)
     uint32_t n_dense;      // how many there are (the host's count)
 };
 __device__ __forceinline__ uint32_t nu_count(const NuExc& x) { return x.cap; }
 static constexpr uint32_t kNuGroup = kPmExcPerWave;  // slots per group (a power of two)
-__device__ __forceinline__ bool nu_valid(const NuExc& x, uint32_t i) { return (i & (kNuGroup - 1u)) < x.cnt[i / kNuGroup]; }
+__device__ __forceinline__ bool nu_valid(const NuExc& x, uint32_t i) {
+    const uint32_t gcap = x.cap - kNuOverflow;
+    return i < gcap ? (i & (kNuGroup - 1u)) < x.cnt[i / kNuGroup] : i - gcap < min(*x.n_over, kNuOverflow);
+}
 
 __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
                                                        uint32_t n, uint32_t span, uint32_t* __restrict__ out) {
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(256) void k_nu_exc_diff(NuExc x, uint32_t* __restri
     const uint32_t n = nu_count(x);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!nu_valid(x, i)) continue;
-        const uint32_t at = x.goff[i / kNuGroup] + (i & (kNuGroup - 1u));
+        const uint32_t gcap = x.cap - kNuOverflow;  // (the overflow region's entries follow the groups' in the dense order)
+        const uint32_t at = i < gcap ? x.goff[i / kNuGroup] + (i & (kNuGroup - 1u)) : x.goff[gcap / kNuGroup] + (i - gcap);
         if (at < x.n_dense) x.dense[at] = i;
         atomicAdd(&diff[x.gs[i]], 1u);
         atomicAdd(&diff[x.ge[i] + 1u], 0xFFFFFFFFu);
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long
 //            groups' counts (cap / 128 words, also the producer's), their scan, and the filled slots' indices (cap words)
 //   state    8 words: [1] exceptions selected this round, [2] give-up flags, [3] selected in all, [4] suspects,
 //            [6] earlier rounds that selected something
-static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense) {
+static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense, const uint32_t* n_over) {
     NuExc x;
     x.gs = exc; x.ge = exc + cap; x.idx = exc + 2 * (size_t)cap; x.pick = exc + 3 * (size_t)cap;
     x.key = reinterpret_cast<unsigned long long*>(exc + 4 * (size_t)cap);
@@ -419,6 +424,7 @@ static NuExc nu_exc_view(uint32_t* exc, uint32_t cap, uint32_t n_dense) {
     x.goff = exc + 6 * (size_t)cap + cap / kNuGroup + 4;
     x.dense = x.goff + cap / kNuGroup + 4;
     x.n_dense = n_dense;
+    x.n_over = n_over;
     return x;
 }
 uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap) { return exc + 6 * (size_t)cap; }
@@ -426,23 +432,23 @@ size_t nu_exc_bytes(uint32_t cap) { return ((size_t)cap * 7 + 2 * (cap / kNuGrou
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out) {
     hipLaunchKernelGGL(k_nu_count_span, dim3(grid_for(n, 256)), dim3(256), 0, st, starts, ends, n, span, out);
 }
-void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                      const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
                      uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state) {
-    const NuExc x = nu_exc_view(exc, cap, n_exc);
+    const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     (void)hipMemsetAsync(ce, 0, ((size_t)ltot + 3) * sizeof(uint32_t), st);
     (void)hipMemsetAsync(state, 0, 8 * sizeof(uint32_t), st);
-    launch_exclusive_scan(st, x.cnt, cap / kNuGroup, x.goff, spine, false);
+    launch_exclusive_scan(st, x.cnt, (cap - kNuOverflow) / kNuGroup, x.goff, spine, true);
     hipLaunchKernelGGL(k_nu_exc_diff, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, ce);
     launch_exclusive_scan(st, ce, ltot + 2, ce, spine, false);
     hipLaunchKernelGGL(k_nu_need_adjust, dim3(grid_for((uint64_t)ltot + 1, 256)), dim3(256), 0, st, boff, ce, ltot, ell, M, nadj);
     hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
 }
-void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next) {
-    const NuExc x = nu_exc_view(exc, cap, n_exc);
+    const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
     v.ce = ce;
@@ -454,8 +460,8 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
                        sweep_from_next);
 }
-void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total) {
-    const NuExc x = nu_exc_view(exc, cap, n_exc);
+    const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, mask, mask_bit0, kept_total);
 }

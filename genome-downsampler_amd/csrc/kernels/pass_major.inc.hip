@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                 if (isx) {
                     skip |= 1u << k;
                     if (slot < kPmExcPerWave) { mine[3u * slot] = gs; mine[3u * slot + 1u] = ge; mine[3u * slot + 2u] = i; }
+                    else nu_overflow_put(exc, exc_cap, stats, gs, ge, i);  // (more than the wave's slots hold: the overflow region)
                 }
                 filled += (uint32_t)__popcll(m);
             }
@@ -234,7 +235,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             }
             if (lane == 0) {
                 exc_cnt[P * kPmWaves + w] = min(filled, kPmExcPerWave);
-                if (filled > kPmExcPerWave) atomicOr(&stats[5], 1u);
             }
         }
 #endif
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
 uint32_t pm_pitch(uint32_t n) { return part_pass_pitch(n); }  // passes of the call, rounded up to a multiple of 4
 uint32_t pm_max_row() { return kPmMaxRow; }
 uint32_t pm_pass() { return (uint32_t)kPmPass; }
-uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave; }  // the exception list's slots (128 per wave and pass)
+uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave + kNuOverflow; }  // the exception list's slots: 128 per wave and pass, and the overflow region
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,

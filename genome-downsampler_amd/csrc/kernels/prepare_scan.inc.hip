@@ -6,6 +6,25 @@
 // create_b_function (quasi_mcp_cpu_max_flow_solver.cpp:61-67) -- here O(1) per read.
 //
 // stats[0] = min span, stats[1] = max span, stats[2] = error flag
+
+// Near-uniform route: the exception list's OVERFLOW region -- its last kNuOverflow slots.  A wave that meets more
+// exceptions than its own 128 slots hold (a coordinate-sorted file's reads around a breakpoint, say: nearly all of
+// them clipped) appends the rest here, one atomic apiece on stats[6]; only if this region fills too is the list
+// incomplete (stats[5]).
+static constexpr uint32_t kNuOverflow = 1u << 20;
+__device__ __forceinline__ void nu_overflow_put(uint32_t* __restrict__ exc, uint32_t exc_cap, uint32_t* __restrict__ stats,
+                                                uint32_t gs, uint32_t ge, uint32_t i) {
+    const uint32_t k = atomicAdd(&stats[6], 1u);
+    if (k < kNuOverflow) {
+        const size_t at = (size_t)exc_cap - kNuOverflow + k;
+        exc[at] = gs;
+        exc[exc_cap + at] = ge;
+        exc[2 * (size_t)exc_cap + at] = i;
+    } else {
+        atomicOr(&stats[5], 1u);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ starts,
                                                  const uint32_t* __restrict__ ends, uint32_t n,
                                                  const uint64_t* __restrict__ contig_read_off,
@@ -117,6 +136,8 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                     exc[slot0 + slot] = gs;
                     exc[exc_cap + slot0 + slot] = ge;
                     exc[2 * (size_t)exc_cap + slot0 + slot] = i;
+                } else if (isx) {
+                    nu_overflow_put(exc, exc_cap, stats, gs, ge, i);
                 }
                 filled += (uint32_t)__popcll(m);
             }
@@ -195,6 +216,8 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
                     exc[slot0 + slot] = gs;
                     exc[exc_cap + slot0 + slot] = pos0 + e;
                     exc[2 * (size_t)exc_cap + slot0 + slot] = i;
+                } else {
+                    nu_overflow_put(exc, exc_cap, stats, gs, pos0 + e, i);
                 }
             }
             if (part_hist && !isx) {
@@ -218,7 +241,6 @@ __global__ __launch_bounds__(256) void k_prepare(const uint32_t* __restrict__ st
             if (!lean) filled = s_fill[threadIdx.x >> 6];
             if ((threadIdx.x & 63u) == 0u) {
                 exc_cnt[tile * 4u + (threadIdx.x >> 6)] = min(filled, 128u);
-                if (filled > 128u) atomicOr(&stats[5], 1u);
             }
         }
         if (part_hist && digit0_hist) {
@@ -279,6 +301,7 @@ __global__ __launch_bounds__(256) void k_nu_count_groups(const uint32_t* __restr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += gridDim.x * blockDim.x) acc += exc_cnt[i];
     acc = wave_sum_u32(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0u) atomicAdd(&stats[4], acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[4], min(stats[6], kNuOverflow));  // (the overflow region's)
 }
 
 // Mixed-span path: per-position end counts and the composite bucketing key

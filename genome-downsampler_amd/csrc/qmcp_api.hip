@@ -876,8 +876,8 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
     SolveRun& run = c->run;
     const uint32_t n = (uint32_t)run.pr.n, ltot = (uint32_t)run.pr.ltot, n_contigs = run.n_contigs;
     uint32_t* d_stats = (uint32_t*)c->stats.p;
-    static const uint32_t zeros[3] = {0u, 0u, 0u};
-    HIP_TRY(hipMemcpyAsync(d_stats + 3, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));  // empty positions, exceptions, overflow
+    static const uint32_t zeros[4] = {0u, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(d_stats + 3, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));  // empty positions, exceptions, list flag, overflow entries
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 65540;
     {
@@ -946,9 +946,9 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     } else {
         // how many reads have the longest span?  (one pass over the spans; the host waits for the count)
         TRY(ensure_near_uniform(c, n, ltot, n_contigs));
-        HIP_TRY(hipMemsetAsync(d_stats + 6, 0, sizeof(uint32_t), st));
-        qmcp::launch_nu_count_span(st, run.d_starts, run.d_ends, n, ell, d_stats + 6);
-        HIP_TRY(hipMemcpyAsync(c->h_nu, d_stats + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(d_stats + 7, 0, sizeof(uint32_t), st));
+        qmcp::launch_nu_count_span(st, run.d_starts, run.d_ends, n, ell, d_stats + 7);
+        HIP_TRY(hipMemcpyAsync(c->h_nu, d_stats + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_exc = n - c->h_nu[0];
         if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
@@ -987,7 +987,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     HIP_TRY(hipEventRecord(c->ev[EV_SORT], st));
     {
         KernelSpan sp(c, "near-uniform setup (exception coverage, need, pre-selection)");
-        qmcp::launch_nu_setup(st, exc, cap, n_exc, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
+        qmcp::launch_nu_setup(st, exc, cap, n_exc, d_stats + 6, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
                               nadj, state);
     }
     // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
@@ -1018,7 +1018,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             }
             {
                 KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
-                qmcp::launch_nu_round(st, exc, cap, n_exc, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
+                qmcp::launch_nu_round(st, exc, cap, n_exc, d_stats + 6, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
                                       (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
                 std::swap(sweep_from[0], sweep_from[1]);
             }
@@ -1060,7 +1060,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     }
     {
         KernelSpan sp(c, "k_nu_mark_selected");
-        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, (unsigned long long*)run.d_mask, run.mask_bit0,
+        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, d_stats + 6, (unsigned long long*)run.d_mask, run.mask_bit0,
                                       (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());

@@ -208,17 +208,17 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
 size_t nu_exc_bytes(uint32_t cap);
 uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap);  // the groups' counts inside the list's buffer  // the exception list: start, end, index (k_pm_prepare_sort), selection time, event key, group counts
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out);
-void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
+void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over /* the producer's stats[6] */,
                      const uint32_t* boff, uint32_t ltot, uint32_t ell, uint32_t M, uint32_t* ce /* ltot + 3 words */,
                      uint32_t* spine, int32_t* nadj /* ltot + 1 */, uint32_t* state /* 8 words */);
-void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, bool first_round,
+void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce /* launch_nu_setup's */,
                      const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx,
                      const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,
                      uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */);
-void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc,
+void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total);
 
 }  // namespace qmcp

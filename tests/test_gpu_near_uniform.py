@@ -191,3 +191,26 @@ def test_contigs_shorter_than_the_dominant_span(pkg, oracle, solver):
         st = solver.last_stats
         assert np.array_equal(got, oracle.solve(s, e, lengths, M, offs)), (M, st.as_dict())
         assert st.path in (pkg.PATH_NEAR_UNIFORM, pkg.PATH_GENERAL)
+
+
+def test_clipped_reads_bunched_in_read_order(pkg, oracle, solver):
+    """a coordinate-sorted file: around a breakpoint nearly every read is clipped, and those reads are NEIGHBOURS in read
+    order -- far more than the 128 list slots of the wave that meets them; the rest goes to the list's overflow region
+    and the route carries on (it used to give way)"""
+    rng = np.random.default_rng(73)
+    L, n = 60_000, 500_000
+    s = np.sort(rng.integers(0, L - 150 + 1, size=n)).astype(np.int64)      # sorted by position, as in a sorted BAM
+    e = s + 149
+    hot = (s > 30_000) & (s < 30_150)                                        # ~1 250 consecutive reads
+    clip = rng.integers(1, 60, size=n)
+    front = rng.random(n) < 0.5
+    pick = hot & (rng.random(n) < 0.9)
+    pick |= rng.random(n) < 0.002
+    s = np.where(pick & front, s + clip, s)
+    e = np.where(pick & ~front, e - clip, e)
+    s, e = s.astype(np.uint32), e.astype(np.uint32)
+    lengths = np.array([L], np.uint32)
+    got = solver.solve(s, e, lengths, 100)
+    st = solver.last_stats
+    assert np.array_equal(got, oracle.solve(s, e, lengths, 100)), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int(pick.sum()), st.as_dict()
