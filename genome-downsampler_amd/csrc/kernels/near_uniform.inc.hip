@@ -69,6 +69,39 @@ __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restric
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
+// How uniform are the spans?  A strided sample of the reads into 512 span bins (LDS), then the fullest bin's share:
+// out[0] = reads sampled, out[1] = reads in the fullest bin.  One workgroup: the sample is 64 Ki reads at most.
+__global__ __launch_bounds__(1024) void k_nu_span_mode_share(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
+                                                             uint32_t n, uint32_t stride, uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_bin[512];
+    __shared__ uint32_t s_red[16];
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_bin[i] = 0;
+    __syncthreads();
+    uint32_t sampled = 0;
+    for (uint64_t j = threadIdx.x; j * stride < n && j < 65536u; j += blockDim.x) {
+        const uint32_t i = (uint32_t)(j * stride);
+        atomicAdd(&s_bin[min(ends[i] - starts[i] + 1u, 511u)], 1u);
+        ++sampled;
+    }
+    __syncthreads();
+    uint32_t best = 0;
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) best = max(best, s_bin[i]);
+    best = wave_max_u32(best);
+    sampled = wave_sum_u32(sampled);
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = best; atomicAdd(&out[0], sampled); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; ++w) m = max(m, s_red[w]);
+        out[1] = m;
+    }
+}
+void launch_span_mode_share(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t* out /* 2 words, zeroed here */) {
+    (void)hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), st);
+    const uint32_t stride = n > 65536u ? n / 65536u : 1u;
+    hipLaunchKernelGGL(k_nu_span_mode_share, dim3(1), dim3(1024), 0, st, starts, ends, n, stride, out);
+}
+
 // +1 at an exception's start, -1 behind its end, and its flags reset
 __global__ __launch_bounds__(256) void k_nu_exc_diff(NuExc x, uint32_t* __restrict__ diff) {
     const uint32_t n = nu_count(x);

@@ -1349,8 +1349,21 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
             // (the first tier starts lower than for one span: a walk is slow per position, so short stretches
             //  matter more, and the second tier is there)
             const uint32_t burn_blocks = std::getenv("QMCP_HIP_SPEC_BURN") ? spec_first_run_in(depth) : spec_first_run_in(depth) * 3u / 5u;
-            const bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M &&
-                                  std::getenv("QMCP_HIP_SPEC") == nullptr && std::getenv("QMCP_HIP_SPEC_BURN") == nullptr;
+            bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M;
+            if (!hopeless && spec_wanted(depth) && in_regs && seg != nullptr && n >= (1u << 20)) {
+                // One dominant read length (what is left for this route once the shorter reads have their own: a few
+                // LONGER ones) forgets its state as slowly as one-length data, and the walk's boundaries then disagree
+                // nearly everywhere (lab/mixed_spec_check.py: 430 against 185 ms at 7.5 x M); a broad mix of lengths
+                // forgets fast and gains (lab/mixed_spec_broad.py: 117 against 271 ms at 5 x M).  A sample of the spans
+                // tells the two apart before anything is queued.
+                uint32_t* d_share = (uint32_t*)c->stats.p + 6;
+                qmcp::launch_span_mode_share(c->stream, d_starts, d_ends, n, d_share);
+                uint32_t share[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(share, d_share, sizeof(share), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                hopeless = share[0] != 0 && (uint64_t)share[1] * 10u >= (uint64_t)share[0] * 9u;
+            }
+            if (std::getenv("QMCP_HIP_SPEC") != nullptr || std::getenv("QMCP_HIP_SPEC_BURN") != nullptr) hopeless = false;
             const bool speculate = !hopeless && spec_wanted(depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
                                    (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {
