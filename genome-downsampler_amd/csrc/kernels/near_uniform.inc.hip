@@ -389,19 +389,19 @@ __global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ s
     }
     if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
 }
-// One workgroup settles every open question of the round: an exception the sweep wants is selected at that time (or
+// Settles every open question of the round: an exception the sweep wants is selected at that time (or
 // earlier than it was), one that is not wanted at its time is unselected; nadj follows, and every contig's next sweep
 // starts two blocks before its earliest change.  Only a contig's EARLIEST question (then the highest priority) is known
 // to be settled for good -- everything before it is certified -- the others are settled tentatively and checked again
 // by the next round (tests/near_uniform_model.py: solve_near_uniform_batched).  A contig whose earliest question is a
 // read without an anchor ends the attempt.
-__global__ __launch_bounds__(1024) void k_nu_select_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+__global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                           uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
                                                           int32_t* __restrict__ nadj,
                                                           const uint64_t* __restrict__ poff, uint32_t ell,
                                                           uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
     const uint32_t n_sus = min(state[4], suspects_cap);
-    for (uint32_t q = threadIdx.x; q < n_sus; q += blockDim.x) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
         if (k == kNuNoKey) continue;
@@ -490,7 +490,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from);
     hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key, swept_from);
-    hipLaunchKernelGGL(k_nu_select_apply, dim3(1), dim3(1024), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
+    hipLaunchKernelGGL(k_nu_select_apply, dim3(64), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
                        sweep_from_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
