@@ -214,3 +214,30 @@ def test_clipped_reads_bunched_in_read_order(pkg, oracle, solver):
     st = solver.last_stats
     assert np.array_equal(got, oracle.solve(s, e, lengths, 100)), st.as_dict()
     assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int(pick.sum()), st.as_dict()
+
+
+def test_two_contexts_in_flight(pkg, oracle):
+    """the two-phase entry (begin / end) on two contexts, as a pipelined caller uses it: the route's look-ups happen
+    inside begin(); masks as from the blocking entry"""
+    import torch
+    rng = np.random.default_rng(83)
+    lengths = np.array([50_000, 40_000], np.uint32)
+    s, e, offs = _contigs(rng, lengths, [420_000, 330_000], 150, 0.01, 40)
+    want = oracle.solve(s, e, lengths, 100, offs)
+    d_s = torch.from_numpy(s.view(np.int32)).cuda()
+    d_e = torch.from_numpy(e.view(np.int32)).cuda()
+    masks = [torch.zeros(pkg.mask_words(s.size), dtype=torch.int64, device="cuda") for _ in range(2)]
+    with pkg.Solver(0) as a, pkg.Solver(0) as b:
+        sv = [a, b]
+        for k in range(2):
+            sv[k].solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, lengths, 100, masks[k].data_ptr(), contig_read_offsets=offs)
+        for step in range(4):
+            k = step & 1
+            st = sv[k].solve_end()
+            assert st.path == pkg.PATH_NEAR_UNIFORM, st.as_dict()
+            assert np.array_equal(masks[k].cpu().numpy().view(np.uint64), want)
+            masks[k].zero_()
+            sv[k].solve_device_begin(d_s.data_ptr(), d_e.data_ptr(), s.size, lengths, 100, masks[k].data_ptr(), contig_read_offsets=offs)
+        for k in range(2):
+            sv[k].solve_end()
+            assert np.array_equal(masks[k].cpu().numpy().view(np.uint64), want)
