@@ -440,6 +440,11 @@ __device__ __forceinline__ uint32_t pm_slot_of(const uint32_t* __restrict__ s_T,
     return (p_lo + s) * kPmStride + s_L[s] + (x - s_T[s]);
 }
 
+// Where the quotas come from when the event-driven sweep ran whole contigs (no stretch table): the kept count of
+// position p is sev[p - (k - lastns[k]) * ell], k its block -- what k_sweep_expand would write into selend[] for the
+// ranking to read back (30 us and 100 MB a solve; here the ranking reads the sweep's own output).
+struct EvQuota { const uint32_t* sev; const uint32_t* lastns; const uint64_t* poff; uint32_t n_contigs, ell; };
+
 // k_rank_mark for the pass-major layout (the walk, the quota protocol and the settling of quota-crossing groups
 // are k_rank_mark's, word for word; what differs is where a record is found).
 __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restrict__ keys16,
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
                                                        unsigned long long* __restrict__ kept_total,
                                                        uint2* __restrict__ amb_lists, int lists_by_records,
                                                        uint32_t* __restrict__ chunk_cursor /* [n / 1024 + 256]: wave 0's cursor per chunk */,
-                                                       uint32_t mask_bit0) {
+                                                       uint32_t mask_bit0, EvQuota evq) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas; then the range's rows of T [kPmMaxRow + 1] and lst [kPmMaxRow]
     __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
@@ -472,6 +477,30 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
     uint32_t* const ccur = chunk_cursor + (lo >> 10) + range;  // (ranges' chunk counts add up to at most n / 1024 + one each)
     for (uint32_t i = tid; i <= n_rel; i += nthreads) s_T[i] = T[(size_t)range * pitch + p_lo + i];
     for (uint32_t i = tid; i < n_rel; i += nthreads) s_L[i] = lst_tab[(size_t)range * pitch + p_lo + i];
+    if (evq.sev != nullptr) {
+        // straight from the event-driven sweep's output (two dependent loads per position, eight positions in flight)
+        for (uint32_t i0 = tid; i0 < live; i0 += 8 * nthreads) {
+            uint32_t src[8], back[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t p = pos0 + min(i0 + u * nthreads, live - 1);  // clamped: every load is issued
+                uint32_t c_lo = 0, c_hi = evq.n_contigs;  // last contig with poff[c] <= p
+                while (c_hi - c_lo > 1) {
+                    const uint32_t mid = (c_lo + c_hi) >> 1;
+                    if ((uint32_t)evq.poff[mid] <= p) c_lo = mid; else c_hi = mid;
+                }
+                const uint32_t base = (uint32_t)evq.poff[c_lo];
+                const uint32_t k = (p - base) / evq.ell;
+                src[u] = p;
+                back[u] = k - evq.lastns[(size_t)(base / (4u * evq.ell) + c_lo) * 4u + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) src[u] = evq.sev[src[u] - back[u] * evq.ell];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * nthreads < live) s_q[i0 + u * nthreads] = (int32_t)src[u];
+        }
+    } else
     for (uint32_t i0 = tid; i0 < live; i0 += 8 * nthreads) {
         uint32_t a[8], b[8];
 #pragma unroll
@@ -703,11 +732,13 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
                          const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
                          const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                         uint32_t* chunk_cursor, uint32_t mask_bit0) {
+                         uint32_t* chunk_cursor, uint32_t mask_bit0, const uint32_t* ev_sev, const uint32_t* ev_lastns,
+                         const uint64_t* d_poff, uint32_t n_contigs, uint32_t ell) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
+    const EvQuota evq{ev_sev, ev_lastns, d_poff, n_contigs, ell};
     const size_t lds = (((size_t)1 << shift) + 1 + 2 * (size_t)kPmMaxRow + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_pm_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, T, lst_tab, pm_pitch(n), rows,
                        shift, ltot, n, boff, selend, mask, kept_total, (uint2*)scratch,
-                       scratch_by_records ? 1 : 0, chunk_cursor, mask_bit0);
+                       scratch_by_records ? 1 : 0, chunk_cursor, mask_bit0, evq);
 }

@@ -471,7 +471,11 @@ int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint3
 }
 
 int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t ltot, uint32_t n_contigs,
-                         uint32_t span, uint32_t M, uint32_t* d_iters, uint32_t empty_positions) {
+                         uint32_t span, uint32_t M, uint32_t* d_iters, uint32_t empty_positions,
+                         bool* expand_left_out = nullptr /* in: the caller can read the event sweep's own output;
+                                                            out: the event sweep ran whole contigs and selend[] was not written */) {
+    const bool may_leave_expand = expand_left_out != nullptr && *expand_left_out;
+    if (expand_left_out) *expand_left_out = false;
     // mean coverage in units of M: the fast form needs the binding jumps to come from the previous
     // block, which holds while coverage is many times M
     const double depth = (double)n * (double)span / ((double)ltot * (double)(M ? M : 1));
@@ -534,6 +538,10 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
         {
             KernelSpan sp(c, "k_sweep_uniform_ev", st);
             qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, pk, sev, lastns, d_iters);
+        }
+        if (may_leave_expand && seg == nullptr) {
+            *expand_left_out = true;  // (the ranking reads sev / lastns itself)
+            return QMCP_OK;
         }
         KernelSpan sp(c, "k_sweep_expand", st);
         qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, span, M, ltot, seg, n_seg_max, sev, lastns, selend);
@@ -1196,13 +1204,15 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         hipStream_t s1 = c->stream;  // (partition and bucket offsets are already queued)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
-        TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters, empty_positions));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
-        sweep_done = true;
         ranked = (uint64_t)max_load_now * kRankBalance <= (uint64_t)n;
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
         run.assumed_ranked = ranked;
+        // (the pass-major ranking can take its quotas from the event-driven sweep's own output: no expand, no selend[])
+        bool expand_left_out = ranked && run.pm && std::getenv("QMCP_HIP_EXPAND") == nullptr;
+        TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters, empty_positions, &expand_left_out));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
+        sweep_done = true;
         if (ranked && run.pm) {
             KernelSpan sp(c, "k_pm_rank_mark");
             qmcp::launch_pm_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p,
@@ -1210,7 +1220,9 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
                                       range_shift, ltot, (const uint32_t*)c->boff.p,
                                       (const uint32_t*)c->selend.p, (unsigned long long*)d_mask,
                                       (unsigned long long*)c->scalars.p, c->rankamb.p,
-                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
+                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0,
+                                      expand_left_out ? (const uint32_t*)c->cstart.p : nullptr, (const uint32_t*)c->evlast.p,
+                                      (const uint64_t*)c->poff.p, n_contigs, max_span);
             HIP_TRY(hipGetLastError());
         } else if (ranked) {
             KernelSpan sp(c, "k_rank_mark");

@@ -201,7 +201,11 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
                          const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
                          const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                         uint32_t* chunk_cursor, uint32_t mask_bit0);
+                         uint32_t* chunk_cursor, uint32_t mask_bit0,
+                         // quotas straight from the event-driven sweep's output (whole contigs, no stretch table), instead
+                         // of selend[] - boff[]: the changed blocks' kept counts, the last changed block per block
+                         const uint32_t* ev_sev = nullptr, const uint32_t* ev_lastns = nullptr,
+                         const uint64_t* d_poff = nullptr, uint32_t n_contigs = 0, uint32_t ell = 0);
 
 
 // near-uniform route (kernels/near_uniform.inc.hip): one dominant span, a few shorter reads as listed exceptions
