@@ -15,8 +15,9 @@ qmcp_hip_solve_device_begin / _end): the selection sweep of one -- a serial chai
 units -- runs beside the bandwidth-bound stages of the next; every solve and gather completes inside
 the timed region.
 
-For N > 1 launch through torch.distributed.run (one rank per GPU over RCCL); rank 0 prints ONE
-JSON line.  The CPU baseline (oracle/, rank 0, N = 1 only) is a reported number, not the target.
+For N > 1 either launch through torch.distributed.run (one rank per GPU over RCCL) or just run
+`python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts that launcher itself as a
+child process (before torch or the GPU is touched) and exits with its code; rank 0 prints ONE JSON line.  The CPU baseline (oracle/, rank 0, N = 1 only) is a reported number, not the target.
 """
 import argparse
 import importlib
@@ -215,6 +216,23 @@ def cpu_baseline(pkg, workload):
     }, first_mask
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>` as a child
+    process, pass its output through (rank 0 prints the one JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +255,15 @@ def main():
     # exercise the N > 1 plumbing on a single-GPU box
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)
+    # one rank, but through the collective library all the same: init_process_group("nccl") and the mask gather on
+    # a one-rank RCCL communicator -- the only way a one-GPU box can execute the RCCL calls of the N > 1 path
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process and before torch or
+        # the GPU is touched (a process that has initialised the GPU must never be replaced by another).
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -254,8 +280,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -300,7 +332,7 @@ def main():
     n_buf = max(4, args.in_flight + 2)
     d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_buf)]
     d_alls = [torch.zeros(words * world, dtype=torch.int64, device=dev) for _ in range(n_buf)] \
-        if world > 1 else None
+        if use_dist else None
     depth = args.in_flight
     solvers = [pkg.Solver(local_rank) for _ in range(depth)]
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -317,7 +349,7 @@ def main():
         solvers[slot].solve_end()
         in_flight[slot] = None
         last_buf[0] = b
-        if world > 1 and args.exchange != "none":
+        if use_dist and args.exchange != "none":
             # the path's one exchange: gather of the keep bitmasks (N/8 bytes per rank) over xGMI
             if args.exchange == "all_gather":
                 gathers[b] = dist.all_gather_into_tensor(d_alls[b], d_masks[b], async_op=True)
@@ -345,7 +377,7 @@ def main():
                 gathers[b].wait()
                 gathers[b] = None
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -387,14 +419,14 @@ def main():
                             d_masks[0].data_ptr(), contig_read_offsets=offs, stream=stream)
     alone_ms = float(solvers[0].last_stats.ms_total)
     d_mask = d_masks[0]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # did the collective library see every rank?  (answerable from the line alone)
     rccl_info = None
-    if world > 1:
+    if use_dist:
         names = [None] * world
         dist.all_gather_object(names, {"rank": rank, "device": torch.cuda.get_device_name(dev),
                                        "local_rank": local_rank})
@@ -453,9 +485,9 @@ def main():
                             "device-resident reads -> device keep bitmask"
                             + (f"; + RCCL {args.exchange} of the keep masks" + (" at rank 0" if args.exchange == "gather" else "") + ", overlapped with the following "
                                "solves (all completed inside the timed region)"
-                               if world > 1 else ""),
+                               if use_dist else ""),
                 "multi_gpu_mode": args.mode if world > 1 else "single GPU",
-                "exchange": args.exchange if world > 1 else None,
+                "exchange": args.exchange if use_dist else None,
                 "rccl_ranks": rccl_info,
                 "solves_in_flight_per_gpu": depth,
                 "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
@@ -538,7 +570,7 @@ def main():
         print(json.dumps(out), flush=True)
     for sv in solvers:
         sv.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,3 +70,30 @@ def test_two_ranks_without_the_exchange():
     assert out.returncode == 0, out.stderr[-2000:]
     b = _one_json_line(out.stdout)
     assert b["n_gpus"] == 2 and b["config"]["exchange"] == "none" and b["value"] > 0
+
+
+def test_plain_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it and no WORLD_SIZE in the environment (what the driver's
+    plain command line is): the script starts torch.distributed.run as a child itself and relays rank 0's line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--workload", "cfg2", "--dist-backend", "gloo", "--single-device"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = _one_json_line(out.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["rccl_ranks"]["world_size"] == 2 and b["value"] > 0
+
+
+def test_one_rank_through_rccl():
+    """the RCCL calls of the N > 1 path -- init_process_group("nccl", device_id), the asynchronous gather of the keep
+    masks, the barrier, the all-reduce of the elapsed time -- executed on a one-rank communicator (one GPU here)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for exchange in ("gather", "all_gather"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "4", "--warmup", "2",
+                              "--workload", "cfg2", "--no-extras", "--exchange", exchange],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        b = _one_json_line(out.stdout)
+        rr = b["config"]["rccl_ranks"]
+        assert rr["backend"] == "nccl" and rr["world_size"] == 1 and b["config"]["exchange"] == exchange and b["value"] > 0
