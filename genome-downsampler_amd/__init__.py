@@ -59,9 +59,10 @@ class Stats(C.Structure):
         ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_mark", C.c_float),
         ("ms_h2d", C.c_float), ("ms_d2h", C.c_float), ("columns_sent", C.c_uint32),
         ("spec_boundaries", C.c_uint32), ("spec_mismatches", C.c_uint32),
-        ("spec_retry_mismatches", C.c_uint32), ("contig_groups", C.c_uint32),
+        ("spec_retry_mismatches", C.c_uint32), ("sweep_blocks_changed", C.c_uint32), ("sweep_blocks", C.c_uint32),
         ("arena_grown_mid_solve", C.c_uint32), ("near_uniform_exceptions", C.c_uint32),
         ("near_uniform_selected", C.c_uint32), ("near_uniform_rounds", C.c_uint32),
+        ("near_uniform_giveup", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -406,14 +406,14 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
 
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
-                 unsigned long long* n_kept, uint32_t mask_bit0) {
+                 unsigned long long* n_kept) {
     if (wide)
         hipLaunchKernelGGL(k_mark<KeysSplit64>, dim3(grid_for(ltot, 256)), dim3(256), 0, st,
                            KeysSplit64{(const uint64_t*)sorted, svals}, ltot, boff, selend,
-                           (uint32_t*)mask, n_kept, mask_bit0);
+                           (uint32_t*)mask, n_kept);
     else
         hipLaunchKernelGGL(k_mark<KeysRec>, dim3(grid_for(ltot, 256)), dim3(256), 0, st,
-                           KeysRec{(const Rec*)sorted}, ltot, boff, selend, (uint32_t*)mask, n_kept, mask_bit0);
+                           KeysRec{(const Rec*)sorted}, ltot, boff, selend, (uint32_t*)mask, n_kept);
 }
 
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
@@ -603,13 +603,13 @@ size_t rank_scratch_bytes(uint32_t shift, uint32_t ltot, uint32_t n) {
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
-                      void* scratch, bool scratch_by_records, uint32_t mask_bit0) {
+                      void* scratch, bool scratch_by_records) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(k_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx, range_start,
-                       shift, ltot, boff, selend, mask, kept_total, (uint2*)scratch, scratch_by_records ? 1 : 0, mask_bit0);
+                       shift, ltot, boff, selend, mask, kept_total, (uint2*)scratch, scratch_by_records ? 1 : 0);
 }
 
 void launch_coverage(hipStream_t st, const uint32_t* boff, const uint32_t* eoff, uint32_t ltot,

@@ -10,13 +10,13 @@ __global__ __launch_bounds__(256) void k_mark(Keys keys, uint32_t ltot,
                                               const uint32_t* __restrict__ boff,
                                               const uint32_t* __restrict__ selend,
                                               uint32_t* __restrict__ mask32,
-                                              unsigned long long* __restrict__ n_kept, uint32_t mask_bit0) {
+                                              unsigned long long* __restrict__ n_kept) {
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t mine = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ltot; q += stride) {
         const uint32_t j0 = boff[q], j1 = selend[q];
         for (uint32_t j = j0; j < j1; ++j) {
-            const uint32_t idx = keys.idx(j) + mask_bit0;
+            const uint32_t idx = keys.idx(j);
             atomicOr(&mask32[idx >> 5], 1u << (idx & 31));
         }
         mine += j1 - j0;

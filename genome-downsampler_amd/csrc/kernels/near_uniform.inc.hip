@@ -429,13 +429,13 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
     }
 }
 
-__global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long long* __restrict__ mask, uint32_t mask_bit0,
+__global__ __launch_bounds__(256) void k_nu_mark_selected(NuExc x, unsigned long long* __restrict__ mask,
                                                           unsigned long long* __restrict__ kept_total) {
     uint32_t kept = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
         const uint32_t i = x.dense[j];
         if (x.pick[i] == kNuUnpicked) continue;
-        const uint64_t bit = (uint64_t)x.idx[i] + mask_bit0;
+        const uint64_t bit = (uint64_t)x.idx[i];
         atomicOr(&mask[bit >> 6], 1ull << (bit & 63));
         ++kept;
     }
@@ -494,7 +494,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                        sweep_from_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
-                             unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total) {
+                             unsigned long long* mask, unsigned long long* kept_total) {
     const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
-    hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, mask, mask_bit0, kept_total);
+    hipLaunchKernelGGL(k_nu_mark_selected, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, mask, kept_total);
 }

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
                                                        unsigned long long* __restrict__ kept_total,
                                                        uint2* __restrict__ amb_lists, int lists_by_records,
                                                        uint32_t* __restrict__ chunk_cursor /* [n / 1024 + 256]: wave 0's cursor per chunk */,
-                                                       uint32_t mask_bit0, EvQuota evq) {
+                                                       EvQuota evq) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas; then the range's rows of T [kPmMaxRow + 1] and lst [kPmMaxRow]
     __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
         }
         __syncthreads();  // every q_after is read before the next chunk draws
         if (keep) {
-            const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (r.slot & ~(uint32_t)(kPmPass - 1)) : (r.slot / kPmStride) * (uint32_t)kPmPass) + r.val + mask_bit0;  // pass * 8192 + index in pass
+            const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (r.slot & ~(uint32_t)(kPmPass - 1)) : (r.slot / kPmStride) * (uint32_t)kPmPass) + r.val;  // pass * 8192 + index in pass
             atomicOr(&mask[v >> 6], 1ull << (v & 63u));
         }
         kept += (uint32_t)__popcll(__ballot(keep));
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
             if (m == 0) continue;
             const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
             if (member && above >= skip) {
-                const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (slot[t] & ~(uint32_t)(kPmPass - 1)) : (slot[t] / kPmStride) * (uint32_t)kPmPass) + idx16[slot[t]] + mask_bit0;
+                const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (slot[t] & ~(uint32_t)(kPmPass - 1)) : (slot[t] / kPmStride) * (uint32_t)kPmPass) + idx16[slot[t]];
                 atomicOr(&mask[v >> 6], 1ull << (v & 63u));
             }
             const uint32_t in_step = (uint32_t)__popcll(m);
@@ -732,7 +732,7 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
                          const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
                          const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                         uint32_t* chunk_cursor, uint32_t mask_bit0, const uint32_t* ev_sev, const uint32_t* ev_lastns,
+                         uint32_t* chunk_cursor, const uint32_t* ev_sev, const uint32_t* ev_lastns,
                          const uint64_t* d_poff, uint32_t n_contigs, uint32_t ell) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const EvQuota evq{ev_sev, ev_lastns, d_poff, n_contigs, ell};
@@ -740,5 +740,5 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
     (void)hipFuncSetAttribute((const void*)k_pm_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_pm_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, T, lst_tab, pm_pitch(n), rows,
                        shift, ltot, n, boff, selend, mask, kept_total, (uint2*)scratch,
-                       scratch_by_records ? 1 : 0, chunk_cursor, mask_bit0, evq);
+                       scratch_by_records ? 1 : 0, chunk_cursor, evq);
 }

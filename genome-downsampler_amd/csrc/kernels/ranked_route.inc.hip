@@ -465,9 +465,7 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
                                                     const uint32_t* __restrict__ selend,
                                                     unsigned long long* __restrict__ mask,
                                                     unsigned long long* __restrict__ kept_total,
-                                                    uint2* __restrict__ amb_lists, int lists_by_records,
-                                                    uint32_t mask_bit0 /* bit of mask[0] that stands for read 0 (a contig
-                                                        group of a larger call need not start at a multiple of 64) */) {
+                                                    uint2* __restrict__ amb_lists, int lists_by_records) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1]; the last entry absorbs idle threads
     __shared__ uint32_t s_namb;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
@@ -552,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
 #pragma unroll
         for (int u = 0; u < kRankU; ++u) {
 #ifndef QMCP_LAB_NO_MASK_ATOMIC  // (lab: what the walk costs without its mask writes -- wrong masks)
-            if (keep[u]) { const uint32_t v = r.val[u] + mask_bit0; atomicOr(&mask[v >> 6], 1ull << (v & 63u)); }
+            if (keep[u]) { const uint32_t v = r.val[u]; atomicOr(&mask[v >> 6], 1ull << (v & 63u)); }
 #endif
             kept += (uint32_t)__popcll(__ballot(keep[u]));
         }
@@ -597,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
             if (m == 0) continue;
             const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
             if (member && above >= skip) {
-                const uint32_t v = idx[j] + mask_bit0;
+                const uint32_t v = idx[j];
                 atomicOr(&mask[v >> 6], 1ull << (v & 63u));
             }
             const uint32_t in_step = (uint32_t)__popcll(m);

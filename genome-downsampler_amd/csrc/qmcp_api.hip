@@ -68,8 +68,6 @@ struct SolveRun {
     uint32_t n_contigs = 0, M = 0;
     uint64_t n64 = 0;
     uint64_t* d_mask = nullptr;
-    uint32_t mask_bit0 = 0;             // bit of d_mask[0] that stands for the call's read 0
-    bool mask_cleared = false;          // the caller has cleared the mask (contig groups share its border words)
     Problem pr;
     qmcp_hip_stats local;
     bool trivial = false, head_done = false, may_rank = false, two_level = false, have_gstart = true;
@@ -77,10 +75,6 @@ struct SolveRun {
     bool pm = false;                    // range-ranked route in its pass-major form (kernels/pass_major.inc.hip)
     uint32_t range_shift = 0;
     uint32_t nu_filter = 0;             // near-uniform route: the span the head's producer treated as regular (0: every read)
-    // a contig group whose tail was queued on the FIRST group's statistics (no host wait of its own): what was
-    // assumed, checked against the group's own read-back when the solve is collected
-    bool speculated = false, assumed_ranked = false;
-    uint32_t assumed[3] = {0, 0, 0};
 };
 
 }  // namespace
@@ -146,22 +140,6 @@ struct qmcp_hip_ctx {
     bool mixed_seen = false;          // a call took the mixed-span route: its arrays are sized up front from then on
     bool sized = false;               // the arena block of the current solve is behind us (growth now is growth mid-solve)
     uint32_t grew_mid_solve = 0;      // buffers that had to grow after the solve's first launch (stats.arena_grown_mid_solve)
-    // Contig groups: a deep multi-contig call is dealt to child contexts (one group of contigs each, its own
-    // stream and arena), so that one group's serial selection chain runs beside the bandwidth-bound stages of
-    // the next groups -- what two solves in flight on two contexts do for a pipelined caller, inside one call.
-    bool is_kid = false;
-    hipStream_t own_stream = nullptr;   // a group context's own stream (`stream` is what the current solve's tail runs on)
-    hipStream_t stream_head = nullptr;  // what the current solve's head runs on (null: `stream`)
-    std::vector<qmcp_hip_ctx*> kids;
-    std::vector<std::vector<uint64_t>> kid_roff;  // the groups' own contig read offsets (host)
-    uint32_t n_split = 0;             // groups of the pending solve (0: not split)
-    bool no_split = false;            // a split call's groups disagreed once: this context solves whole from then on
-    struct SplitArgs {                // the pending split call, kept for a whole re-solve if its groups disagree
-        const uint32_t* d_starts = nullptr; const uint32_t* d_ends = nullptr;
-        std::vector<uint64_t> roff; std::vector<uint32_t> lengths;
-        uint64_t n64 = 0; uint32_t M = 0; uint64_t* d_mask = nullptr;
-    } split_args;
-    hipEvent_t ev_go = nullptr;       // parent stream -> groups: inputs ordered, mask cleared
     // optional per-kernel timing (qmcp_hip_set_profiling): one event pair per launch group
     int profiling = 0;  // 0 off, 1 every kernel, 2 the selection sweep only
     size_t tables_count = 0;          // contig tables currently on the device (upload_tables)
@@ -233,8 +211,6 @@ int ensure(qmcp_hip_ctx* c, DevBuf& b, size_t bytes) {
         // one case where a later call is larger than every earlier one)
         if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
-        if (c->stream_head) HIP_TRY(hipStreamSynchronize(c->stream_head));
-        if (c->own_stream) HIP_TRY(hipStreamSynchronize(c->own_stream));
         HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -647,34 +623,26 @@ bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift, uint32
 // keep mask) + solve_complete (collects).  SolveRun is what the two enqueue halves share.
 int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                  const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
-                 uint32_t M, uint64_t* d_mask, uint32_t mask_bit0, bool mask_cleared) {
+                 uint32_t M, uint64_t* d_mask) {
     if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
-    // a contig group's head may run on another stream than its tail (the call's main stream, in order behind the
-    // groups before it): everything below launches on c->stream, so it stands in for the length of the head
-    struct StreamSwap {
-        qmcp_hip_ctx* c; hipStream_t tail;
-        explicit StreamSwap(qmcp_hip_ctx* ctx) : c(ctx), tail(ctx->stream) { if (c->stream_head) c->stream = c->stream_head; }
-        ~StreamSwap() { c->stream = tail; }
-    } swap(c);
     c->pend_spiky = false;
     if (!c->h_scalars) HIP_TRY(hipHostMalloc((void**)&c->h_scalars, 16 * sizeof(unsigned long long), hipHostMallocDefault));
     SolveRun& run = c->run;
     run = SolveRun();
     run.d_starts = d_starts; run.d_ends = d_ends; run.roff = roff; run.lengths = lengths;
     run.n_contigs = n_contigs; run.n64 = n64; run.M = M; run.d_mask = d_mask;
-    run.mask_bit0 = mask_bit0; run.mask_cleared = mask_cleared;
     Problem& pr = run.pr;
     TRY(check_problem(roff, lengths, n_contigs, n64, pr));
     const uint32_t n = (uint32_t)pr.n;
     const uint32_t ltot = (uint32_t)pr.ltot;
-    const size_t mask_words = (size_t)((n64 + mask_bit0 + 63) / 64);
+    const size_t mask_words = (size_t)((n64 + 63) / 64);
     qmcp_hip_stats& local = run.local;
     std::memset(&local, 0, sizeof(local));
     local.n_reads = n64;
     local.n_contigs = n_contigs;
     local.total_length = pr.ltot;
     if (n == 0 || ltot == 0) {
-        if (mask_words && !mask_cleared) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
+        if (mask_words) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
         if (n != 0) return fail(QMCP_EREAD, "reads given for zero-length contigs");
         run.trivial = true;
         HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
@@ -741,7 +709,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
     hs[4] = 0xFFFFFFFFu;  // unknown unless the range-ranked route counted them
     run.have_gstart = true;
     if (!run.may_rank) {
-        if (!mask_cleared) HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
+        HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
         uint32_t hs3[3];
         TRY(run_prepare(c, d_starts, d_ends, pr, nullptr, true, false, false, range_shift, nullptr, hs3));
         hs[0] = hs3[0]; hs[1] = hs3[1]; hs[2] = hs3[2];
@@ -758,7 +726,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         static const uint32_t init[8] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
         run.pm = !two_level && pm_rows_fit(roff, pr, range_shift, c->h_pm_rows);
-        run.nu_filter = !c->is_kid ? c->nu_ell : 0u;
+        run.nu_filter = c->nu_ell;
         hs[5] = hs[6] = 0;
         if (run.pm) {
             HIP_TRY(hipMemcpyAsync(c->pm_rows.p, c->h_pm_rows, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s1));
@@ -770,7 +738,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
                 qmcp::launch_pm_prepare_sort(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
                                              n_contigs, range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
                                              (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->stats.p,
-                                             mask_cleared ? nullptr : (unsigned long long*)d_mask,
+                                             (unsigned long long*)d_mask,
                                              run.nu_filter, run.nu_filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
                                              run.nu_filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
             }
@@ -791,10 +759,10 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
             }
         } else {
             // the range-major form: k_prepare, scan, partition (one or two levels), bucket offsets
-            TRY(queue_rm_head(c, s1, run.nu_filter, !mask_cleared));
+            TRY(queue_rm_head(c, s1, run.nu_filter, true));
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_head, s1));  // a contig group's head: the next group's may start
+        HIP_TRY(hipEventRecord(c->ev_head, s1));
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         HIP_TRY(hipMemcpyAsync(hs, c->stats.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
         HIP_TRY(hipMemcpyAsync(hs + 3, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream2));
@@ -893,7 +861,7 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
         qmcp::launch_pm_prepare_sort(st, run.d_starts, run.d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
                                      n_contigs, run.range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
                                      (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, d_stats,
-                                     run.mask_cleared ? nullptr : (unsigned long long*)run.d_mask, filter,
+                                     (unsigned long long*)run.d_mask, filter,
                                      filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
                                      filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
     }
@@ -929,11 +897,11 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const uint32_t ell = max_span;
     const double depth = (double)n * (double)ell / ((double)ltot * (double)(M ? M : 1));
     const bool dbg = std::getenv("QMCP_HIP_NEAR_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[near] pm %d may_rank %d kid %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
-                     (int)run.may_rank, (int)c->is_kid, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
+    if (dbg) fprintf(stderr, "[near] pm %d may_rank %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
+                     (int)run.may_rank, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
     double min_depth = kNuMinDepth;
     if (const char* e = std::getenv("QMCP_HIP_NEAR_MIN_DEPTH")) min_depth = std::strtod(e, nullptr);  // (lab)
-    if (!run.may_rank || c->is_kid || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
+    if (!run.may_rank || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
         depth < min_depth || min_span == 0)
         return QMCP_OK;
     {
@@ -964,7 +932,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
         c->nu_ell = ell;
         if (run.pm) TRY(queue_pm_head(c, st, ell));
-        else TRY(queue_rm_head(c, st, ell, !run.mask_cleared));
+        else TRY(queue_rm_head(c, st, ell, true));
         uint32_t* d_max_load = (uint32_t*)c->ranges.p + 65540;
         HIP_TRY(hipMemcpyAsync(c->h_nu, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(c->h_nu + 1, d_stats + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1058,17 +1026,17 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         qmcp::launch_pm_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p, (const uint32_t*)c->hist2.p,
                                   (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, boff, selend,
                                   (unsigned long long*)run.d_mask, (unsigned long long*)c->scalars.p, c->rankamb.p,
-                                  qmcp::rank_scratch_by_records(run.range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0);
+                                  qmcp::rank_scratch_by_records(run.range_shift, ltot, n), (uint32_t*)c->pm_ccur.p);
     } else {
         KernelSpan sp(c, "k_rank_mark");
         qmcp::launch_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->ranges.p,
                                run.range_shift, ltot, boff, selend, (unsigned long long*)run.d_mask,
                                (unsigned long long*)c->scalars.p, c->rankamb.p,
-                               qmcp::rank_scratch_by_records(run.range_shift, ltot, n), run.mask_bit0);
+                               qmcp::rank_scratch_by_records(run.range_shift, ltot, n));
     }
     {
         KernelSpan sp(c, "k_nu_mark_selected");
-        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, d_stats + 6, (unsigned long long*)run.d_mask, run.mask_bit0,
+        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, d_stats + 6, (unsigned long long*)run.d_mask,
                                       (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());
@@ -1076,13 +1044,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     return QMCP_OK;
 }
 
-// `assume`: null, or the read-back of the call's first contig group {min span, max span, error flag}: the tail is
-// then queued on it at once -- the groups of one call nearly always agree (one library, one read length) -- and
-// collect_one compares with the group's own numbers (QMCP_ESPECULATION: the caller solves the call again whole).
-// Whatever a wrong guess queues stays in bounds: the sweeps and the ranking index by position and by the
-// partition's records, which do not depend on the spans.
-constexpr int QMCP_ESPECULATION = -1000;  // internal: never leaves this file
-int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
+int enqueue_tail(qmcp_hip_ctx* c) {
     SolveRun& run = c->run;
     const Problem& pr = run.pr;
     qmcp_hip_stats& local = run.local;
@@ -1106,24 +1068,17 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
     const uint32_t* hs = c->h_head;
     bool have_gstart = run.have_gstart;
     const bool ranked_counted = run.ranked_counted;
-    // (only on a one-length first group: the mixed-span kernels size their rings by the longest span)
-    const bool speculate = assume != nullptr && may_rank && !run.wait_empty && assume[2] == 0 &&
-                           assume[0] == assume[1] && assume[1] <= qmcp::kMaxUniformSpan;
-    if (may_rank && !speculate) {
+    if (may_rank) {
         HIP_TRY(hipStreamSynchronize(c->stream2));
-        hipStream_t head_stream = c->stream_head ? c->stream_head : c->stream;
-        if (run.wait_empty) HIP_TRY(hipStreamSynchronize(head_stream));
+        if (run.wait_empty) HIP_TRY(hipStreamSynchronize(c->stream));
         if (hs[2] != 0) {
-            (void)hipStreamSynchronize(head_stream);  // what was queued stays in bounds; let it drain
+            (void)hipStreamSynchronize(c->stream);  // what was queued stays in bounds; let it drain
             return fail(QMCP_EREAD, "a read has start > end or end >= its contig length");
         }
     }
-    run.speculated = speculate;
-    if (speculate) { run.assumed[0] = assume[0]; run.assumed[1] = assume[1]; run.assumed[2] = assume[2]; }
-    if (c->stream_head && c->stream_head != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_head, 0));
-    const uint32_t max_load = speculate ? 0u : hs[3];  // (assumed balanced: checked afterwards)
-    const uint32_t empty_positions = hs[4];            // (speculating: the last solve of this shape's, set by the head)
-    const uint32_t min_span = speculate ? assume[0] : hs[0], max_span = speculate ? assume[1] : hs[1];
+    const uint32_t max_load = hs[3];
+    const uint32_t empty_positions = hs[4];            // (the last solve of this shape's, or this one's: set by the head)
+    const uint32_t min_span = hs[0], max_span = hs[1];
     local.min_span = min_span;
     local.max_span = max_span;
     const bool uniform = (min_span == max_span) && max_span <= qmcp::kMaxUniformSpan;
@@ -1158,19 +1113,18 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         // the head listed every read as an exception to the last call's span: its stages again, unfiltered
         c->nu_ell = 0;
         if (run.pm) TRY(queue_pm_head(c, c->stream, 0));
-        else TRY(queue_rm_head(c, c->stream, 0, !run.mask_cleared));
+        else TRY(queue_rm_head(c, c->stream, 0, true));
         HIP_TRY(hipMemcpyAsync(c->h_nu, (uint32_t*)c->ranges.p + 65540, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         max_load_now = c->h_nu[0];
     }
     if (!uniform) c->mixed_seen = true;
-    if (!uniform && !speculate && max_span <= qmcp::kMaxUniformSpan) {
+    if (!uniform && max_span <= qmcp::kMaxUniformSpan) {
         HIP_TRY(hipMemsetAsync(c->scalars.p, 0, 64, c->stream));
         TRY(near_uniform_tail(c, min_span, max_span, max_load, d_iters, near_done));
         if (near_done) {
             local.path = QMCP_PATH_NEAR_UNIFORM;
             sweep_done = ranked = true;
-            run.assumed_ranked = true;
         }
     }
     if (!uniform && !near_done) {
@@ -1206,7 +1160,6 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         HIP_TRY(hipEventRecord(c->ev[EV_SORT], s1));
         ranked = (uint64_t)max_load_now * kRankBalance <= (uint64_t)n;
         if (std::getenv("QMCP_HIP_NO_RANK") != nullptr) ranked = false;  // test hook: force the sort
-        run.assumed_ranked = ranked;
         // (the pass-major ranking can take its quotas from the event-driven sweep's own output: no expand, no selend[])
         bool expand_left_out = ranked && run.pm && std::getenv("QMCP_HIP_EXPAND") == nullptr;
         TRY(launch_uniform_sweep(c, s1, n, ltot, n_contigs, max_span, M, d_iters, empty_positions, &expand_left_out));
@@ -1220,7 +1173,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
                                       range_shift, ltot, (const uint32_t*)c->boff.p,
                                       (const uint32_t*)c->selend.p, (unsigned long long*)d_mask,
                                       (unsigned long long*)c->scalars.p, c->rankamb.p,
-                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p, run.mask_bit0,
+                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p,
                                       expand_left_out ? (const uint32_t*)c->cstart.p : nullptr, (const uint32_t*)c->evlast.p,
                                       (const uint64_t*)c->poff.p, n_contigs, max_span);
             HIP_TRY(hipGetLastError());
@@ -1230,7 +1183,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
                                    d_range_start, range_shift, ltot,
                                    (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p,
                                    (unsigned long long*)d_mask, (unsigned long long*)c->scalars.p,
-                                   c->rankamb.p, qmcp::rank_scratch_by_records(range_shift, ltot, n), run.mask_bit0);
+                                   c->rankamb.p, qmcp::rank_scratch_by_records(range_shift, ltot, n));
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1436,7 +1389,7 @@ int enqueue_tail(qmcp_hip_ctx* c, const uint32_t* assume = nullptr) {
         KernelSpan sp(c, "k_mark");
         qmcp::launch_mark(c->stream, wide, c->keys[kin].p, (const uint32_t*)c->vals[vin].p, ltot,
                           (const uint32_t*)c->boff.p, (const uint32_t*)c->selend.p, d_mask,
-                          (unsigned long long*)c->scalars.p, run.mask_bit0);
+                          (unsigned long long*)c->scalars.p);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[EV_MARK], c->stream));
@@ -1471,14 +1424,6 @@ int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
                 it[0], it[1], it[2], it[4], it[5], it[6], it[7], it[8]);
     }
 #endif
-    if (c->run.speculated) {
-        // the group's own statistics against what its tail was queued on
-        HIP_TRY(hipStreamSynchronize(c->stream2));
-        const uint32_t* hs = c->h_head;
-        const bool same = hs[0] == c->run.assumed[0] && hs[1] == c->run.assumed[1] && hs[2] == 0 &&
-                          (!c->run.assumed_ranked || (uint64_t)hs[3] * kRankBalance <= c->run.n64);
-        if (!same) return QMCP_ESPECULATION;
-    }
     qmcp_hip_stats local = c->pend_stats;
     const unsigned long long* host_scalars = c->h_scalars;
     if (c->pend_spiky) {
@@ -1488,6 +1433,8 @@ int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     local.n_kept = host_scalars[0];
     c->last_iters = (uint32_t)(host_scalars[2] & 0xFFFFFFFFu);
     c->last_blocks = (uint32_t)(host_scalars[2] >> 32);
+    local.sweep_blocks_changed = c->last_iters;
+    local.sweep_blocks = c->last_blocks;
     local.sweep_stretches = (uint32_t)(host_scalars[3] & 0xFFFFFFFFu) + c->pend_whole_contig_chains;
     local.spec_mismatches = (uint32_t)(host_scalars[4] & 0xFFFFFFFFu);
     local.spec_boundaries = (uint32_t)(host_scalars[4] >> 32);
@@ -1505,75 +1452,11 @@ int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     local.ms_mark = elapsed(c->ev[EV_SWEEP], c->ev[EV_MARK]);
     local.ms_total = elapsed(c->ev[EV_BEGIN], c->ev[EV_MARK]);
     local.arena_grown_mid_solve = c->grew_mid_solve;
-    local.contig_groups = 1;
     if (st) *st = local;
     return QMCP_OK;
 }
 
-int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
-    if (c->n_split == 0) return collect_one(c, st);
-    if (!c->pending) return fail(QMCP_EINVAL, "no solve is pending on this context");
-    c->pending = false;
-    const uint32_t groups = c->n_split;
-    c->n_split = 0;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms_last = 0.f;
-    qmcp_hip_stats sum;
-    std::memset(&sum, 0, sizeof(sum));
-    sum.min_span = 0xFFFFFFFFu;
-    sum.path = QMCP_PATH_UNIFORM;
-    int rc = QMCP_OK;
-    bool disagreed = false;
-    for (uint32_t g = 0; g < groups; ++g) {
-        qmcp_hip_stats k;
-        const int rk = collect_one(c->kids[g], &k);
-        if (rk == QMCP_ESPECULATION) { disagreed = true; continue; }
-        if (rk != QMCP_OK) { rc = rk; continue; }
-        const float ms_end = elapsed(c->ev[EV_BEGIN], c->kids[g]->ev[EV_MARK]);  // (one device: events compare across streams)
-        ms_last = ms_end > ms_last ? ms_end : ms_last;
-        sum.n_reads += k.n_reads;
-        sum.n_kept += k.n_kept;
-        sum.total_length += k.total_length;
-        sum.n_contigs += k.n_contigs;
-        if (k.path == QMCP_PATH_GENERAL) sum.path = QMCP_PATH_GENERAL;
-        if (k.n_reads) {
-            sum.min_span = k.min_span < sum.min_span ? k.min_span : sum.min_span;
-            sum.max_span = k.max_span > sum.max_span ? k.max_span : sum.max_span;
-        }
-        sum.sort_passes = k.sort_passes > sum.sort_passes ? k.sort_passes : sum.sort_passes;
-        sum.sweep_stretches += k.sweep_stretches;
-        sum.spec_boundaries += k.spec_boundaries;
-        sum.spec_mismatches += k.spec_mismatches;
-        sum.spec_retry_mismatches += k.spec_retry_mismatches;
-        sum.arena_grown_mid_solve += k.arena_grown_mid_solve;
-        // the groups overlap: per stage, the longest group's time (the total is the parent's own bracket)
-        sum.ms_prepare = k.ms_prepare > sum.ms_prepare ? k.ms_prepare : sum.ms_prepare;
-        sum.ms_scan = k.ms_scan > sum.ms_scan ? k.ms_scan : sum.ms_scan;
-        sum.ms_sort = k.ms_sort > sum.ms_sort ? k.ms_sort : sum.ms_sort;
-        sum.ms_sweep = k.ms_sweep > sum.ms_sweep ? k.ms_sweep : sum.ms_sweep;
-        sum.ms_mark = k.ms_mark > sum.ms_mark ? k.ms_mark : sum.ms_mark;
-        c->last_iters = c->kids[g]->last_iters;
-        c->last_blocks = c->kids[g]->last_blocks;
-    }
-    if (rc != QMCP_OK) return rc;
-    if (disagreed) {
-        // A group's tail was queued on the first group's read length and its own reads say otherwise (or one of
-        // its reads is invalid, or one of its ranges is too heavy to rank): the call is solved again, whole, the
-        // plain way -- which also reports an invalid read as the unsplit call would.
-        const auto& a = c->split_args;
-        TRY(enqueue_head(c, a.d_starts, a.d_ends, a.roff.data(), a.lengths.data(), (uint32_t)a.lengths.size(), a.n64,
-                         a.M, a.d_mask, 0, false));
-        TRY(enqueue_tail(c));
-        TRY(collect_one(c, st));
-        c->no_split = true;  // (valid data whose contigs differ in read length: this context solves whole from now on)
-        return QMCP_OK;
-    }
-    if (sum.min_span == 0xFFFFFFFFu) sum.min_span = 0;
-    sum.ms_total = ms_last;  // from the call's first launch to the last group's last
-    sum.contig_groups = groups;
-    if (st) *st = sum;
-    return QMCP_OK;
-}
+int solve_complete(qmcp_hip_ctx* c, qmcp_hip_stats* st) { return collect_one(c, st); }
 
 int create_ctx(int device, qmcp_hip_ctx** out_ctx) {
     if (!out_ctx) return fail(QMCP_EINVAL, "out_ctx is null");
@@ -1599,7 +1482,6 @@ int create_ctx(int device, qmcp_hip_ctx** out_ctx) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_head, 8 * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         qmcp_hip_destroy(c);
@@ -1610,149 +1492,21 @@ int create_ctx(int device, qmcp_hip_ctx** out_ctx) {
 }
 
 
-// Contig groups of a call (first contig of every group, + n_contigs at the end; one group: no split).
-// OPT-IN (QMCP_HIP_GROUPS=<n>: n groups of equal shares; QMCP_HIP_GROUPS=auto: two groups, the first with
-// QMCP_HIP_SPLIT_PCT per cent of the reads, default 63, on large deep multi-contig calls): measured on cfg4
-//  a split gains 4 % of the device time and nothing of the call's wall time.  With H the time
-// of all bandwidth-bound stages before the sweep, C a chain and R the ranking, a whole call takes H + C + R and two
-// groups at best H + C + (1 - f) R -- every chain still has to wait for its own group's H share and the last one
-// for all of H -- and the split kernels' extra boundaries (and the two rankings running beside each other) eat
-// most of f R: 1.26 against 1.31 ms.  What shortens one call is a shorter chain.
-std::vector<uint32_t> contig_groups_for(uint64_t n, uint32_t n_contigs, const uint64_t* roff, uint64_t ltot, uint32_t M) {
-    std::vector<uint32_t> first{0u};
-    std::vector<double> share_end;  // cumulative share of the reads at which each group but the last ends
-    if (n_contigs >= 2 && n != 0) {
-        const char* e = std::getenv("QMCP_HIP_GROUPS");
-        if (e && std::strcmp(e, "auto") == 0) {
-            // (the read length is not known before the first kernel has run: depth judged with 100 bases per read)
-            if (n >= (1ull << 24) && ltot != 0 && (double)n * 100.0 / ((double)ltot * (double)(M ? M : 1)) >= kGenDepth) {
-                double f = 0.63;
-                if (const char* p = std::getenv("QMCP_HIP_SPLIT_PCT")) f = std::strtod(p, nullptr) / 100.0;
-                share_end.push_back(f);
-            }
-        } else if (e) {
-            const uint32_t want = (uint32_t)std::strtoul(e, nullptr, 10);
-            for (uint32_t g = 1; g < want && g < n_contigs; ++g) share_end.push_back((double)g / want);
-        }
-    }
-    for (double f : share_end) {
-        const uint64_t want = (uint64_t)((double)n * f);
-        uint32_t k = first.back() + 1;
-        while (k < n_contigs && roff[k] < want) ++k;
-        if (k > first.back() + 1 && want - roff[k - 1] < roff[k] - want) --k;  // the nearer contig border
-        if (k >= n_contigs) break;
-        first.push_back(k);
-    }
-    first.push_back(n_contigs);
-    return first;
-}
-
 // Everything of a solve up to and including its last launch; nothing here waits for the device
 // except the small read-back that picks the route (span statistics, heaviest range), and that
 // wait leaves the device free to work on whatever else is queued.  solve_complete collects.
-// may_split: blocking entries only -- a caller of the two-phase entry keeps solves in flight himself, and
-// the next solve's bandwidth-bound stages are what runs beside a chain there.
 int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                   const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
-                  uint32_t M, uint64_t* d_mask, bool may_split = false) {
+                  uint32_t M, uint64_t* d_mask) {
     if (c->pending) return fail(QMCP_EINVAL, "a solve is already pending on this context (call qmcp_hip_solve_end)");
-    std::vector<uint32_t> first_contig{0u, n_contigs};
-    Problem whole;
-    if (may_split && !c->is_kid && !c->no_split && roff && lengths && n_contigs >= 2 &&
-        check_problem(roff, lengths, n_contigs, n64, whole) == QMCP_OK)
-        first_contig = contig_groups_for(n64, n_contigs, roff, whole.ltot, M);
-    const uint32_t groups = (uint32_t)first_contig.size() - 1;
-    if (groups <= 1) {
-        TRY(enqueue_head(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask, 0, false));
-        return enqueue_tail(c);
-    }
-    while (c->kids.size() < groups) {
-        qmcp_hip_ctx* k = nullptr;
-        TRY(create_ctx(c->device, &k));
-        k->is_kid = true;
-        c->kids.push_back(k);
-    }
-    c->kid_roff.resize(groups);
-    {
-        auto& a = c->split_args;
-        a.d_starts = d_starts; a.d_ends = d_ends; a.n64 = n64; a.M = M; a.d_mask = d_mask;
-        a.roff.assign(roff, roff + n_contigs + 1);
-        a.lengths.assign(lengths, lengths + n_contigs);
-    }
-    const bool trace = std::getenv("QMCP_HIP_TRACE") != nullptr;  // lab: host time of every enqueue step, to stderr
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto stamp = [&](const char* what, uint32_t g) {
-        if (trace)
-            fprintf(stderr, "[qmcp trace] %s %u at %.1f us\n", what, g,
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
-    };
-    HIP_TRY(hipEventRecord(c->ev[EV_BEGIN], c->stream));
-    // the groups share the mask's border words (a contig need not start at a multiple of 64 reads): cleared
-    // here once, only ever OR-ed into by them
-    const size_t mask_words = (size_t)((n64 + 63) / 64);
-    HIP_TRY(hipMemsetAsync(d_mask, 0, mask_words * sizeof(uint64_t), c->stream));
-    auto drain = [&](uint32_t from, uint32_t upto) {  // an error after groups were queued: let them finish, forget them
-        (void)hipStreamSynchronize(c->stream);
-        for (uint32_t g = from; g < upto; ++g) {
-            (void)hipStreamSynchronize(c->kids[g]->stream);
-            (void)hipStreamSynchronize(c->kids[g]->stream2);
-            c->kids[g]->pending = false;
-        }
-    };
-    // Heads, in order ON THE CALL'S OWN STREAM: group g + 1's bandwidth-bound stages behind group g's, so that the
-    // first groups' bucket offsets -- what their chains wait for -- are not held up by the last groups' partition,
-    // and without a wait packet between streams (one blocked at the head of a hardware queue for the length of a
-    // head slowed the other queues' dispatches: 40 us per kernel boundary in the rocprofv3 kernel trace).  Tails:
-    // the last group's follows its head on the same stream; the others run on the groups' own streams, each behind
-    // one short wait for its head's last kernel.
-    for (uint32_t g = 0; g < groups; ++g) {
-        qmcp_hip_ctx* k = c->kids[g];
-        k->profiling = c->profiling;
-        if (!k->own_stream) k->own_stream = k->stream;
-        k->stream_head = c->stream;
-        k->stream = g + 1 == groups ? c->stream : k->own_stream;
-        const uint32_t c0 = first_contig[g], c1 = first_contig[g + 1];
-        const uint64_t r0 = roff[c0];
-        std::vector<uint64_t>& ro = c->kid_roff[g];
-        ro.resize((size_t)(c1 - c0) + 1);
-        for (uint32_t x = c0; x <= c1; ++x) ro[x - c0] = roff[x] - r0;
-        int rc = enqueue_head(k, d_starts + r0, d_ends + r0, ro.data(), c->split_args.lengths.data() + c0, c1 - c0,
-                              roff[c1] - r0, M, d_mask + (r0 >> 6), (uint32_t)(r0 & 63u), true);
-        // (a small or empty group's head has no device-side end of its own)
-        if (rc == QMCP_OK && (!k->run.may_rank || k->run.trivial) && hipEventRecord(k->ev_head, c->stream) != hipSuccess)
-            rc = fail(QMCP_EHIP, "event record failed");
-        if (rc != QMCP_OK) {
-            drain(0, g + 1);
-            return rc;
-        }
-        stamp("head queued", g);
-    }
-    // tails: the first group's waits for its read-back; the others are queued on the same read length at once
-    // (checked when the solve is collected), so the device never waits for the host between groups
-    const uint32_t* assume = nullptr;
-    for (uint32_t g = 0; g < groups; ++g) {
-        qmcp_hip_ctx* k = c->kids[g];
-        int rc = enqueue_tail(k, assume);
-        if (rc == QMCP_OK && assume == nullptr && k->run.may_rank && !k->run.trivial) assume = k->h_head;
-        // (the parent's stream does not wait for the groups on the device: a wait packet blocked at the head of
-        //  one hardware queue for the length of a chain slowed every other queue's dispatches -- 40 us per kernel
-        //  boundary, rocprofv3 kernel trace; solve_complete waits for the groups' streams from the host)
-        if (rc != QMCP_OK) {
-            drain(0, groups);
-            return rc;
-        }
-        stamp("tail queued", g);
-    }
-    for (int i = EV_PREP; i <= EV_MARK; ++i) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
-    c->n_split = groups;
-    c->pending = true;
-    return QMCP_OK;
+    TRY(enqueue_head(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask));
+    return enqueue_tail(c);
 }
 
 int solve_on_device(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends,
                     const uint64_t* roff, const uint32_t* lengths, uint32_t n_contigs, uint64_t n64,
                     uint32_t M, uint64_t* d_mask, qmcp_hip_stats* st) {
-    TRY(solve_enqueue(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask, true));
+    TRY(solve_enqueue(c, d_starts, d_ends, roff, lengths, n_contigs, n64, M, d_mask));
     return solve_complete(c, st);
 }
 
@@ -1897,8 +1651,6 @@ int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx) { return create_ctx(devi
 
 void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (!c) return;
-    for (qmcp_hip_ctx* k : c->kids) qmcp_hip_destroy(k);
-    c->kids.clear();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -1923,12 +1675,10 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_head) (void)hipEventDestroy(c->ev_head);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->ev_go) (void)hipEventDestroy(c->ev_go);
     if (c->h_head) (void)hipHostFree(c->h_head);
     if (c->h_pm_rows) (void)hipHostFree(c->h_pm_rows);
     if (c->h_nu) (void)hipHostFree(c->h_nu);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->own_stream) c->stream = c->own_stream;  // (a group context's `stream` may stand for its parent's)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1937,7 +1687,6 @@ int qmcp_hip_set_profiling(qmcp_hip_ctx* c, int enabled) {
     if (!c) return fail(QMCP_EINVAL, "null context");
     c->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     c->acc.clear();
-    for (qmcp_hip_ctx* k : c->kids) { k->profiling = c->profiling; k->acc.clear(); }
     return QMCP_OK;
 }
 
@@ -1945,15 +1694,6 @@ int qmcp_hip_kernel_times(qmcp_hip_ctx* c, char* buf, size_t cap) {
     if (!c || !buf || cap == 0) return fail(QMCP_EINVAL, "null argument");
     size_t used = 0;
     buf[0] = 0;
-    // (a call dealt to contig groups ran its kernels on the groups' contexts: their times are added in)
-    for (qmcp_hip_ctx* k : c->kids)
-        for (const auto& ka : k->acc) {
-            bool found = false;
-            for (auto& a : c->acc)
-                if (a.name == ka.name) { a.launches += ka.launches; a.ms += ka.ms; found = true; break; }
-            if (!found) c->acc.push_back(ka);
-        }
-    for (qmcp_hip_ctx* k : c->kids) k->acc.clear();
     for (const auto& a : c->acc) {
         int w = snprintf(buf + used, cap - used, "%s\t%llu\t%.6f\n", a.name.c_str(),
                          (unsigned long long)a.launches, a.ms);

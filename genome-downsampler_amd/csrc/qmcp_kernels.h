@@ -125,7 +125,7 @@ void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_
                                     uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out);
 void launch_mark(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals, uint32_t ltot,
                  const uint32_t* boff, const uint32_t* selend, uint64_t* mask,
-                 unsigned long long* n_kept, uint32_t mask_bit0 = 0);
+                 unsigned long long* n_kept);
 void launch_bucket_heads(hipStream_t st, bool wide, const void* sorted, const uint32_t* svals,
                          uint32_t n, uint32_t span_bits, uint32_t ltot, uint32_t* boff);
 void launch_reverse_min_scan(hipStream_t st, uint32_t* data, uint32_t n, uint32_t* spine);
@@ -181,7 +181,7 @@ bool rank_scratch_by_records(uint32_t shift, uint32_t ltot, uint32_t n);
 void launch_rank_mark(hipStream_t st, const uint16_t* keys16, const uint32_t* idx,
                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
                       const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total,
-                      void* scratch, bool scratch_by_records, uint32_t mask_bit0 = 0);
+                      void* scratch, bool scratch_by_records);
 
 // range-ranked route, pass-major layout (kernels/pass_major.inc.hip): one-level genomes
 uint32_t pm_pitch(uint32_t n);     // row pitch of the [range][pass] tables
@@ -201,7 +201,7 @@ void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t*
                          const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
                          const uint32_t* boff, const uint32_t* selend,
                          unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                         uint32_t* chunk_cursor, uint32_t mask_bit0,
+                         uint32_t* chunk_cursor,
                          // quotas straight from the event-driven sweep's output (whole contigs, no stretch table), instead
                          // of selend[] - boff[]: the changed blocks' kept counts, the last changed block per block
                          const uint32_t* ev_sev = nullptr, const uint32_t* ev_lastns = nullptr,
@@ -224,7 +224,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                      const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,
                      uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */);
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
-                             unsigned long long* mask, uint32_t mask_bit0, unsigned long long* kept_total);
+                             unsigned long long* mask, unsigned long long* kept_total);
 
 }  // namespace qmcp
 #endif

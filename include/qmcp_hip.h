@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMCP_HIP_ABI_VERSION 3
+#define QMCP_HIP_ABI_VERSION 4
 
 enum {
     QMCP_OK = 0,
@@ -99,16 +99,31 @@ typedef struct qmcp_hip_stats {
                                  run-in                                                              */
     uint32_t spec_retry_mismatches; /* ... and how many disagreed in that sweep: those parts were
                                  swept exactly                                                       */
-    uint32_t contig_groups;   /* 1, or the number of contig groups a deep multi-contig call was dealt to
-                                 (each on a stream of its own: one group's selection chain runs beside the
-                                 next groups' bandwidth-bound stages)                                 */
+    uint32_t sweep_blocks_changed; /* event-driven sweep (deep data): blocks of one read length's positions that
+                                 changed the kept profile -- the chain's serial work is ~170 instructions per
+                                 changed block + ~60 per 16 blocks tested; block-scan sweeps: blocks redone in
+                                 the general form                                                     */
+    uint32_t sweep_blocks;    /* ... of this many blocks swept                                       */
     uint32_t arena_grown_mid_solve; /* device buffers that had to grow after the solve's first launch (a
                                  stall on queued work); 0 from the second call of a shape on         */
     uint32_t near_uniform_exceptions; /* QMCP_PATH_NEAR_UNIFORM (also when the route was tried and given up for
                                  the mixed-span one): reads shorter than the dominant span            */
     uint32_t near_uniform_selected;   /* ... of those, kept                                              */
     uint32_t near_uniform_rounds;     /* ... sweeps it took (1 = no exception was wanted by the sweep)   */
+    uint32_t near_uniform_giveup;     /* 0, or why the route handed the call to the mixed-span one: QMCP_NU_GIVEUP_* */
 } qmcp_hip_stats;
+
+/* qmcp_hip_stats.near_uniform_giveup */
+enum {
+    QMCP_NU_GIVEUP_NONE = 0,
+    QMCP_NU_GIVEUP_NOT_TRIED = 1,      /* switched off, small call, span or M outside the event-driven sweep, too shallow */
+    QMCP_NU_GIVEUP_LONGER_READS = 2,   /* the dominant span is not the longest (a deletion lengthens a read)              */
+    QMCP_NU_GIVEUP_TOO_MANY = 3,       /* more than a tenth of the reads are exceptions, or the list overflowed           */
+    QMCP_NU_GIVEUP_HEAVY_RANGE = 4,    /* one position range holds too many reads for the ranked route                    */
+    QMCP_NU_GIVEUP_UNMODELLED = 5,     /* a run of used-up buckets without an anchor, or too many suspects / neighbours   */
+    QMCP_NU_GIVEUP_BUDGET = 6,         /* the rounds did not settle within the budget                                     */
+    QMCP_NU_GIVEUP_REMEMBERED = 7      /* an earlier call of this shape on this context did not settle                    */
+};
 
 int qmcp_hip_abi_version(void);
 const char* qmcp_hip_last_error(void);

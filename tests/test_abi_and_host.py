@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     nm = subprocess.run(["nm", "-D", "--defined-only", pkg.HIP_LIB_PATH], capture_output=True, text=True)
     exported = set(re.findall(r" T (qmcp_hip_\w+)", nm.stdout))
     assert exported == set(declared)
-    assert pkg.abi_version() == 3
+    assert pkg.abi_version() == 4
 
 
 def test_signatures_are_plain_c(pkg):
