@@ -4,33 +4,39 @@
 // inside a range.  Its first form reads the reads twice before it can write them -- k_prepare (histogram of every
 // pass of 8 192 reads), a scan of the histograms, k_range_partition (re-reads the starts, writes 6 B per read to
 // where the scan says) -- because a range-major array needs every pass's counts before the first record can be
-// placed: 2.0 GB of the 3.2 GB a cfg4 solve moved.  Here the grouped array is never materialised:
+// placed.  Here the grouped array is never materialised (host model with every index asserted in bounds:
+// tests/pass_major_model.py, tests/test_pass_major_model.py):
 //   k_pm_prepare_sort   ONE pass over the reads (8 B per read in): validate, span statistics, clear the keep mask,
-//                       sort every pass of 8 192 reads by range IN PLACE -- slot P * 8192 + j of two 16-bit streams
-//                       holds the pass's j-th record in (range, read index) order: position inside the range and
-//                       read index inside the pass, 4 B per read out -- and two small tables laid out [range][pass]:
-//                       how many records of the range the pass holds, and where they begin inside the pass.
-//   (scan)              exclusive scan over the count table: T[d][P] = where pass P's slice of range d WOULD begin in
-//                       a range-major array -- the flat coordinate the consumers walk.
-//   k_pm_offsets        per range: LDS histogram of its slices' positions -> bucket offsets (k_range_offsets' job).
-//   k_pm_rank_mark      per range: k_rank_mark's ordered walk over the range's records in flat order; a wave finds
-//                       the slices under its 64 flat positions with a cursor over the range's row of T, kept in LDS.
-// A range's records in read-index order are its slices in pass order, so nothing about the selection changes:
-// the kept set is bit for bit the first form's.  tests/pass_major_model.py restates the layout and both mappings on
-// the host (every index asserted in bounds) and tests/test_pass_major_model.py runs it on ragged inputs.
-// One-level genomes only (<= 256 ranges); longer ones keep the two-level partition.
+//                       sort every pass of 8 192 reads by range; the pass's records of range d -- its SLICE (d, P) --
+//                       leave as two 16-bit streams (position inside the range, read index inside the pass: 4 B per
+//                       read) at a slot that is a multiple of 64: pass P owns the slots [P stride, (P + 1) stride),
+//                       stride = 8192 + 64 n_ranges, the slices follow each other padded to whole groups of 64 slots.
+//                       Two tables laid out [range][pass]: the slice's record count rounded up to a multiple of 64, and
+//                       (first slot - P stride) / 64 | true count << 16.
+//   (scan)              exclusive scan over the padded count table: Tp[d][P] = the PADDED FLAT position of the slice --
+//                       range d's records in read-index order are its slices in pass order, each padded to whole
+//                       groups, so a group of 64 padded flat positions (a WAVE-SLOT) lies in exactly one slice.
+//   k_pm_descr          one thread per table entry: one descriptor word per wave-slot, (first slot / 64) << 6 |
+//                       (records in the group - 1), and the inverse map slot group -> wave-slot; the rows' true counts
+//                       added up and scanned: the ranges' true flat starts (the bucket offsets' bases) + heaviest load.
+//   k_pm_offsets        per range: LDS histogram of its wave-slots' positions -> bucket offsets (k_range_offsets' job).
+//   k_pm_walk           per range: k_rank_mark's ordered walk, a chunk of sixteen wave-slots per step, each wave's
+//                       records found through ONE scalar descriptor (round 3 searched the table's row with a cursor in
+//                       LDS: 57 vector instructions per wave and chunk against the range-major walk's 21).  Kept
+//                       records are not marked one atomic at a time (32 B of HBM writes per kept bit): their slots go
+//                       to the range's kept list, every wave-slot notes where.
+//   k_pm_tiles          per pass: the pass's 128 mask words from the lists, every word written once.
+//   k_pm_settle         the (chunk, position) groups whose quota ran out inside a chunk, one wave per group, chip-wide.
+// A range's records in read-index order are its slices in pass order, so nothing about the selection changes: the
+// kept set is bit for bit the first form's.  One-level genomes only (<= 256 ranges); longer ones keep the two-level
+// partition, and so do calls whose slices would be short (narrow ranges: the padding would be most of a group).
 static constexpr int kPmPass = 8192;             // reads per pass
-#ifndef QMCP_PM_PAD
-#define QMCP_PM_PAD 0  // (measured: 0, 64 and 2048 slots of pad give the same times -- no channel aliasing to avoid)
-#endif
-// slots between the beginnings of two passes: a pass and a pad, so that the slices of one range in successive passes
-// are not a power of two apart (a range's kernels have dozens of them in flight)
-static constexpr uint32_t kPmStride = kPmPass + QMCP_PM_PAD;
+// slots between the beginnings of two passes: the pass's records and up to 63 slots of padding per range
+__host__ __device__ inline uint32_t pm_stride_of(uint32_t n_ranges) { return (uint32_t)kPmPass + 64u * n_ranges; }
 static constexpr int kPmThreads = 512;           // 8 waves: wave w owns records [1024 w, 1024 (w + 1)) of the pass
 static constexpr int kPmWaves = kPmThreads / 64;
 static constexpr int kPmPassesPerWg = 4;         // a workgroup's passes leave their table entries as 16-byte runs
-static constexpr uint32_t kPmMaxRow = 3072;      // passes of a range's row the consumers hold in LDS (2 x 12 KiB): 25 M reads over the contigs a range overlaps
-static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 128) * sizeof(uint32_t);
+static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 2 * 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 128 + kPmPassesPerWg) * sizeof(uint32_t);
 static constexpr uint32_t kPmExcPerWave = 128;  // list slots per wave and pass: an eighth of the wave's 1 024 reads
 
 #ifndef QMCP_PM_MIN_WAVES
@@ -39,8 +45,11 @@ static constexpr uint32_t kPmExcPerWave = 128;  // list slots per wave and pass:
 __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_sort(
     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends, uint32_t n,
     const uint64_t* __restrict__ contig_read_off, const uint64_t* __restrict__ contig_pos_off, uint32_t n_contigs,
-    uint32_t shift, uint16_t* __restrict__ keys16, uint16_t* __restrict__ idx16,
+    uint32_t shift, uint32_t stride /* pm_stride_of(ranges of the genome) */,
+    uint16_t* __restrict__ keys16, uint16_t* __restrict__ idx16,
     uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ lst_tab, uint32_t pitch /* multiple of 4 */,
+    uint32_t* __restrict__ used64 /* [pitch]: slot groups every pass uses */,
+    uint32_t* __restrict__ work /* 260 words k_pm_descr adds into: cleared here */,
     uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask,
     // near-uniform route (kernels/near_uniform.inc.hip): reads whose span is not ell_reg are left out of the sorted
     // passes and listed instead -- {global start, global end, read index}, three arrays of exc_cap words.  Every wave
@@ -52,11 +61,14 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     extern __shared__ uint32_t s_pm[];
     uint32_t* s_stage = s_pm;                           // [8192] a pass's records, sorted: key | index in pass << 16
     uint32_t* s_cnt = s_stage + kPmPass;                // [8][256] per-wave digit counts, then offsets
-    uint32_t* s_gbase = s_cnt + kPmWaves * 256;         // [256] where a digit's records begin inside the pass
-    uint32_t* s_wave = s_gbase + 256;                   // [16]
+    uint32_t* s_gbase = s_cnt + kPmWaves * 256;         // [256] where a digit's records begin inside the sorted pass
+    uint32_t* s_pbase = s_gbase + 256;                  // [256] ... and where its slice begins inside the pass's slots (padded)
+    uint32_t* s_wave = s_pbase + 256;                   // [16]
     uint32_t* s_tabc = s_wave + 16;                     // [4][256] the workgroup's table entries
     uint32_t* s_tabl = s_tabc + kPmPassesPerWg * 256;   // [4][256]
     uint32_t* s_exc = s_tabl + kPmPassesPerWg * 256;    // [8][128][3] every wave's exceptions of the pass, until the pass is written out
+    uint32_t* s_used = s_exc + kPmWaves * 3 * 128;      // [4] slot groups the workgroup's passes use
+    if (blockIdx.x == 0 && threadIdx.x < 260) work[threadIdx.x] = 0;  // (k_pm_descr's row sums and ticket)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
     auto contig_of = [&](uint32_t i) {
@@ -72,6 +84,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         const uint64_t base64 = (uint64_t)P * kPmPass;
         if (base64 >= n) {  // (uniform) a pass beyond the reads: zero table entries, the scan runs over the padding too
             if (threadIdx.x < 256) { s_tabc[g * 256 + threadIdx.x] = 0; s_tabl[g * 256 + threadIdx.x] = 0; }
+            if (threadIdx.x == 0) s_used[g] = 0;
             if (ell_reg != 0u && lane == 0 && P < pitch) exc_cnt[P * kPmWaves + w] = 0;
             continue;
         }
@@ -182,26 +195,35 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         }
         __syncthreads();
         if (threadIdx.x < 256) {
-            // digit d = threadIdx.x: its total over the waves, then (below) where it begins inside the pass
+            // digit d = threadIdx.x: its total over the waves, then (below) where it begins inside the sorted pass and
+            // where its slice -- padded to whole groups of 64 slots -- begins inside the pass's slots
             const uint32_t d = threadIdx.x;
             uint32_t tot = 0;
 #pragma unroll
             for (int x = 0; x < kPmWaves; ++x) tot += s_cnt[x * 256 + d];
+            const uint32_t ptot = (tot + 63u) & ~63u;
             const uint32_t inc = wave_incl_scan_add(tot);
-            if (lane == 63) s_wave[w] = inc;
+            const uint32_t pinc = wave_incl_scan_add(ptot);
+            if (lane == 63) { s_wave[w] = inc; s_wave[8 + w] = pinc; }
             s_gbase[d] = inc - tot;  // exclusive inside the wave; completed after the barrier
-            s_tabc[g * 256 + d] = tot;
+            s_pbase[d] = pinc - ptot;
+            s_tabc[g * 256 + d] = ptot;
+            s_tabl[g * 256 + d] = tot << 16;
         }
         __syncthreads();
         if (threadIdx.x < 256) {
             const uint32_t d = threadIdx.x;
-            uint32_t wave_base = 0;
-            for (int x = 0; x < w; ++x) wave_base += s_wave[x];
+            uint32_t wave_base = 0, pwave_base = 0;
+            for (int x = 0; x < w; ++x) { wave_base += s_wave[x]; pwave_base += s_wave[8 + x]; }
             const uint32_t tile_off = s_gbase[d] + wave_base;
+            const uint32_t ptile_off = s_pbase[d] + pwave_base;
             uint32_t run = tile_off;
 #pragma unroll
             for (int x = 0; x < kPmWaves; ++x) { const uint32_t cx = s_cnt[x * 256 + d]; s_cnt[x * 256 + d] = run; run += cx; }
-            s_tabl[g * 256 + d] = tile_off;
+            s_gbase[d] = tile_off;
+            s_pbase[d] = ptile_off;
+            s_tabl[g * 256 + d] |= ptile_off >> 6;   // (< 2^16: a pass has at most 8192 / 64 + 256 slot groups)
+            if (d == 255) s_used[g] = (ptile_off + s_tabc[g * 256 + 255]) >> 6;
         }
         __syncthreads();
 #pragma unroll
@@ -214,18 +236,28 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             }
         }
         __syncthreads();
-        // out, two records per thread and store: a dword of two positions, a dword of two indices (base and j are even)
-#pragma unroll
-        for (int k = 0; k < kSortItems / 2; ++k) {
-            const uint32_t j = 2u * (uint32_t)(k * kPmThreads + threadIdx.x);
-            if (j < count) {
-                const uint32_t v0 = s_stage[j];
-                const uint32_t v1 = j + 1 < count ? s_stage[j + 1] : 0u;
-                *reinterpret_cast<uint32_t*>(keys16 + (size_t)P * kPmStride + j) = (v0 & 0xFFFFu) | (v1 << 16);
-                *reinterpret_cast<uint32_t*>(idx16 + (size_t)P * kPmStride + j) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+        // out, slice by slice: wave w takes the digits w, w + 8, ...; two records per lane and store (a dword of two
+        // positions, a dword of two indices: slices begin at multiples of 64 slots, so every store is aligned)
+        {
+            const uint32_t my_d = (uint32_t)w + 8u * ((uint32_t)lane & 31u);
+            const uint32_t my_tot = lane < 32 ? s_tabl[g * 256 + my_d] >> 16 : 0u;
+            const uint32_t my_gb = s_gbase[my_d], my_pb = s_pbase[my_d];
+            uint64_t todo = __ballot(my_tot != 0u);
+            while (todo != 0ull) {  // uniform
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)my_tot, l);
+                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)my_gb, l);
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)my_pb, l);
+                const size_t out0 = (size_t)P * stride + pb;
+                for (uint32_t j = 2u * (uint32_t)lane; j < cnt; j += 128u) {
+                    const uint32_t v0 = s_stage[gb + j];
+                    const uint32_t v1 = j + 1 < cnt ? s_stage[gb + j + 1] : 0u;
+                    *reinterpret_cast<uint32_t*>(keys16 + out0 + j) = (v0 & 0xFFFFu) | (v1 << 16);
+                    *reinterpret_cast<uint32_t*>(idx16 + out0 + j) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+                }
             }
         }
-#ifndef QMCP_LAB_NO_EXC_OUT
         if (ell_reg != 0u) {
             const size_t slot0 = ((size_t)P * kPmWaves + w) * kPmExcPerWave;
             for (uint32_t r = (uint32_t)lane; r < min(filled, kPmExcPerWave); r += 64u) {
@@ -237,7 +269,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
                 exc_cnt[P * kPmWaves + w] = min(filled, kPmExcPerWave);
             }
         }
-#endif
         __syncthreads();  // (the next pass clears the counters and re-fills the stage)
     }
     __syncthreads();
@@ -252,6 +283,8 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             *reinterpret_cast<uint4*>(lst_tab + (size_t)threadIdx.x * pitch + P0) = b;
         }
     }
+    if (threadIdx.x < kPmPassesPerWg && blockIdx.x * kPmPassesPerWg + threadIdx.x < pitch)
+        used64[blockIdx.x * kPmPassesPerWg + threadIdx.x] = s_used[threadIdx.x];
     // statistics: block reduction, at most one atomic per statistic per workgroup (k_prepare)
     __shared__ uint32_t s_red[3][kPmWaves];
     mn = wave_min_u32(mn);
@@ -267,100 +300,128 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     }
 }
 
-// where every range begins in flat coordinates (257 entries) and the heaviest range's load, from the scanned table
-__global__ __launch_bounds__(256) void k_pm_range_table(const uint32_t* __restrict__ T, uint32_t pitch, uint32_t n,
-                                                        uint32_t* __restrict__ range_start, uint32_t* __restrict__ max_load) {
+// k_pm_descr's working words (cleared by k_pm_prepare_sort): [0..255] the rows' true record counts, [256] ticket
+static constexpr uint32_t kPmWorkWords = 260;
+
+// One thread per (range, pass) table entry: the slice's wave-slot descriptors and the inverse map; per range the true
+// record count (one atomic per workgroup and range); the last workgroup to finish scans the 256 counts into the
+// ranges' true flat starts (the bucket offsets' bases, the kept lists' and the ambiguity lists' bases) and the
+// heaviest range's load.
+__global__ __launch_bounds__(256) void k_pm_descr(const uint32_t* __restrict__ Tp, const uint32_t* __restrict__ lstw,
+                                                  uint32_t pitch, uint32_t s64 /* stride / 64 */, uint32_t n_groups /* total padded flat / 64 bound */,
+                                                  uint32_t* __restrict__ desc, uint32_t* __restrict__ inv,
+                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ range_start /* [257] */,
+                                                  uint32_t* __restrict__ max_load) {
     __shared__ uint32_t s_red[4];
-    const uint32_t d = threadIdx.x;
-    const uint32_t lo = T[(size_t)d * pitch];
-    const uint32_t hi = T[(size_t)(d + 1) * pitch];  // (d == 255: the scan's total -- the records listed, which the
-    range_start[d] = lo;                             //  near-uniform route makes fewer than the call's reads)
-    if (d == 255) range_start[256] = hi;
-    (void)n;
-    const uint32_t m = wave_max_u32(hi - lo);
-    if ((d & 63) == 0) s_red[d >> 6] = m;
+    __shared__ uint32_t s_last;
+    const uint32_t d = blockIdx.y, P = blockIdx.x * 256u + threadIdx.x;
+    uint32_t cnt = 0;
+    if (P < pitch) {
+        const uint32_t w = lstw[(size_t)d * pitch + P];
+        cnt = w >> 16;
+        if (cnt != 0u) {
+            const uint32_t g = Tp[(size_t)d * pitch + P] >> 6;
+            const uint32_t group = P * s64 + (w & 0xFFFFu);
+            const uint32_t n_ws = (cnt + 63u) >> 6;
+            for (uint32_t j = 0; j < n_ws; ++j) {
+                if (g + j < n_groups) {  // (always: the bound is the buffers' size)
+                    desc[g + j] = ((group + j) << 6) | (min(64u, cnt - 64u * j) - 1u);
+                    inv[group + j] = g + j;
+                }
+            }
+        }
+    }
+    const uint32_t sum = wave_sum_u32(cnt);
+    if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (d == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (tot != 0u) atomicAdd(&work[d], tot);
+        __threadfence();
+        const uint32_t ticket = atomicAdd(&work[256], 1u);
+        s_last = ticket == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;  // uniform
+    __threadfence();
+    // the last workgroup: exclusive scan of the 256 row counts
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t c = __hip_atomic_load(&work[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t inc = wave_incl_scan_add(c);
+    const uint32_t mx = wave_max_u32(c);
+    __syncthreads();
+    if (lane == 63u) s_red[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t x = 0; x < wv; ++x) base += s_red[x];
+    range_start[threadIdx.x] = base + inc - c;
+    if (threadIdx.x == 255u) range_start[256] = base + inc;
+    __syncthreads();
+    if (lane == 0u) s_red[wv] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-// k_range_offsets for the pass-major layout: the range's positions come as slices, one per pass, in any order.
-__global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ T,
-                                                     const uint32_t* __restrict__ lst_tab, uint32_t pitch,
-                                                     const uint32_t* __restrict__ rows /* [2][256]: p_lo, p_hi of every range (the host's pm_relevant_passes) */,
+// A wave-slot's descriptor, unpacked (uniform)
+struct PmSlot { uint32_t slot0, nv; };
+__device__ __forceinline__ PmSlot pm_unpack(uint32_t dsc, bool has) {
+    PmSlot s;
+    s.slot0 = has ? (dsc >> 6) << 6 : 0u;
+    s.nv = has ? (dsc & 63u) + 1u : 0u;
+    return s;
+}
+
+// k_range_offsets for the pass-major layout: the range's positions come as wave-slots, in any order.  A wave takes four
+// wave-slots at a time -- sixteen lanes each, four records (8 bytes) per lane: one 512-byte request -- and keeps kU
+// such requests in flight.
+__global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ desc,
+                                                     const uint32_t* __restrict__ Tp, uint32_t pitch,
+                                                     const uint32_t* __restrict__ range_start /* true flat starts */,
                                                      uint32_t shift, uint32_t ltot, uint32_t* __restrict__ boff,
                                                      uint32_t* __restrict__ empty_positions) {
-    extern __shared__ uint32_t s_cnt32[];  // [(1 << shift) padded] counters, then [kPmMaxRow + 1] + [kPmMaxRow] row copies
+    extern __shared__ uint32_t s_cnt32[];  // [(1 << shift) padded] counters
 #define PADDED(i) ((i) + ((i) >> 5))
     __shared__ uint32_t s_wsum[16], s_esum[16];
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
-    uint32_t* const s_T = s_cnt32 + width + (width >> 5) + 1;
-    uint32_t* const s_L = s_T + kPmMaxRow + 1;
-    const uint32_t lo = T[(size_t)range * pitch];
-    const uint32_t p_lo = rows[range], p_hi = rows[256 + range];
-    const uint32_t n_rel = min(p_hi - p_lo, kPmMaxRow);  // (the host takes this route only where no row is longer)
+    const uint32_t lo_p = Tp[(size_t)range * pitch], hi_p = Tp[(size_t)(range + 1) * pitch];
+    const uint32_t g0 = lo_p >> 6, n_ws = (hi_p - lo_p) >> 6;
+    const uint32_t lo = range_start[range];
     for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) s_cnt32[PADDED(i)] = 0;
-    for (uint32_t i = threadIdx.x; i <= n_rel; i += blockDim.x) s_T[i] = T[(size_t)range * pitch + p_lo + i];
-    for (uint32_t i = threadIdx.x; i < n_rel; i += blockDim.x) s_L[i] = lst_tab[(size_t)range * pitch + p_lo + i];
     __syncthreads();
-    auto count = [&](uint32_t li) {
-        if (li < width) atomicAdd(&s_cnt32[PADDED(li)], 1u);
-    };
-    // wave w takes the slices w, w + 16, ...; four slices' loads in flight (records four at a time, 8-byte loads from
-    // the 8-byte-aligned address at or below the slice: what lies outside the slice is the neighbouring ranges')
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    // Two batches of four slices alternate: the next batch's loads are under way while this one's are counted
-    // (single batches of eight left the wave idle for a trip to memory twelve to twenty-four times: 0.12 ms).
-    constexpr int U = 4;
-    struct Batch { uint32_t first[U], n_q[U], skip[U], end[U]; uint2 q[U][2]; };
-    auto fetch = [&](Batch& b, uint32_t k0) {
+    const uint32_t lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t sub = lane >> 4, l16 = lane & 15u;
+    constexpr int kU = 4;
+    const uint32_t n_quads = (n_ws + 3u) >> 2;
+    for (uint32_t q0 = w; q0 < n_quads; q0 += kU * nw) {
+        uint2 v[kU];
+        uint32_t nv[kU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t k = k0 + u * nw;
-            const uint32_t cnt = k < n_rel ? s_T[k + 1] - s_T[k] : 0u;
-            const uint32_t f = k < n_rel ? (p_lo + k) * kPmStride + s_L[k] : 0u;
-            const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);  // (uniform: scalar branches below)
-            const uint32_t fu = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-            b.first[u] = fu & ~3u;                       // aligned record index the quads start at
-            b.skip[u] = fu & 3u;                         // elements of the first quad that belong to the slice before
-            b.end[u] = b.skip[u] + cu;                   // one past the slice's last element, counted from first[u]
-            b.n_q[u] = cu ? (b.end[u] + 3u) >> 2 : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint2* __restrict__ quads = reinterpret_cast<const uint2*>(keys16 + b.first[u]);
-            b.q[u][0] = lane < b.n_q[u] ? quads[lane] : make_uint2(0u, 0u);
-            if (b.n_q[u] > 64u) b.q[u][1] = lane + 64u < b.n_q[u] ? quads[lane + 64u] : make_uint2(0u, 0u);
-        }
-    };
-    auto consume = [&](const Batch& b) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            auto count_quad = [&](uint2 v, uint32_t j) {
-                const uint32_t e0 = 4u * j;  // element index of the quad's first, from first[u]
-                if (e0 >= b.skip[u] && e0 < b.end[u]) count(v.x & 0xFFFFu);
-                if (e0 + 1 >= b.skip[u] && e0 + 1 < b.end[u]) count(v.x >> 16);
-                if (e0 + 2 >= b.skip[u] && e0 + 2 < b.end[u]) count(v.y & 0xFFFFu);
-                if (e0 + 3 >= b.skip[u] && e0 + 3 < b.end[u]) count(v.y >> 16);
-            };
-            if (lane < b.n_q[u]) count_quad(b.q[u][0], lane);
-            if (b.n_q[u] > 64u) {
-                if (lane + 64u < b.n_q[u]) count_quad(b.q[u][1], lane + 64u);
-                // slices longer than 128 quads (a pass whose reads fall into few ranges): the rest, plainly
-                for (uint32_t j = lane + 128u; j < b.n_q[u]; j += 64u)
-                    count_quad(reinterpret_cast<const uint2*>(keys16 + b.first[u])[j], j);
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t q = q0 + (uint32_t)u * nw;
+            // the lane's wave-slot of the quad: its descriptor (four scalar words, the lane's one picked out)
+            uint32_t dsc = 0;
+            bool has = false;
+            if (q < n_quads) {  // uniform
+                const uint32_t ws = 4u * q;
+                const uint32_t d0 = desc[g0 + ws];
+                const uint32_t d1 = ws + 1 < n_ws ? desc[g0 + ws + 1] : 0u;
+                const uint32_t d2 = ws + 2 < n_ws ? desc[g0 + ws + 2] : 0u;
+                const uint32_t d3 = ws + 3 < n_ws ? desc[g0 + ws + 3] : 0u;
+                dsc = sub == 0 ? d0 : sub == 1 ? d1 : sub == 2 ? d2 : d3;
+                has = ws + sub < n_ws;
             }
+            const uint32_t slot0 = has ? (dsc >> 6) << 6 : 0u;
+            nv[u] = has ? (dsc & 63u) + 1u : 0u;
+            v[u] = *reinterpret_cast<const uint2*>(keys16 + slot0 + 4u * l16);   // (inside the slice's padded group: always readable)
         }
-    };
-    {
-        Batch A, B;
-        const uint32_t step = U * nw;
-        uint32_t k0 = w;
-        if (k0 < n_rel) fetch(A, k0);
-        for (; k0 < n_rel; k0 += 2 * step) {
-            if (k0 + step < n_rel) fetch(B, k0 + step);
-            consume(A);
-            if (k0 + 2 * step < n_rel) fetch(A, k0 + 2 * step);
-            if (k0 + step < n_rel) consume(B);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t e = 4u * l16;
+            if (e < nv[u]) atomicAdd(&s_cnt32[PADDED(v[u].x & 0xFFFFu)], 1u);
+            if (e + 1 < nv[u]) atomicAdd(&s_cnt32[PADDED(v[u].x >> 16)], 1u);
+            if (e + 2 < nv[u]) atomicAdd(&s_cnt32[PADDED(v[u].y & 0xFFFFu)], 1u);
+            if (e + 3 < nv[u]) atomicAdd(&s_cnt32[PADDED(v[u].y >> 16)], 1u);
         }
     }
     __syncthreads();
@@ -375,10 +436,11 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
             empties += (cq == 0 && pos0 + firstp + qq < ltot) ? 1u : 0u;
         }
     const uint32_t inc = wave_incl_scan_add(sum);
-    if (lane == 63) s_wsum[w] = inc;
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 63) s_wsum[wv] = inc;
     if (empty_positions != nullptr) {
         empties = wave_sum_u32(empties);
-        if (lane == 0) s_esum[w] = empties;
+        if (lane == 0) s_esum[wv] = empties;
     }
     __syncthreads();
     if (empty_positions != nullptr && threadIdx.x == 0) {
@@ -387,7 +449,7 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
         if (total != 0) atomicAdd(empty_positions, total);
     }
     uint32_t run = lo + inc - sum;
-    for (uint32_t x = 0; x < w; ++x) run += s_wsum[x];
+    for (uint32_t x = 0; x < wv; ++x) run += s_wsum[x];
     if (firstp < width)
         for (uint32_t qq = 0; qq < per; ++qq) {
             const uint32_t cq = s_cnt32[PADDED(firstp + qq)];
@@ -400,83 +462,45 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
 #undef PADDED
 }
 
-// A wave's 64 consecutive flat positions [x0, x0 + 64) of a range -> the slots of their records.  `cur` is the wave's
-// cursor: the last pass (relative to p_lo) whose slice begins at or before the wave's previous first position; it
-// only moves forward.  tests/pass_major_model.py: wave_cursor_walk.  Returns the lane's slot; its pass is slot >> 13.
-__device__ __forceinline__ uint32_t pm_slot_of(const uint32_t* __restrict__ s_T, const uint32_t* __restrict__ s_L,
-                                               uint32_t n_rel, uint32_t p_lo, uint32_t& cur, uint32_t x0, uint32_t x,
-                                               uint32_t lane) {
-    uint32_t cand;
-    for (;;) {
-        const uint32_t i = cur + 1u + lane;
-        cand = i <= n_rel ? s_T[i] : 0xFFFFFFFFu;
-        const uint32_t nb = (uint32_t)__popcll(__ballot(cand <= x0));  // slices that begin at or before x0
-        cur += nb;
-        if (nb < 64u) {
-            if (nb != 0u) {  // (re-read relative to the cursor's new place)
-                const uint32_t i2 = cur + 1u + lane;
-                cand = i2 <= n_rel ? s_T[i2] : 0xFFFFFFFFu;
-            }
-            break;
-        }
-    }
-    const uint32_t n_in = (uint32_t)__popcll(__ballot(cand <= x0 + 63u));  // borders inside the wave's positions
-    uint32_t s = cur;
-    if (n_in < 64u) {
-        for (uint32_t t = 0; t < n_in; ++t) {  // uniform
-            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)t);
-            s += x >= b ? 1u : 0u;
-        }
-    } else {
-        // more than 63 borders under 64 positions (runs of empty slices): every lane searches the row
-        uint32_t lo = cur, hi = n_rel;  // last k with s_T[k] <= x
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_T[mid] <= x) lo = mid; else hi = mid;
-        }
-        s = lo;
-    }
-    s = min(s, n_rel - 1u);
-    return (p_lo + s) * kPmStride + s_L[s] + (x - s_T[s]);
-}
-
 // Where the quotas come from when the event-driven sweep ran whole contigs (no stretch table): the kept count of
 // position p is sev[p - (k - lastns[k]) * ell], k its block -- what k_sweep_expand would write into selend[] for the
 // ranking to read back (30 us and 100 MB a solve; here the ranking reads the sweep's own output).
 struct EvQuota { const uint32_t* sev; const uint32_t* lastns; const uint64_t* poff; uint32_t n_contigs, ell; };
 
-// k_rank_mark for the pass-major layout (the walk, the quota protocol and the settling of quota-crossing groups
-// are k_rank_mark's, word for word; what differs is where a record is found).
-__global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restrict__ keys16,
-                                                       const uint16_t* __restrict__ idx16,
-                                                       const uint32_t* __restrict__ T,
-                                                       const uint32_t* __restrict__ lst_tab, uint32_t pitch,
-                                                       const uint32_t* __restrict__ rows /* [2][256]: p_lo, p_hi of every range */,
-                                                       uint32_t shift, uint32_t ltot, uint32_t n,
-                                                       const uint32_t* __restrict__ boff,
-                                                       const uint32_t* __restrict__ selend,
-                                                       unsigned long long* __restrict__ mask,
-                                                       unsigned long long* __restrict__ kept_total,
-                                                       uint2* __restrict__ amb_lists, int lists_by_records,
-                                                       uint32_t* __restrict__ chunk_cursor /* [n / 1024 + 256]: wave 0's cursor per chunk */,
-                                                       EvQuota evq) {
-    extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas; then the range's rows of T [kPmMaxRow + 1] and lst [kPmMaxRow]
-    __shared__ uint32_t s_namb;
+// k_rank_mark's ordered walk for the pass-major layout: one workgroup (16 waves) per range, quota array q[p] = S(p) in
+// LDS, the range's wave-slots in order, sixteen (a CHUNK: one per wave) per step: `old = q[p]--`, barrier, `aft = q[p]`,
+// barrier; kept iff old > 0 -- except where the quota runs out inside the chunk (old > 0 but aft < 0: the draws of one
+// chunk come in no particular order): those groups are listed (chunk, position, -aft) by the record that drew
+// old == 1 and settled by k_pm_settle.  A wave's records are the 64 slots its descriptor names -- one scalar word, asked
+// for two rounds of the unrolled loop ahead -- and their positions are asked for kRankDepth - 1 chunks ahead, issued and
+// waited for by hand (see k_rank_mark).  Kept records: the wave adds its count to the range's running total (one LDS
+// atomic per wave and chunk, its answer picked up a chunk later so that nothing waits for it) and stores the kept
+// records' slots there in the range's kept list; kpw[wave-slot] = {where, how many} is what k_pm_tiles follows.
+__global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ desc,
+                                                  const uint32_t* __restrict__ Tp, uint32_t pitch,
+                                                  const uint32_t* __restrict__ range_start /* true flat starts */,
+                                                  uint32_t shift, uint32_t ltot,
+                                                  const uint32_t* __restrict__ boff, const uint32_t* __restrict__ selend,
+                                                  EvQuota evq,
+                                                  uint32_t* __restrict__ kept_list, uint2* __restrict__ kpw,
+                                                  uint2* __restrict__ amb_lists, int lists_by_records,
+                                                  uint32_t* __restrict__ amb_count /* [256] */,
+                                                  unsigned long long* __restrict__ kept_total) {
+    extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas
+    __shared__ uint32_t s_namb, s_total, s_kept;
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nw = nthreads >> 6;
-    const uint32_t lane = tid & 63u, w = tid >> 6;
-    uint32_t* const s_T = reinterpret_cast<uint32_t*>(s_q) + width + 1;
-    uint32_t* const s_L = s_T + kPmMaxRow + 1;
-    const uint32_t lo = T[(size_t)range * pitch];
-    const uint32_t hi = T[(size_t)(range + 1) * pitch];  // (range 255: the scan's total)
-    if (lo >= hi) return;  // uniform: a range without reads needs no quotas either
-    const uint32_t p_lo = rows[range], p_hi = rows[256 + range];
-    const uint32_t n_rel = min(p_hi - p_lo, kPmMaxRow);
-    uint2* const amb = amb_lists + (lists_by_records ? (size_t)lo : (size_t)range * width);
-    uint32_t* const ccur = chunk_cursor + (lo >> 10) + range;  // (ranges' chunk counts add up to at most n / 1024 + one each)
-    for (uint32_t i = tid; i <= n_rel; i += nthreads) s_T[i] = T[(size_t)range * pitch + p_lo + i];
-    for (uint32_t i = tid; i < n_rel; i += nthreads) s_L[i] = lst_tab[(size_t)range * pitch + p_lo + i];
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t lo_p = Tp[(size_t)range * pitch];
+    const uint32_t hi_p = Tp[(size_t)(range + 1) * pitch];  // (range 255: the scan's total)
+    if (tid == 0) amb_count[range] = 0;
+    if (lo_p >= hi_p) return;  // uniform: a range without reads needs no quotas either
+    const uint32_t g0 = lo_p >> 6, n_ws = (hi_p - lo_p) >> 6;
+    const uint32_t n_chunks = (n_ws + 15u) >> 4;
+    const uint32_t lo_true = range_start[range];
+    uint2* const amb = amb_lists + (lists_by_records ? (size_t)lo_true : (size_t)range * width);
     if (evq.sev != nullptr) {
         // straight from the event-driven sweep's output (two dependent loads per position, eight positions in flight)
         for (uint32_t i0 = tid; i0 < live; i0 += 8 * nthreads) {
@@ -513,175 +537,247 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
         for (int u = 0; u < 8; ++u)
             if (i0 + u * nthreads < live) s_q[i0 + u * nthreads] = (int32_t)(a[u] - b[u]);
     }
-    if (tid == 0) s_namb = 0;
+    if (tid == 0) { s_namb = 0; s_total = 0; s_kept = 0; }
     __syncthreads();
-    const uint32_t chunk_recs = nthreads;
-    const uint32_t n_chunks = (hi - lo + chunk_recs - 1) / chunk_recs;
-    uint32_t kept = 0;
-    uint32_t cur = 0;  // the wave's cursor over the range's row
 
-    struct Recs { uint32_t key, val, slot; };
-    // The wave's cursor and the row entries at it (uniform): slice `cur` begins at flat position t_cur, at l_cur inside
-    // its pass.  A fetch reads the next 64 row entries (one LDS read per table), counts the slices that begin at or
-    // before the wave's first position (the cursor moves on by that many) and those that begin inside its 64
-    // positions; every lane then picks its slice's entries out of the candidate registers by lane number -- no
-    // dependent LDS gathers.  More than 63 borders under one read (runs of empty slices): pm_slot_of, the plain way.
-    uint32_t t_cur = s_T[0], l_cur = s_L[0];
-    auto cand_read = [&](uint32_t& cand_t, uint32_t& cand_l) {
-        const uint32_t i = cur + 1u + lane;
-        cand_t = i <= n_rel ? s_T[i] : 0xFFFFFFFFu;
-        cand_l = i < n_rel ? s_L[i] : 0u;
+    // The loads in flight -- positions and descriptors of the chunks ahead -- land in registers the COMPILER NEVER SEES:
+    // v96..v103 (positions of the chunk consumed at slot k of the unrolled loop), v104..v111 (descriptors), v112 (the
+    // answer of the wave's list-space request).  They are named in the assembly, issued and waited for by hand, and every
+    // assembly statement of the kernel lists all of them as clobbered, so the compiler keeps nothing of its own there.
+    // The first form of this kernel held them in compiler-allocated registers, as k_rank_mark does: the compiler then
+    // kept a loop-carried descriptor in another register than the one its load writes and COPIED it at the loop's end --
+    // a copy of a register whose load is still in flight, i.e. of what was there before: cfg4 came out different from
+    // run to run, one run ended in a memory access fault (a stale descriptor's slots); small inputs never showed it.
+    // tools/isa_hazards.py checks the assembly for such reads and that v96..v112 occur in hand-written assembly only
+    // (tests/test_isa_hazards.py).
+#define QMCP_PM_RING "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112"
+#define QMCP_PM_KEYREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_KEY_, k))
+#define QMCP_PM_DSCREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_DSC_, k))
+#define QMCP_PM_STR(x) QMCP_PM_STR2(x)
+#define QMCP_PM_STR2(x) #x
+#define QMCP_PM_CAT(a, b) QMCP_PM_CAT2(a, b)
+#define QMCP_PM_CAT2(a, b) a##b
+#define QMCP_PM_KEY_0 96
+#define QMCP_PM_KEY_1 97
+#define QMCP_PM_KEY_2 98
+#define QMCP_PM_KEY_3 99
+#define QMCP_PM_KEY_4 100
+#define QMCP_PM_KEY_5 101
+#define QMCP_PM_KEY_6 102
+#define QMCP_PM_KEY_7 103
+#define QMCP_PM_DSC_0 104
+#define QMCP_PM_DSC_1 105
+#define QMCP_PM_DSC_2 106
+#define QMCP_PM_DSC_3 107
+#define QMCP_PM_DSC_4 108
+#define QMCP_PM_DSC_5 109
+#define QMCP_PM_DSC_6 110
+#define QMCP_PM_DSC_7 111
+    static_assert(kRankDepth == 8, "the ring registers are named for eight slots");
+    struct Slot { uint32_t slot0, nv; };  // of a chunk whose positions are in flight or being consumed (uniform; the compiler's)
+    auto desc_offset = [&](uint32_t c) -> uint32_t {  // byte offset of the wave's descriptor of chunk c (the range's last beyond it: never used)
+        return (g0 + min(16u * c + w, n_ws - 1u)) * 4u;
     };
-    auto slot_from = [&](uint32_t cand_t, uint32_t cand_l, uint32_t c) -> uint32_t {
-        const uint32_t x0 = min(lo + c * chunk_recs + 64u * w, hi - 1);
-        const uint32_t x = min(lo + c * chunk_recs + tid, hi - 1);
-        const uint32_t nb = (uint32_t)__popcll(__ballot(cand_t <= x0));
-        const uint32_t tot = (uint32_t)__popcll(__ballot(cand_t <= x0 + 63u));
-        uint32_t slot;
-        if (tot < 64u) {
-            if (nb != 0u) {
-                t_cur = (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)(nb - 1u));
-                l_cur = (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)(nb - 1u));
-                cur += nb;
-            }
-            uint32_t ts = t_cur, ls = l_cur, sl = cur;
-            for (uint32_t t = nb; t < tot; ++t) {  // uniform: the borders inside the wave's positions
-                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)t);
-                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)t);
-                const bool in = x >= b;
-                ts = in ? b : ts;
-                ls = in ? l : ls;
-                sl += in ? 1u : 0u;
-            }
-            sl = min(sl, n_rel - 1u);
-            slot = (p_lo + cur) * kPmStride + __umul24(sl - cur, kPmStride) + ls + (x - ts);  // (uniform base + a small per-lane part)
-        } else {
-            slot = pm_slot_of(s_T, s_L, n_rel, p_lo, cur, x0, x, lane);
-            t_cur = s_T[cur];
-            l_cur = s_L[min(cur, n_rel - 1u)];
+    auto slot_of = [&](uint32_t dsc, uint32_t c) -> Slot {
+        const bool has = 16u * c + w < n_ws;  // uniform
+        Slot s;
+        s.slot0 = has ? (dsc >> 6) << 6 : 0u;
+        s.nv = has ? (dsc & 63u) + 1u : 0u;
+        return s;
+    };
+    uint32_t kept = 0;
+    // what the previous chunk left to do once the answer of its list-space request is in: the wave's kept lanes, their
+    // first slot, the wave-slot
+    uint64_t pend_kb = 0;
+    uint32_t pend_slot0 = 0, pend_g = 0xFFFFFFFFu;
+    bool pend_asked = false;
+    const uint32_t total_addr = (uint32_t)(uintptr_t)&s_total;
+    auto flush = [&]() {
+        if (pend_g == 0xFFFFFFFFu) return;  // uniform
+        uint32_t ans = 0;
+        if (pend_asked) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, v112" : "=v"(ans) : : QMCP_PM_RING, "memory");  // (lane 0's is the answer)
+        const uint32_t cw = (uint32_t)__popcll(pend_kb);
+        const uint32_t base = lo_true + (uint32_t)__builtin_amdgcn_readfirstlane((int)ans);
+        if ((pend_kb >> lane) & 1ull) {
+            const uint32_t below = (uint32_t)__popcll(pend_kb & ((1ull << lane) - 1ull));
+            kept_list[base + below] = pend_slot0 + lane;
         }
-        // (wave 0's cursor at the chunk's first position, for the settling pass below; read after the walk)
-        if (w == 0 && lane == 0 && c < n_chunks) ccur[c] = cur;
-#ifdef QMCP_LAB_PM_TRIVIAL_SLOT  // (lab: the look-up's arithmetic kept, its result replaced by the flat position -- wrong masks)
-        slot = (slot & 1u) + (x & ~1u);
-#endif
-        return slot;
+        if (lane == 0) kpw[pend_g] = make_uint2(base, cw);
+        pend_g = 0xFFFFFFFFu;
     };
-    auto issue = [&](Recs& dst) {
-        asm volatile("global_load_ushort %0, %2, %3\n\tglobal_load_ushort %1, %2, %4"
-                     : "=&v"(dst.key), "=&v"(dst.val)
-                     : "v"(dst.slot * 2u), "s"(keys16), "s"(idx16)
-                     : "memory");
-    };
-    // One slot of the walk: chunk c is consumed from `r` while chunk c + kRankDepth - 1 is looked up and asked for
-    // into `f`.  The look-up's LDS reads are issued before the quota draw and used after the first barrier, its
-    // arithmetic runs between the barriers: the walk is bound by the latency of its two LDS round trips and two
-    // barriers per chunk, and the look-up hides in them (as a block in front of the draw it cost 0.14 ms at cfg4).
-    auto step = [&](Recs& r, Recs& f, uint32_t c) {
-        uint32_t cand_t, cand_l;
-#ifdef QMCP_LAB_PM_NO_LOOKUP  // (lab: no look-up at all, records read at their flat positions -- wrong masks)
-        cand_t = 0xFFFFFFFFu; cand_l = 0;
-#else
-        cand_read(cand_t, cand_l);
-#endif
-        // the chunk's records have landed once at most the loads of the kRankDepth - 2 chunks asked for after it are
-        // outstanding (this slot's own request comes below)
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.key), "+v"(r.val) : "n"(2 * (kRankDepth - 2)) : "memory");
-        const bool valid = lo + c * chunk_recs + tid < hi;
-        const uint32_t li = valid ? r.key : width;
-        const int32_t old = atomicSub(&s_q[li], 1);
-        // (the look-up's arithmetic sits between the draw and its barrier: it runs while the LDS atomic is under way)
-#ifdef QMCP_LAB_PM_NO_LOOKUP
-        f.slot = min(lo + (c + (uint32_t)(kRankDepth - 1)) * chunk_recs + tid, hi - 1);
-#else
-        f.slot = slot_from(cand_t, cand_l, c + (uint32_t)(kRankDepth - 1));
-#endif
-        __syncthreads();
-        const int32_t aft = s_q[li];
-        issue(f);
-        const bool keep = valid && old > 0 && aft >= 0;
-        if (valid && old == 1 && aft < 0) {
-            const uint32_t k = atomicAdd(&s_namb, 1u);
-            amb[k] = make_uint2((c << 15) | li, (uint32_t)(-aft));  // c < 2^17, li < 2^15
-        }
-        __syncthreads();  // every q_after is read before the next chunk draws
-        if (keep) {
-            const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (r.slot & ~(uint32_t)(kPmPass - 1)) : (r.slot / kPmStride) * (uint32_t)kPmPass) + r.val;  // pass * 8192 + index in pass
-            atomicOr(&mask[v >> 6], 1ull << (v & 63u));
-        }
-        kept += (uint32_t)__popcll(__ballot(keep));
-    };
-    Recs R[kRankDepth];
-#pragma unroll
-    for (int k = 0; k < kRankDepth - 1; ++k) {
-        uint32_t cand_t, cand_l;
-        cand_read(cand_t, cand_l);
-        R[k].slot = slot_from(cand_t, cand_l, (uint32_t)k);
-        issue(R[k]);
+    // One slot of the walk (K: its place in the unrolled loop, KF = (K + 7) % 8): chunk c is consumed from ring slot K;
+    // chunk c + 7's positions are asked for into slot KF through slot K's descriptor (asked for eight slots ago), and
+    // slot K's descriptor is asked for again, for chunk c + 15.
+    // Loads complete in issue order.  Per slot two are issued: positions, then a descriptor.  The positions of chunk c
+    // were asked for seven slots ago and 13 loads have been issued since; the descriptor read with them is older still.
+    // (Younger stores only make the wait longer.)
+#define QMCP_PM_STEP(K, KF)                                                                                                   \
+    {                                                                                                                         \
+        const uint32_t c = c0 + (uint32_t)(K);                                                                                \
+        uint32_t key, dsc;                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(13)\n\tv_mov_b32 %0, " QMCP_PM_KEYREG(K) "\n\tv_mov_b32 %1, " QMCP_PM_DSCREG(K)          \
+                     : "=v"(key), "=v"(dsc) : : QMCP_PM_RING, "memory");                                                      \
+        const Slot at = S[K];                                                                                                 \
+        const bool valid = lane < at.nv;                                                                                      \
+        int32_t old = 0;                                                                                                      \
+        if (valid) old = atomicSub(&s_q[key], 1); /* (the 16-bit load zero-extends) */                                        \
+        S[KF] = slot_of(dsc, c + 7u);                                                                                         \
+        asm volatile("global_load_ushort " QMCP_PM_KEYREG(KF) ", %0, %1\n\tglobal_load_dword " QMCP_PM_DSCREG(K) ", %2, %3"     \
+                     : : "v"((S[KF].slot0 + lane) * 2u), "s"(keys16), "v"(desc_offset(c + 15u)), "s"(desc)                    \
+                     : QMCP_PM_RING, "memory");                                                                               \
+        __syncthreads();                                                                                                      \
+        int32_t aft = 0;                                                                                                      \
+        if (valid) aft = s_q[key];                                                                                            \
+        flush(); /* (the previous chunk's kept records: its request's answer came in with the LDS reads above) */             \
+        const bool keep = valid && old > 0 && aft >= 0;                                                                       \
+        if (valid && old == 1 && aft < 0) {                                                                                   \
+            const uint32_t k = atomicAdd(&s_namb, 1u);                                                                        \
+            amb[k] = make_uint2((c << 15) | key, (uint32_t)(-aft)); /* c < 2^17, key < 2^15 */                                \
+        }                                                                                                                     \
+        __syncthreads(); /* every q_after is read before the next chunk draws */                                              \
+        const uint64_t kb = __ballot(keep);                                                                                   \
+        if (at.nv != 0u) { /* uniform: the wave has a wave-slot in this chunk */                                              \
+            const uint32_t cw = (uint32_t)__popcll(kb);                                                                       \
+            pend_kb = kb;                                                                                                     \
+            pend_slot0 = at.slot0;                                                                                            \
+            pend_g = g0 + 16u * c + w;                                                                                        \
+            pend_asked = cw != 0u;                                                                                            \
+            /* (by hand: the compiler would wait for the answer on the spot) */                                               \
+            if (cw != 0u && lane == 0)                                                                                        \
+                asm volatile("ds_add_rtn_u32 v112, %0, %1" : : "v"(total_addr), "v"(cw) : QMCP_PM_RING, "memory");            \
+            kept += cw;                                                                                                       \
+        }                                                                                                                     \
     }
-    for (uint32_t c = 0; c < n_chunks; c += kRankDepth) {
+    Slot S[kRankDepth];
+    {
+        // chunks 0..6: descriptors the plain way (nothing is in flight yet), their positions into the ring; descriptors
+        // of chunks 7..14 into the ring; then everything is waited for once -- the loop's counted wait assumes its own
+        // issue order (positions, descriptor, positions, ...), which these requests do not have
+        uint32_t d0[kRankDepth - 1];
 #pragma unroll
-        for (int k = 0; k < kRankDepth; ++k) step(R[k], R[(k + kRankDepth - 1) % kRankDepth], c + (uint32_t)k);
+        for (int k = 0; k < kRankDepth - 1; ++k) d0[k] = desc[desc_offset((uint32_t)k) / 4u];
+#pragma unroll
+        for (int k = 0; k < kRankDepth - 1; ++k) S[k] = slot_of(d0[k], (uint32_t)k);
+        S[kRankDepth - 1] = Slot{0u, 0u};
+#define QMCP_PM_ASK_KEYS(K) asm volatile("global_load_ushort " QMCP_PM_KEYREG(K) ", %0, %1" : : "v"((S[K].slot0 + lane) * 2u), "s"(keys16) : QMCP_PM_RING, "memory");
+#define QMCP_PM_ASK_DSC(K) asm volatile("global_load_dword " QMCP_PM_DSCREG(K) ", %0, %1" : : "v"(desc_offset(7u + (uint32_t)(K))), "s"(desc) : QMCP_PM_RING, "memory");
+        QMCP_PM_ASK_KEYS(0) QMCP_PM_ASK_KEYS(1) QMCP_PM_ASK_KEYS(2) QMCP_PM_ASK_KEYS(3) QMCP_PM_ASK_KEYS(4) QMCP_PM_ASK_KEYS(5) QMCP_PM_ASK_KEYS(6)
+        QMCP_PM_ASK_DSC(0) QMCP_PM_ASK_DSC(1) QMCP_PM_ASK_DSC(2) QMCP_PM_ASK_DSC(3) QMCP_PM_ASK_DSC(4) QMCP_PM_ASK_DSC(5) QMCP_PM_ASK_DSC(6) QMCP_PM_ASK_DSC(7)
+        asm volatile("s_waitcnt vmcnt(0)" : : : QMCP_PM_RING, "memory");
+#undef QMCP_PM_ASK_KEYS
+#undef QMCP_PM_ASK_DSC
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads asked for beyond the last chunk; ccur is written)
-    // settle the listed (chunk, position) groups: one wave per entry, walking the chunk backwards
-    __threadfence_block();
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += kRankDepth) {
+        QMCP_PM_STEP(0, 7) QMCP_PM_STEP(1, 0) QMCP_PM_STEP(2, 1) QMCP_PM_STEP(3, 2)
+        QMCP_PM_STEP(4, 3) QMCP_PM_STEP(5, 4) QMCP_PM_STEP(6, 5) QMCP_PM_STEP(7, 6)
+    }
+#undef QMCP_PM_STEP
+    asm volatile("s_waitcnt vmcnt(0)" : : : QMCP_PM_RING, "memory");  // (the loads asked for beyond the last chunk)
+    flush();
+    if (lane == 0 && kept) atomicAdd(&s_kept, kept);
     __syncthreads();
-    const uint32_t namb = s_namb;
+    if (tid == 0) {
+        amb_count[range] = s_namb;
+        if (s_kept) atomicAdd(kept_total, (unsigned long long)s_kept);
+    }
+}
+
+// The keep mask of one pass (8 192 reads, 128 words) from the kept lists: the pass's slot groups -> wave-slots (inv[]) ->
+// where each wave-slot's kept records went (kpw[]) -> their slots (kept_list[]) -> their read indices inside the pass
+// (idx16[]); bits are gathered in LDS and every word is written once.
+__global__ __launch_bounds__(256) void k_pm_tiles(const uint32_t* __restrict__ used64, const uint32_t* __restrict__ inv,
+                                                  const uint2* __restrict__ kpw, const uint32_t* __restrict__ kept_list,
+                                                  const uint16_t* __restrict__ idx16, uint32_t s64, uint32_t n,
+                                                  unsigned long long* __restrict__ mask) {
+    __shared__ uint32_t s_m[256];        // the pass's 128 mask words, as halves
+    __shared__ uint32_t s_pos[512];      // per slot group: where its kept records are listed
+    __shared__ uint32_t s_pref[513];     // ... and how many kept records the groups before it have
+    __shared__ uint32_t s_wsum[4];
+    const uint32_t P = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if ((uint64_t)P * kPmPass >= n) return;  // (uniform)
+    const uint32_t u = min(used64[P], 512u);  // (at most 8192 / 64 + 256 = 384)
+    s_m[tid] = 0;
+    uint32_t c0 = 0, c1 = 0;
+    {
+        const uint32_t t0 = 2u * tid, t1 = 2u * tid + 1u;
+        if (t0 < u) { const uint2 kp = kpw[inv[(size_t)P * s64 + t0]]; s_pos[t0] = kp.x; c0 = kp.y; }
+        if (t1 < u) { const uint2 kp = kpw[inv[(size_t)P * s64 + t1]]; s_pos[t1] = kp.x; c1 = kp.y; }
+    }
+    const uint32_t inc = wave_incl_scan_add(c0 + c1);
+    if (lane == 63u) s_wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t x = 0; x < wv; ++x) base += s_wsum[x];
+    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    s_pref[2u * tid] = base + inc - c0 - c1;
+    s_pref[2u * tid + 1u] = base + inc - c1;
+    if (tid == 255u) s_pref[512] = total;
+    __syncthreads();
+    for (uint32_t e = tid; e < total; e += 256u) {
+        uint32_t lo = 0, hi = 512;  // last group t with pref[t] <= e (groups beyond u hold no records: pref stays at total)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= e) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = kept_list[s_pos[lo] + (e - s_pref[lo])];
+        const uint32_t i = idx16[slot];
+        atomicOr(&s_m[(i >> 5) & 255u], 1u << (i & 31u));
+    }
+    __syncthreads();
+    if (tid < 128u) {
+        const uint64_t word = (uint64_t)P * 128u + tid;
+        if (word < ((uint64_t)n + 63u) / 64u) mask[word] = (unsigned long long)s_m[2u * tid] | ((unsigned long long)s_m[2u * tid + 1u] << 32);
+    }
+}
+
+// The listed (chunk, position) groups of every range: the position's `skip` LAST records of that chunk are the ones the
+// quota did not reach, so a wave walks the chunk's sixteen wave-slots backwards, passes over that many matches and
+// keeps the rest (their bits: the tile pass has written every word by now).  grid (ranges, kPmSettleY), four waves per
+// workgroup: a range's groups are dealt to 4 kPmSettleY waves.
+static constexpr uint32_t kPmSettleY = 16;
+__global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ keys16, const uint16_t* __restrict__ idx16,
+                                                   const uint32_t* __restrict__ desc, const uint32_t* __restrict__ Tp,
+                                                   uint32_t pitch, const uint32_t* __restrict__ range_start, uint32_t shift,
+                                                   uint32_t s64, const uint2* __restrict__ amb_lists, int lists_by_records,
+                                                   const uint32_t* __restrict__ amb_count,
+                                                   unsigned long long* __restrict__ mask,
+                                                   unsigned long long* __restrict__ kept_total) {
+    __shared__ uint32_t s_kept;
+    const uint32_t range = blockIdx.x, width = 1u << shift;
+    const uint32_t namb = amb_count[range];
+    if (namb == 0u) return;  // uniform
+    if (threadIdx.x == 0) s_kept = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lo_p = Tp[(size_t)range * pitch], hi_p = Tp[(size_t)(range + 1) * pitch];
+    const uint32_t g0 = lo_p >> 6, n_ws = (hi_p - lo_p) >> 6;
+    const uint2* const amb = amb_lists + (lists_by_records ? (size_t)range_start[range] : (size_t)range * width);
     const uint64_t gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // lanes above this one
-    for (uint32_t k = w; k < namb; k += nw) {
+    uint32_t kept = 0;
+    for (uint32_t k = blockIdx.y * 4u + w; k < namb; k += 4u * gridDim.y) {
         const uint2 ent = amb[k];
         const uint32_t c = ent.x >> 15, p = ent.x & 0x7FFFu;
         uint32_t skip = ent.y;  // matches still to be passed over, from the chunk's end
-        const uint32_t first = lo + c * chunk_recs;
-        const uint32_t last = min(first + chunk_recs, hi);
-        constexpr int kSteps = 16;  // blockDim.x == 1024: 64-record steps per chunk
-        uint32_t key[kSteps], slot[kSteps];
-        uint32_t scur = __hip_atomic_load(&ccur[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (uniform; own workgroup's store)
-        scur = (uint32_t)__builtin_amdgcn_readfirstlane((int)scur);
-        {
-            // the chunk's 1024 positions cross few slices: ONE read of the 64 row entries behind the chunk's cursor serves
-            // all sixteen steps from registers (more than 63 borders inside a chunk: step by step through pm_slot_of)
-            const uint32_t ci = scur + 1u + lane;
-            const uint32_t cand_t = ci <= n_rel ? s_T[ci] : 0xFFFFFFFFu;
-            const uint32_t cand_l = ci < n_rel ? s_L[ci] : 0u;
-            const uint32_t t0 = s_T[scur], l0 = s_L[min(scur, n_rel - 1u)];
-            const bool few = (uint32_t)__popcll(__ballot(cand_t <= min(first + chunk_recs - 1u, hi - 1))) < 64u;
+        constexpr int kSteps = 16;
+        uint32_t key[kSteps], slot0[kSteps], nv[kSteps];
 #pragma unroll
-            for (int t = 0; t < kSteps; ++t) {
-                const uint32_t x0 = min(first + t * 64u, hi - 1);
-                const uint32_t x = min(first + t * 64u + lane, hi - 1);
-                if (few) {
-                    const uint32_t nb = (uint32_t)__popcll(__ballot(cand_t <= x0));
-                    const uint32_t tot = (uint32_t)__popcll(__ballot(cand_t <= x0 + 63u));
-                    uint32_t ts = nb ? (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)(nb - 1u)) : t0;
-                    uint32_t ls = nb ? (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)(nb - 1u)) : l0;
-                    uint32_t sl = scur + nb;
-                    for (uint32_t u = nb; u < tot; ++u) {  // uniform: the borders inside the step's positions
-                        const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)cand_t, (int)u);
-                        const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)cand_l, (int)u);
-                        const bool in = x >= bt;
-                        ts = in ? bt : ts;
-                        ls = in ? bl : ls;
-                        sl += in ? 1u : 0u;
-                    }
-                    sl = min(sl, n_rel - 1u);
-                    slot[t] = (p_lo + sl) * kPmStride + ls + (x - ts);
-                } else {
-                    slot[t] = pm_slot_of(s_T, s_L, n_rel, p_lo, scur, x0, x, lane);
-                }
-                key[t] = keys16[slot[t]];
-            }
+        for (int t = 0; t < kSteps; ++t) {
+            const uint32_t ws = 16u * c + (uint32_t)t;
+            const PmSlot at = pm_unpack(ws < n_ws ? desc[g0 + ws] : 0u, ws < n_ws);
+            slot0[t] = at.slot0;
+            nv[t] = at.nv;
+            key[t] = keys16[at.slot0 + lane];
         }
 #pragma unroll
         for (int t = kSteps - 1; t >= 0; --t) {
-            const uint32_t j = first + t * 64u + lane;
-            const bool member = j < last && key[t] == p;
+            const bool member = lane < nv[t] && key[t] == p;
             const uint64_t m = __ballot(member);
             if (m == 0) continue;
             const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
             if (member && above >= skip) {
-                const uint32_t v = (kPmStride == (uint32_t)kPmPass ? (slot[t] & ~(uint32_t)(kPmPass - 1)) : (slot[t] / kPmStride) * (uint32_t)kPmPass) + idx16[slot[t]];
+                const uint32_t pass = (slot0[t] >> 6) / s64;
+                const uint32_t v = pass * (uint32_t)kPmPass + idx16[slot0[t] + lane];
                 atomicOr(&mask[v >> 6], 1ull << (v & 63u));
             }
             const uint32_t in_step = (uint32_t)__popcll(m);
@@ -689,56 +785,75 @@ __global__ __launch_bounds__(1024) void k_pm_rank_mark(const uint16_t* __restric
             skip = skip > in_step ? skip - in_step : 0u;
         }
     }
+    if (lane == 0 && kept) atomicAdd(&s_kept, kept);
     __syncthreads();
-    if (tid == 0) s_namb = 0;
-    __syncthreads();
-    if (lane == 0 && kept) atomicAdd(&s_namb, kept);
-    __syncthreads();
-    if (tid == 0 && s_namb) atomicAdd(kept_total, (unsigned long long)s_namb);
+    if (threadIdx.x == 0 && s_kept) atomicAdd(kept_total, (unsigned long long)s_kept);
 }
 
 // ---- launchers
 uint32_t pm_pitch(uint32_t n) { return part_pass_pitch(n); }  // passes of the call, rounded up to a multiple of 4
-uint32_t pm_max_row() { return kPmMaxRow; }
 uint32_t pm_pass() { return (uint32_t)kPmPass; }
+uint32_t pm_stride(uint32_t ltot, uint32_t shift) { return pm_stride_of((ltot >> shift) + 1u); }
+size_t pm_slots(uint32_t n, uint32_t ltot, uint32_t shift) { return (size_t)pm_pitch(n) * pm_stride(ltot, shift); }  // slots of keys16 / idx16
+uint32_t pm_work_words() { return kPmWorkWords; }
 uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave + kNuOverflow; }  // the exception list's slots: 128 per wave and pass, and the overflow region
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
-                            const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift,
-                            uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
-                            uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg, uint32_t* exc,
+                            const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
+                            uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab, uint32_t* used64,
+                            uint32_t* work, uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg, uint32_t* exc,
                             uint32_t exc_cap, uint32_t* exc_cnt) {
     const uint32_t pitch = pm_pitch(n);
     if (pitch == 0) return;
     (void)hipFuncSetAttribute((const void*)k_pm_prepare_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPmSortLds);
     hipLaunchKernelGGL(k_pm_prepare_sort, dim3(pitch / kPmPassesPerWg), dim3(kPmThreads), kPmSortLds, st, starts, ends, n,
-                       d_roff, d_poff, n_contigs, shift, keys16, idx16, cnt_tab, lst_tab, pitch, stats, zero_mask,
-                       exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
+                       d_roff, d_poff, n_contigs, shift, pm_stride(ltot, shift), keys16, idx16, cnt_tab, lst_tab, pitch,
+                       used64, work, stats, zero_mask, exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
     if (exc != nullptr && ell_reg != 0u)
         hipLaunchKernelGGL(k_nu_count_groups, dim3(32), dim3(256), 0, st, exc_cnt, pitch * kPmWaves, stats);
 }
-void launch_pm_range_table(hipStream_t st, const uint32_t* T, uint32_t n, uint32_t* range_start, uint32_t* max_load) {
-    hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, T, pm_pitch(n), n, range_start, max_load);
+void launch_pm_descr(hipStream_t st, const uint32_t* Tp, const uint32_t* lstw, uint32_t n, uint32_t ltot, uint32_t shift,
+                     uint32_t* desc, uint32_t* inv, uint32_t* work, uint32_t* range_start, uint32_t* max_load) {
+    const uint32_t pitch = pm_pitch(n), n_ranges = (ltot >> shift) + 1u;
+    const uint32_t s64 = pm_stride(ltot, shift) / 64u;
+    hipLaunchKernelGGL(k_pm_descr, dim3((pitch + 255u) / 256u, 256), dim3(256), 0, st, Tp, lstw, pitch, s64, pitch * s64,
+                       desc, inv, work, range_start, max_load);
+    (void)n_ranges;
 }
-void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* T, const uint32_t* lst_tab, uint32_t n,
-                       const uint32_t* rows, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
+void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
+                       const uint32_t* range_start, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
     const uint32_t n_ranges = (ltot >> shift) + 1;  // covers positions 0..ltot
     const size_t width = (size_t)1 << shift;
-    const size_t lds = (width + width / 32 + 1 + 2 * (size_t)kPmMaxRow + 1) * sizeof(uint32_t);
+    const size_t lds = (width + width / 32 + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_offsets, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, T, lst_tab, pm_pitch(n), rows, shift, ltot,
-                       boff, empty_positions);
+    hipLaunchKernelGGL(k_pm_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, desc, Tp, pm_pitch(n), range_start, shift,
+                       ltot, boff, empty_positions);
 }
-void launch_pm_rank_mark(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* T,
-                         const uint32_t* lst_tab, uint32_t n, const uint32_t* rows, uint32_t shift, uint32_t ltot,
-                         const uint32_t* boff, const uint32_t* selend,
-                         unsigned long long* mask, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                         uint32_t* chunk_cursor, const uint32_t* ev_sev, const uint32_t* ev_lastns,
-                         const uint64_t* d_poff, uint32_t n_contigs, uint32_t ell) {
+// The ranking: walk, tile pass, settling -- three launches, in this order.
+void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
+                    const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
+                    uint32_t* kept_list, void* kpw, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
+                    uint32_t* amb_count, const uint32_t* ev_sev, const uint32_t* ev_lastns, const uint64_t* d_poff,
+                    uint32_t n_contigs, uint32_t ell) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const EvQuota evq{ev_sev, ev_lastns, d_poff, n_contigs, ell};
-    const size_t lds = (((size_t)1 << shift) + 1 + 2 * (size_t)kPmMaxRow + 1) * sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void*)k_pm_rank_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_rank_mark, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, T, lst_tab, pm_pitch(n), rows,
-                       shift, ltot, n, boff, selend, mask, kept_total, (uint2*)scratch,
-                       scratch_by_records ? 1 : 0, chunk_cursor, evq);
+    const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void*)k_pm_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_pm_walk, dim3(n_ranges), dim3(1024), lds, st, keys16, desc, Tp, pm_pitch(n), range_start, shift, ltot,
+                       boff, selend, evq, kept_list, (uint2*)kpw, (uint2*)scratch, scratch_by_records ? 1 : 0, amb_count,
+                       kept_total);
+}
+void launch_pm_tiles(hipStream_t st, const uint16_t* idx16, const uint32_t* inv, const uint32_t* used64, uint32_t n,
+                     uint32_t shift, uint32_t ltot, const uint32_t* kept_list, const void* kpw, unsigned long long* mask) {
+    const uint32_t s64 = pm_stride(ltot, shift) / 64u;
+    hipLaunchKernelGGL(k_pm_tiles, dim3((n + (uint32_t)kPmPass - 1u) / (uint32_t)kPmPass), dim3(256), 0, st, used64, inv,
+                       (const uint2*)kpw, kept_list, idx16, s64, n, mask);
+}
+void launch_pm_settle(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,
+                      uint32_t n, const uint32_t* range_start, uint32_t shift, uint32_t ltot, const void* scratch,
+                      bool scratch_by_records, const uint32_t* amb_count, unsigned long long* mask,
+                      unsigned long long* kept_total) {
+    const uint32_t n_ranges = (ltot >> shift) + 1;
+    const uint32_t s64 = pm_stride(ltot, shift) / 64u;
+    hipLaunchKernelGGL(k_pm_settle, dim3(n_ranges, kPmSettleY), dim3(256), 0, st, keys16, idx16, desc, Tp, pm_pitch(n),
+                       range_start, shift, s64, (const uint2*)scratch, scratch_by_records ? 1 : 0, amb_count, mask, kept_total);
 }

@@ -93,9 +93,10 @@ struct qmcp_hip_ctx {
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
-    DevBuf pm_ccur;    // pass-major form: wave 0's slice cursor at every 1024-record chunk of every range
-    DevBuf pm_rows;    // ... and every range's row of passes [p_lo, p_hi) (2 x 256 words), from the host
-    uint32_t* h_pm_rows = nullptr;  // pinned staging of the same
+    // pass-major form (kernels/pass_major.inc.hip): one descriptor word per wave-slot and the inverse map, where every
+    // wave-slot's kept records were listed, slot groups used per pass, k_pm_descr's working words + the ranges' counts of
+    // quota-crossing groups
+    DevBuf pm_desc, pm_inv, pm_kpw, pm_used, pm_work;
     // near-uniform route (kernels/near_uniform.inc.hip): the dominant span of the last call that took it -- the next
     // call's head filters on it at once -- and the route's buffers
     uint32_t nu_ell = 0;
@@ -586,34 +587,29 @@ int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_c
 }
 
 int queue_rm_head(qmcp_hip_ctx* c, hipStream_t s1, uint32_t filter, bool clear_mask);
+int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter);
 
-// The pass-major form of the range-ranked route keeps, per range, the row of the passes that can hold its records
-// in LDS: those of the contigs whose positions overlap the range (kernels/pass_major.inc.hip: pm_relevant_passes,
-// restated here on the host's tables).  True if no row is longer than the kernels' share of LDS.
-bool pm_rows_fit(const uint64_t* roff, const Problem& pr, uint32_t shift, uint32_t* rows /* [2][256] out: p_lo, p_hi */) {
-    if (const char* e = std::getenv("QMCP_HIP_PM"))
-        if (e[0] == '0') return false;  // (A/B: the range-major form)
-    const uint32_t ltot = (uint32_t)pr.ltot, n_contigs = pr.n_contigs;
-    auto contig_at = [&](uint32_t pos) {
-        uint32_t lo = 0, hi = n_contigs;  // last c with poff[c] <= pos
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)pr.poff[mid] <= pos) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-    const uint32_t pass = qmcp::pm_pass();
-    for (uint32_t d = 0; d <= (ltot >> shift); ++d) {
-        const uint32_t pos0 = d << shift;
-        const uint32_t pos1 = std::min(pos0 + (1u << shift), ltot + 1u) - 1u;
-        const uint64_t p_lo = roff[contig_at(pos0)] / pass;
-        const uint64_t p_hi = (roff[contig_at(pos1) + 1] + pass - 1) / pass;
-        if (p_hi - p_lo > qmcp::pm_max_row()) return false;
-        rows[d] = (uint32_t)p_lo;
-        rows[256 + d] = (uint32_t)p_hi;
+// The pass-major form of the range-ranked route (kernels/pass_major.inc.hip) pads every (range, pass) slice to whole
+// groups of 64 slots: it pays where slices are long -- a pass's 8 192 reads over the ranges its contig spans --, and
+// where they would be short (narrow ranges: small genomes) the padding is most of a group and the range-major form is
+// kept.  Hard limits: one partition level, slots addressable with 32-bit byte offsets.
+bool pm_route_ok(const uint64_t* roff, const Problem& pr, uint32_t shift) {
+    const char* e = std::getenv("QMCP_HIP_PM");
+    if (e && e[0] == '0') return false;  // (A/B: the range-major form)
+    const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot;
+    if ((uint64_t)qmcp::pm_slots(n, ltot, shift) >= (1ull << 31)) return false;
+    if (e && e[0] == '1') return true;   // (tests: the form on small inputs)
+    // expected wave-slots against the records' own 1 / 64: a contig's pass deals its reads to the ranges the contig spans
+    double slots = 0.0;
+    for (uint32_t k = 0; k < pr.n_contigs; ++k) {
+        const uint64_t reads = roff[k + 1] - roff[k];
+        if (reads == 0 || pr.poff[k + 1] == pr.poff[k]) continue;
+        const double ranges = (double)(((pr.poff[k + 1] - 1) >> shift) - (pr.poff[k] >> shift) + 1);
+        const double passes = (double)reads / (double)qmcp::pm_pass() < 1.0 ? 1.0 : (double)reads / (double)qmcp::pm_pass();
+        const double slice = (double)reads / (passes * ranges);
+        slots += passes * ranges * std::ceil(slice / 64.0);
     }
-    for (uint32_t d = (ltot >> shift) + 1; d < 256; ++d) rows[d] = rows[256 + d] = 0;
-    return true;
+    return slots <= 1.3 * ((double)n / 64.0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -657,15 +653,24 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         const uint32_t spine_b = qmcp::scan_spine_entries(ltot + 1) + 1;
         TRY(ensure(c, c->spine, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist, (size_t)256 * tiles_seg * sizeof(uint32_t)));
-        TRY(ensure(c, c->keys[0], (size_t)n * sizeof(uint64_t)));
-        TRY(ensure(c, c->keys[1], (size_t)n * sizeof(uint64_t)));
+        // (the pass-major form's two 16-bit record streams live in keys[0] and keys[1]: padded slices, ~6 B per read)
+        const bool may_pm = n >= rank_min_reads() && qmcp::range_path_supported(ltot) && !qmcp::range_path_two_level(ltot) &&
+                            pm_route_ok(roff, pr, qmcp::range_shift_for(ltot));
+        const size_t pm_bytes = may_pm ? qmcp::pm_slots(n, ltot, qmcp::range_shift_for(ltot)) * sizeof(uint16_t) : 0;
+        TRY(ensure(c, c->keys[0], std::max((size_t)n * sizeof(uint64_t), pm_bytes)));
+        TRY(ensure(c, c->keys[1], std::max((size_t)n * sizeof(uint64_t), pm_bytes)));
+        if (may_pm) {
+            const size_t groups = pm_bytes / (64 * sizeof(uint16_t));
+            TRY(ensure(c, c->pm_desc, groups * sizeof(uint32_t)));
+            TRY(ensure(c, c->pm_inv, groups * sizeof(uint32_t)));
+            TRY(ensure(c, c->pm_kpw, groups * 2 * sizeof(uint32_t)));
+            TRY(ensure(c, c->pm_used, (size_t)qmcp::pm_pitch(n) * sizeof(uint32_t)));
+            TRY(ensure(c, c->pm_work, 1024 * sizeof(uint32_t)));
+        }
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->vals[1], (size_t)n * sizeof(uint32_t)));
         TRY(ensure(c, c->spine2, (size_t)(spine_a > spine_b ? spine_a : spine_b) * sizeof(uint32_t) + 16));
         TRY(ensure(c, c->hist2, ((size_t)256 * qmcp::part_pass_pitch(n) + 4) * sizeof(uint32_t)));  // (+ the scan's total)
-        TRY(ensure(c, c->pm_ccur, ((size_t)n / 1024 + 260) * sizeof(uint32_t)));
-        TRY(ensure(c, c->pm_rows, 512 * sizeof(uint32_t)));
-        if (!c->h_pm_rows) HIP_TRY(hipHostMalloc((void**)&c->h_pm_rows, 512 * sizeof(uint32_t), hipHostMallocDefault));
         TRY(ensure(c, c->cstart, ((size_t)ltot + 8) * sizeof(uint32_t)));  // also the event sweep's changed-block S
         TRY(ensure(c, c->boff, ((size_t)ltot + 1) * sizeof(uint32_t)));
         TRY(ensure(c, c->selend, ((size_t)ltot + 8) * sizeof(uint32_t)));  // + spare words for idle lanes
@@ -725,38 +730,15 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         hipStream_t s1 = c->stream;
         static const uint32_t init[8] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(c->stats.p, init, sizeof(init), hipMemcpyHostToDevice, s1));
-        run.pm = !two_level && pm_rows_fit(roff, pr, range_shift, c->h_pm_rows);
+        run.pm = !two_level && pm_route_ok(roff, pr, range_shift);
         run.nu_filter = c->nu_ell;
         hs[5] = hs[6] = 0;
         if (run.pm) {
-            HIP_TRY(hipMemcpyAsync(c->pm_rows.p, c->h_pm_rows, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s1));
             // One pass over the reads: validate, statistics, mask clear, and every pass of 8 192 reads sorted by range
-            // in place (4 B per read out, two [range][pass] tables); a scan of the count table gives the flat
-            // coordinates the per-range kernels walk.  No range-major copy, no second read of the starts.
-            {
-                KernelSpan sp(c, "k_pm_prepare_sort");
-                qmcp::launch_pm_prepare_sort(s1, d_starts, d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
-                                             n_contigs, range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
-                                             (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->stats.p,
-                                             (unsigned long long*)d_mask,
-                                             run.nu_filter, run.nu_filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
-                                             run.nu_filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev[EV_PREP], s1));
-            {
-                KernelSpan sp(c, "scan_radix_hist(3 kernels)");
-                qmcp::launch_exclusive_scan(s1, (const uint32_t*)c->hist2.p, 256u * qmcp::pm_pitch(n),
-                                            (uint32_t*)c->hist2.p, (uint32_t*)c->spine2.p, true);
-                qmcp::launch_pm_range_table(s1, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
-            }
-            HIP_TRY(hipEventRecord(c->ev_fork, s1));  // statistics and heaviest load are final here
-            {
-                KernelSpan sp(c, "k_pm_offsets");
-                qmcp::launch_pm_offsets(s1, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p,
-                                        n, (const uint32_t*)c->pm_rows.p, range_shift, ltot,
-                                        (uint32_t*)c->boff.p, (uint32_t*)c->stats.p + 3);
-            }
+            // (4 B per read out, two [range][pass] tables); a scan of the padded count table gives the padded flat
+            // coordinates, one more small kernel the wave-slot descriptors the per-range kernels follow.  No range-major
+            // copy, no second read of the starts.
+            TRY(queue_pm_head(c, s1, run.nu_filter));
         } else {
             // the range-major form: k_prepare, scan, partition (one or two levels), bucket offsets
             TRY(queue_rm_head(c, s1, run.nu_filter, true));
@@ -792,6 +774,10 @@ int queue_rm_head(qmcp_hip_ctx* c, hipStream_t s1, uint32_t filter, bool clear_m
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 65540;
     uint32_t* d_seg_tables = d_range_start + 65544;  // super_start, tile_base, pass_base (257 each)
+    // (a re-run of the head -- after a span change, or with the filter switched on -- must not add to what the first
+    //  run counted: empty positions, exceptions, list flag, overflow entries)
+    static const uint32_t zeros[4] = {0u, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync((uint32_t*)c->stats.p + 3, zeros, sizeof(zeros), hipMemcpyHostToDevice, s1));
     uint32_t* exc = filter ? (uint32_t*)c->nu_exc.p : nullptr;
     const uint32_t cap = nu_cap_for(n);
     uint32_t* exc_cnt = filter ? qmcp::nu_exc_counts(exc, cap) : nullptr;
@@ -857,28 +843,64 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
     uint32_t* d_range_start = (uint32_t*)c->ranges.p;
     uint32_t* d_max_load = d_range_start + 65540;
     {
-        KernelSpan sp(c, "k_pm_prepare_sort");
+        KernelSpan sp(c, "k_pm_prepare_sort", st);
         qmcp::launch_pm_prepare_sort(st, run.d_starts, run.d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
-                                     n_contigs, run.range_shift, (uint16_t*)c->keys[0].p, (uint16_t*)c->vals[0].p,
-                                     (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, d_stats,
-                                     (unsigned long long*)run.d_mask, filter,
+                                     n_contigs, run.range_shift, ltot, (uint16_t*)c->keys[0].p, (uint16_t*)c->keys[1].p,
+                                     (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->pm_used.p,
+                                     (uint32_t*)c->pm_work.p, d_stats, (unsigned long long*)run.d_mask, filter,
                                      filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
                                      filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
     }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[EV_PREP], st));
     {
-        KernelSpan sp(c, "scan_radix_hist(3 kernels)");
+        KernelSpan sp(c, "scan_radix_hist(3 kernels)", st);
         qmcp::launch_exclusive_scan(st, (const uint32_t*)c->hist2.p, 256u * qmcp::pm_pitch(n), (uint32_t*)c->hist2.p,
                                     (uint32_t*)c->spine2.p, true);
-        qmcp::launch_pm_range_table(st, (const uint32_t*)c->hist2.p, n, d_range_start, d_max_load);
     }
     {
-        KernelSpan sp(c, "k_pm_offsets");
-        qmcp::launch_pm_offsets(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n,
-                                (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, (uint32_t*)c->boff.p, d_stats + 3);
+        KernelSpan sp(c, "k_pm_descr", st);
+        qmcp::launch_pm_descr(st, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, ltot, run.range_shift,
+                              (uint32_t*)c->pm_desc.p, (uint32_t*)c->pm_inv.p, (uint32_t*)c->pm_work.p, d_range_start, d_max_load);
+    }
+    HIP_TRY(hipEventRecord(c->ev_fork, st));  // statistics and heaviest load are final here
+    {
+        KernelSpan sp(c, "k_pm_offsets", st);
+        qmcp::launch_pm_offsets(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->pm_desc.p, (const uint32_t*)c->hist2.p, n,
+                                d_range_start, run.range_shift, ltot, (uint32_t*)c->boff.p, d_stats + 3);
     }
     HIP_TRY(hipGetLastError());
     run.nu_filter = filter;
     return QMCP_OK;
+}
+
+// The ranking of the pass-major form on `st`: the ordered walk, the tile pass, the settling of quota-crossing groups.
+void queue_pm_rank(qmcp_hip_ctx* c, hipStream_t st, const uint32_t* ev_sev, const uint32_t* ev_lastns, uint32_t ell) {
+    SolveRun& run = c->run;
+    const uint32_t n = (uint32_t)run.pr.n, ltot = (uint32_t)run.pr.ltot;
+    const bool by_records = qmcp::rank_scratch_by_records(run.range_shift, ltot, n);
+    const uint16_t* keys16 = (const uint16_t*)c->keys[0].p;
+    const uint16_t* idx16 = (const uint16_t*)c->keys[1].p;
+    const uint32_t* desc = (const uint32_t*)c->pm_desc.p;
+    const uint32_t* Tp = (const uint32_t*)c->hist2.p;
+    const uint32_t* range_start = (const uint32_t*)c->ranges.p;
+    uint32_t* kept_list = (uint32_t*)c->vals[1].p;
+    uint32_t* amb_count = (uint32_t*)c->pm_work.p + 512;
+    unsigned long long* kept_total = (unsigned long long*)c->scalars.p;
+    {
+        KernelSpan sp(c, "k_pm_walk", st);
+        qmcp::launch_pm_walk(st, keys16, desc, Tp, n, range_start, run.range_shift, ltot, (const uint32_t*)c->boff.p,
+                             (const uint32_t*)c->selend.p, kept_list, c->pm_kpw.p, kept_total, c->rankamb.p, by_records,
+                             amb_count, ev_sev, ev_lastns, (const uint64_t*)c->poff.p, run.n_contigs, ell);
+    }
+    {
+        KernelSpan sp(c, "k_pm_tiles", st);
+        qmcp::launch_pm_tiles(st, idx16, (const uint32_t*)c->pm_inv.p, (const uint32_t*)c->pm_used.p, n, run.range_shift, ltot,
+                              kept_list, c->pm_kpw.p, (unsigned long long*)run.d_mask);
+    }
+    KernelSpan sp(c, "k_pm_settle", st);
+    qmcp::launch_pm_settle(st, keys16, idx16, desc, Tp, n, range_start, run.range_shift, ltot, c->rankamb.p, by_records,
+                           amb_count, (unsigned long long*)run.d_mask, kept_total);
 }
 
 // The near-uniform route's half of the tail (kernels/near_uniform.inc.hip).  Called when the call's spans differ.
@@ -1022,11 +1044,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     if (!settled) return QMCP_OK;
     HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], st));
     if (run.pm) {
-        KernelSpan sp(c, "k_pm_rank_mark");
-        qmcp::launch_pm_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p, (const uint32_t*)c->hist2.p,
-                                  (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p, run.range_shift, ltot, boff, selend,
-                                  (unsigned long long*)run.d_mask, (unsigned long long*)c->scalars.p, c->rankamb.p,
-                                  qmcp::rank_scratch_by_records(run.range_shift, ltot, n), (uint32_t*)c->pm_ccur.p);
+        queue_pm_rank(c, st, nullptr, nullptr, 0);
     } else {
         KernelSpan sp(c, "k_rank_mark");
         qmcp::launch_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->ranges.p,
@@ -1167,15 +1185,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
         HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], s1));
         sweep_done = true;
         if (ranked && run.pm) {
-            KernelSpan sp(c, "k_pm_rank_mark");
-            qmcp::launch_pm_rank_mark(s1, (const uint16_t*)c->keys[0].p, (const uint16_t*)c->vals[0].p,
-                                      (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, (const uint32_t*)c->pm_rows.p,
-                                      range_shift, ltot, (const uint32_t*)c->boff.p,
-                                      (const uint32_t*)c->selend.p, (unsigned long long*)d_mask,
-                                      (unsigned long long*)c->scalars.p, c->rankamb.p,
-                                      qmcp::rank_scratch_by_records(range_shift, ltot, n), (uint32_t*)c->pm_ccur.p,
-                                      expand_left_out ? (const uint32_t*)c->cstart.p : nullptr, (const uint32_t*)c->evlast.p,
-                                      (const uint64_t*)c->poff.p, n_contigs, max_span);
+            queue_pm_rank(c, s1, expand_left_out ? (const uint32_t*)c->cstart.p : nullptr, (const uint32_t*)c->evlast.p, max_span);
             HIP_TRY(hipGetLastError());
         } else if (ranked) {
             KernelSpan sp(c, "k_rank_mark");
@@ -1657,7 +1667,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_ccur, &c->pm_rows, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_desc, &c->pm_inv, &c->pm_kpw, &c->pm_used, &c->pm_work, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -1676,7 +1686,6 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     if (c->ev_head) (void)hipEventDestroy(c->ev_head);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->h_head) (void)hipHostFree(c->h_head);
-    if (c->h_pm_rows) (void)hipHostFree(c->h_pm_rows);
     if (c->h_nu) (void)hipHostFree(c->h_nu);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);

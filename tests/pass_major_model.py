@@ -1,21 +1,31 @@
-"""Host-side model of the PASS-MAJOR layout of the range-ranked route (csrc/kernels/pass_major.inc.hip) -- every
-index its producer writes and its two consumers read, with bounds asserted -- so that the layout's arithmetic is
-checked on the CPU before (and beside) any GPU run.  Written after round 2's abandoned 16-bit-index experiment
-ended in a GPU memory-access fault whose code was not kept: this round the indexing was modelled first.
+"""Host-side model of the PASS-MAJOR layout of the range-ranked route (csrc/kernels/pass_major.inc.hip), round 4 form
+-- every index its producer writes and its consumers read, with bounds asserted -- so that the layout's arithmetic is
+checked on the CPU before (and beside) any GPU run.  (Round 2's abandoned 16-bit-index experiment ended in a GPU
+memory-access fault whose code was not kept; since then a layout is modelled first.)
 
-Layout.  The reads of a call are cut into PASSES of 8 192 consecutive reads.  k_pm_prepare_sort sorts every pass
-by position range (digit = clamped global start >> shift, <= 256 ranges), stably, IN PLACE: slot P * 8192 + j of
-the two 16-bit streams holds, for the pass's j-th record in (range, read index) order,
-    keys16 = global start & (2^shift - 1)        idx16 = read index - P * 8192        (both < 2^15 resp. 2^13)
-and two tables laid out [range][pass] (row pitch a multiple of 4) hold, per (range d, pass P),
-    cnt[d][P] = records of range d in pass P       lst[d][P] = where they begin inside the pass.
-An exclusive scan over the flattened cnt table gives T[d][P] = number of records of lower ranges + of range d in
-lower passes: the position the slice WOULD have in a range-major array, which is never materialised.  Range d's
-records in read-index order are the concatenation of its slices in pass order; flat position x in [T[d][0],
-T[d+1][0]) lies in the last pass P with T[d][P] <= x, at slot P * 8192 + lst[d][P] + (x - T[d][P])."""
+Layout.  The reads of a call are cut into PASSES of 8 192 consecutive reads.  k_pm_prepare_sort sorts every pass by
+position range (digit = clamped global start >> shift, <= 256 ranges), stably, and writes the pass's records of range
+d -- its SLICE (d, P) -- at a slot that is a multiple of 64: pass P owns the slots [P * stride, (P + 1) * stride),
+stride = 8192 + 64 * n_ranges, and the slices follow each other padded to whole groups of 64 slots.  Two 16-bit
+streams: keys16[slot] = global start & (2^shift - 1), idx16[slot] = read index - P * 8192.  Two tables laid out
+[range][pass] (row pitch a multiple of 4):
+    cntp[d][P] = records of the slice rounded up to a multiple of 64      lstw[d][P] = (first slot - P * stride) / 64
+                                                                                       | true record count << 16
+An exclusive scan over the flattened cntp table gives Tp[d][P]: the PADDED FLAT position of the slice -- range d's
+records in read-index order are its slices in pass order, each padded to whole groups.  A group of 64 padded flat
+positions (a WAVE-SLOT, g = position / 64) therefore lies in exactly one slice, and a one-word descriptor per
+wave-slot says where: desc[g] = (first slot / 64) << 6 | (records in the group - 1).  The consumers never search:
+    k_pm_offsets  walks a range's wave-slots in any order (LDS histogram of the positions);
+    k_pm_walk     walks them in order, sixteen (one chunk) per step, against the per-position quotas; kept records go
+                  to the range's kept list L (their slots), and every wave-slot records where its entries went;
+    k_pm_tiles    builds every pass's 128 mask words from the lists (inv[] maps a pass's slot groups back to
+                  wave-slots), every word written once;
+    k_pm_settle   decides the (chunk, position) groups whose quota ran out inside a chunk.
+"""
 import numpy as np
 
 PASS = 8192
+CHUNK_WS = 16          # wave-slots per chunk (one per wave of the walking workgroup)
 
 
 def pitch_for(n):
@@ -23,95 +33,187 @@ def pitch_for(n):
     return (n_pass + 3) & ~3
 
 
-def producer(gstart, shift):
-    """-> keys16, idx16 (length n), cnt, lst ([256][pitch] uint32)"""
+def stride_for(n_ranges):
+    return PASS + 64 * n_ranges
+
+
+def producer(gstart, shift, n_ranges):
+    """-> keys16, idx16 (pitch * stride slots, 0xFFFF where nothing was written), cntp, lstw ([256][pitch] uint32)"""
     n = gstart.size
     pitch = pitch_for(n)
-    keys16 = np.zeros(n, np.uint16)
-    idx16 = np.zeros(n, np.uint16)
-    cnt = np.zeros((256, pitch), np.uint32)
-    lst = np.zeros((256, pitch), np.uint32)
+    stride = stride_for(n_ranges)
+    keys16 = np.full(pitch * stride, 0xFFFF, np.uint16)
+    idx16 = np.full(pitch * stride, 0xFFFF, np.uint16)
+    cntp = np.zeros((256, pitch), np.uint32)
+    lstw = np.zeros((256, pitch), np.uint32)
     for P in range((n + PASS - 1) // PASS):
         lo, hi = P * PASS, min(n, (P + 1) * PASS)
         d = (gstart[lo:hi] >> shift).astype(np.int64)
-        assert d.max() < 256
+        assert d.max() < n_ranges <= 256
         order = np.argsort(d, kind="stable")
-        keys16[lo:hi] = (gstart[lo:hi][order] & ((1 << shift) - 1)).astype(np.uint16)
-        idx16[lo:hi] = order.astype(np.uint16)
-        c = np.bincount(d, minlength=256).astype(np.uint32)
-        cnt[:, P] = c
-        lst[:, P] = np.concatenate([[0], np.cumsum(c)[:-1]]).astype(np.uint32)
-    return keys16, idx16, cnt, lst
+        c = np.bincount(d, minlength=256).astype(np.int64)
+        pad = (c + 63) // 64 * 64
+        first = np.concatenate([[0], np.cumsum(pad)[:-1]])
+        assert first[-1] + pad[-1] <= stride
+        compact = np.concatenate([[0], np.cumsum(c)[:-1]])
+        for dd in np.nonzero(c)[0]:
+            src = order[compact[dd]:compact[dd] + c[dd]]
+            at = P * stride + first[dd]
+            keys16[at:at + c[dd]] = (gstart[lo:hi][src] & ((1 << shift) - 1)).astype(np.uint16)
+            idx16[at:at + c[dd]] = src.astype(np.uint16)
+        cntp[:, P] = pad.astype(np.uint32)
+        assert (first // 64).max() < (1 << 16) and c.max() < (1 << 16)
+        lstw[:, P] = ((first // 64) | (c << 16)).astype(np.uint32)
+    return keys16, idx16, cntp, lstw
 
 
-def scan_table(cnt):
+def scan_table(cntp):
     """exclusive scan over the flattened [range][pass] table, total appended (launch_exclusive_scan, write_total)"""
-    flat = cnt.reshape(-1).astype(np.uint64)
+    flat = cntp.reshape(-1).astype(np.uint64)
     return np.concatenate([[0], np.cumsum(flat)]).astype(np.uint32)
 
 
-def relevant_passes(d, shift, ltot, roff, poff):
-    """passes that can hold records of range d: those of the contigs whose positions overlap the range"""
-    pos0 = d << shift
-    if pos0 > ltot:
-        return 0, 0
-    pos1 = min(pos0 + (1 << shift), ltot + 1) - 1       # last position of the range (ltot itself included: the
-    c_first = int(np.searchsorted(poff, pos0, side="right") - 1)   # clamp rule puts a zero-length contig's reads there)
-    c_last = int(np.searchsorted(poff, pos1, side="right") - 1)
-    c_first = min(max(c_first, 0), len(roff) - 2)
-    c_last = min(max(c_last, 0), len(roff) - 2)
-    return int(roff[c_first]) // PASS, (int(roff[c_last + 1]) + PASS - 1) // PASS
+def descriptors(Tp, lstw, n, n_ranges):
+    """k_pm_descr: one thread per (range, pass) table entry -> the slice's wave-slot descriptors, the inverse map, and
+    (row sums of the true counts, scanned) the ranges' TRUE flat starts.  -> desc [G], inv [pitch * stride / 64],
+    range_start [257] (true), used64 [pitch] (slot groups every pass uses)"""
+    pitch = pitch_for(n)
+    stride = stride_for(n_ranges)
+    s64 = stride // 64
+    G = int(Tp[-1]) // 64
+    desc = np.full(G, 0xFFFFFFFF, np.uint32)
+    inv = np.full(pitch * s64, 0xFFFFFFFF, np.uint32)
+    true_rows = np.zeros(256, np.int64)
+    used64 = np.zeros(pitch, np.uint32)
+    for d in range(256):
+        for P in range(pitch):
+            w = int(lstw[d, P])
+            cnt, lst64 = w >> 16, w & 0xFFFF
+            if cnt == 0:
+                continue
+            true_rows[d] += cnt
+            t = int(Tp[d * pitch + P])
+            assert t % 64 == 0
+            g = t // 64
+            n_ws = (cnt + 63) // 64
+            used64[P] = max(used64[P], lst64 + n_ws)
+            for j in range(n_ws):
+                group = P * s64 + lst64 + j
+                assert group < (1 << 26) and g + j < G and desc[g + j] == 0xFFFFFFFF and inv[group] == 0xFFFFFFFF
+                desc[g + j] = (group << 6) | (min(64, cnt - 64 * j) - 1)
+                inv[group] = g + j
+    assert not (desc == 0xFFFFFFFF).any()      # every wave-slot of the padded flat space belongs to a slice
+    range_start = np.concatenate([[0], np.cumsum(true_rows)]).astype(np.uint32)
+    assert int(range_start[-1]) <= n
+    return desc, inv, range_start, used64
 
 
-def flat_to_slot(T, lst, pitch, d, x, p_lo, p_hi):
-    """the consumer's mapping, as a binary search over the range's row (the device walks a cursor instead)"""
-    row = T[d * pitch + p_lo:d * pitch + p_hi + 1]
-    k = int(np.searchsorted(row, x, side="right") - 1)       # last pass with T <= x
-    assert 0 <= k < p_hi - p_lo, (d, x, k)
-    P = p_lo + k
-    return P, P * PASS + int(lst[d, P]) + (x - int(row[k]))
+def range_wave_slots(Tp, pitch, d):
+    lo, hi = int(Tp[d * pitch]), int(Tp[(d + 1) * pitch])
+    assert lo % 64 == 0 and hi % 64 == 0
+    return lo // 64, (hi - lo) // 64
 
 
-def wave_cursor_walk(T, lst, pitch, d, lo, hi, p_lo, p_hi, chunk=1024, depth=1):
-    """The device's walk, lane for lane: the workgroup's 16 waves take 64 consecutive flat positions each per chunk;
-    a wave keeps a cursor k0 (last pass whose slice begins at or before its first position), advances it with one
-    row read of 64 candidates per step, counts the slice borders inside its 64 positions, and every lane derives its
-    pass and slot.  Returns the slots in flat order."""
-    row = T[d * pitch + p_lo:d * pitch + p_hi + 1].astype(np.int64)
-    n_rel = p_hi - p_lo
+def offsets(keys16, desc, Tp, pitch, d, shift):
+    """k_pm_offsets: the range's positions, histogrammed (order-free)"""
+    g0, n_ws = range_wave_slots(Tp, pitch, d)
+    hist = np.zeros(1 << shift, np.int64)
+    for ws in range(n_ws):
+        dsc = int(desc[g0 + ws])
+        slot0, nv = (dsc >> 6) * 64, (dsc & 63) + 1
+        k = keys16[slot0:slot0 + nv]
+        assert k.max() < (1 << shift)
+        np.add.at(hist, k.astype(np.int64), 1)
+    return hist
 
-    def cand_of(k0):
-        i = k0 + 1 + np.arange(64)
-        return np.where(i <= n_rel, row[np.minimum(i, n_rel)], np.int64(1) << 40)   # beyond the row: never <= x
 
-    slots = np.zeros(hi - lo, np.int64)
-    passes = np.zeros(hi - lo, np.int64)
-    n_chunks = (hi - lo + chunk - 1) // chunk
-    for w in range(chunk // 64):
-        k0 = 0
-        for c in range(n_chunks):
-            j0 = lo + c * chunk + 64 * w
-            if j0 >= hi:
-                break
-            # advance: passes whose slices begin at or before j0
-            while True:
-                cand = cand_of(k0)
-                n_before = int((cand <= j0).sum())
-                k0 += n_before
-                if n_before < 64:
-                    break
-            cand = cand_of(k0)
-            x = j0 + np.arange(64)
-            n_in = int((cand <= j0 + 63).sum())
-            s = np.full(64, k0, np.int64)
-            for t in range(n_in):
-                s += (x >= cand[t]).astype(np.int64)
-            if n_in == 64:      # more than 64 borders inside 64 positions (empty slices): the slow, exact way
-                s = np.array([np.searchsorted(row[:n_rel + 1], xi, side="right") - 1 for xi in x], np.int64)
-            live = x < hi
-            s = np.minimum(s, n_rel - 1)
-            P = p_lo + s
-            slot = P * PASS + lst[d, P].astype(np.int64) + (x - row[s])
-            slots[(x - lo)[live]] = slot[live]
-            passes[(x - lo)[live]] = P[live]
-    return slots, passes
+def walk(keys16, desc, Tp, pitch, d, quota, range_start, rng):
+    """k_pm_walk for one range.  quota: int array [1 << shift] = S(p).  Chunks of 16 wave-slots in order; inside a chunk
+    the draws happen in an arbitrary order (rng permutation: the device's LDS arbitration).  -> L (dict position ->
+    slot, positions from range_start[d]), kpw (dict g -> (position, count)), amb [(chunk, position key, skip)], kept"""
+    g0, n_ws = range_wave_slots(Tp, pitch, d)
+    q = quota.astype(np.int64).copy()
+    L, kpw, amb = {}, {}, []
+    total = 0
+    kept = 0
+    n_chunks = (n_ws + CHUNK_WS - 1) // CHUNK_WS
+    for c in range(n_chunks):
+        recs = []          # (wave, lane, key, slot)
+        for w in range(CHUNK_WS):
+            ws = c * CHUNK_WS + w
+            if ws >= n_ws:
+                continue
+            dsc = int(desc[g0 + ws])
+            slot0, nv = (dsc >> 6) * 64, (dsc & 63) + 1
+            for lane in range(nv):
+                recs.append((w, lane, int(keys16[slot0 + lane]), slot0 + lane))
+        order = rng.permutation(len(recs))
+        old = [0] * len(recs)
+        for i in order:
+            old[i] = q[recs[i][2]]
+            q[recs[i][2]] -= 1
+        per_wave = {}
+        for i, (w, lane, key, slot) in enumerate(recs):
+            aft = q[key]
+            if old[i] > 0 and aft >= 0:
+                per_wave.setdefault(w, []).append(slot)
+            if old[i] == 1 and aft < 0:
+                amb.append((c, key, int(-aft)))
+        for w in rng.permutation(CHUNK_WS):          # the waves' appends come in any order
+            ws = c * CHUNK_WS + int(w)
+            if ws >= n_ws:
+                continue
+            ent = per_wave.get(int(w), [])
+            pos = int(range_start[d]) + total
+            kpw[g0 + ws] = (pos, len(ent))
+            for k, slot in enumerate(ent):
+                assert pos + k < int(range_start[d + 1])      # the list has room for every record of the range
+                L[pos + k] = slot
+            total += len(ent)
+            kept += len(ent)
+    return L, kpw, amb, kept
+
+
+def tiles(L, kpw, inv, idx16, used64, n, n_ranges):
+    """k_pm_tiles: every pass's mask words from the kept lists"""
+    s64 = stride_for(n_ranges) // 64
+    mask = np.zeros(n, bool)
+    for P in range((n + PASS - 1) // PASS):
+        for t in range(int(used64[P])):
+            g = int(inv[P * s64 + t])
+            assert g != 0xFFFFFFFF
+            pos, cnt = kpw[g]
+            for e in range(cnt):
+                slot = L[pos + e]
+                assert slot // (s64 * 64) == P
+                i = int(idx16[slot])
+                assert i < PASS and P * PASS + i < n and not mask[P * PASS + i]
+                mask[P * PASS + i] = True
+    return mask
+
+
+def settle(amb, keys16, idx16, desc, Tp, pitch, d, n, n_ranges, mask):
+    """k_pm_settle: a listed (chunk, position) group keeps all of the chunk's records at that position but the last
+    `skip` in read-index order"""
+    stride = stride_for(n_ranges)
+    g0, n_ws = range_wave_slots(Tp, pitch, d)
+    kept = 0
+    for (c, key, skip) in amb:
+        members = []
+        for w in range(CHUNK_WS):
+            ws = c * CHUNK_WS + w
+            if ws >= n_ws:
+                continue
+            dsc = int(desc[g0 + ws])
+            slot0, nv = (dsc >> 6) * 64, (dsc & 63) + 1
+            for lane in range(nv):
+                if int(keys16[slot0 + lane]) == key:
+                    members.append(slot0 + lane)
+        assert len(members) > skip
+        for slot in members[:len(members) - skip]:
+            P = slot // stride
+            i = P * PASS + int(idx16[slot])
+            assert i < n and not mask[i]
+            mask[i] = True
+            kept += 1
+    return kept

@@ -1,7 +1,9 @@
-"""CPU model of the pass-major layout (tests/pass_major_model.py): the producer's slots and tables, the scanned
-table, the consumers' flat-position -> slot mapping (by binary search and by the device's per-wave cursor walk):
-every index in bounds, every range's records recovered in read-index order -- on ragged inputs (last pass partial,
-ranges straddling contig borders, empty ranges and empty slices, one range holding everything)."""
+"""CPU model of the pass-major layout (tests/pass_major_model.py, round 4 form: slices padded to whole groups of 64
+slots, one descriptor word per wave-slot, kept lists + tile pass): the producer's slots and tables, the scanned table,
+the descriptors and their inverse, the three consumers -- every index in bounds, every range's records recovered in
+read-index order, and the keep mask of walk + tiles + settle equal to "the S(p) lowest read indices of every start
+position p" for random quotas -- on ragged inputs (last pass partial, ranges straddling contig borders, empty ranges
+and empty slices, one range holding everything, slices of a few records)."""
 import numpy as np
 import pytest
 
@@ -30,61 +32,111 @@ CASES = [
     ([5_000, 5_000, 5_000], [0, 25_000, 0], 6),                         # contigs without reads
     ([300], [20_000], 3),                                               # tiny genome, 38 ranges
     ([40_000], [17_000], 15),                                           # ONE range holds everything
-    ([(1 << 21) - 5], [40_000], 13),                                        # 256 ranges, sparse: many empty slices
+    ([(1 << 21) - 5], [40_000], 13),                                    # 256 ranges, sparse: slices of a few records
 ]
 
 
+def _expected_mask(gs, quota_of):
+    """the quota_of(p) lowest read indices of every global start p"""
+    n = gs.size
+    order = np.argsort(gs, kind="stable")
+    mask = np.zeros(n, bool)
+    sorted_g = gs[order]
+    starts = np.concatenate([[0], np.nonzero(np.diff(sorted_g))[0] + 1, [n]])
+    for a, b in zip(starts[:-1], starts[1:]):
+        k = min(int(quota_of(int(sorted_g[a]))), b - a)
+        mask[order[a:a + k]] = True
+    return mask
+
+
 @pytest.mark.parametrize("lengths,counts,shift", CASES)
-def test_layout_round_trip_and_bounds(lengths, counts, shift):
+def test_layout_round_trip_bounds_and_mask(lengths, counts, shift):
     rng = np.random.default_rng(len(lengths) * 1000 + shift)
     gs, roff, poff, ltot = _case(rng, lengths, counts, shift)
     n = gs.size
-    assert (ltot >> shift) < 256
-    keys16, idx16, cnt, lst = pm.producer(gs, shift)
+    n_ranges = (ltot >> shift) + 1
+    assert n_ranges <= 256
+    keys16, idx16, cntp, lstw = pm.producer(gs, shift, n_ranges)
     pitch = pm.pitch_for(n)
-    T = pm.scan_table(cnt)
-    assert T.size == 256 * pitch + 1 and int(T[-1]) == n
-    assert int(idx16.max()) < pm.PASS and int(keys16.max()) < (1 << shift)
+    stride = pm.stride_for(n_ranges)
+    Tp = pm.scan_table(cntp)
+    assert Tp.size == 256 * pitch + 1 and int(Tp[-1]) % 64 == 0 and int(Tp[-1]) >= n
+    desc, inv, range_start, used64 = pm.descriptors(Tp, lstw, n, n_ranges)
+    assert int(range_start[-1]) == n
+    # the slot-group <-> wave-slot maps are inverse to each other, and a pass's groups are used from 0 on
+    for g, dsc in enumerate(desc):
+        assert int(inv[int(dsc) >> 6]) == g
+    for P in range(pitch):
+        s64 = stride // 64
+        assert not (inv[P * s64:P * s64 + int(used64[P])] == 0xFFFFFFFF).any()
+        assert (inv[P * s64 + int(used64[P]):(P + 1) * s64] == 0xFFFFFFFF).all()
+    # random quotas: 0, 1, a few, everything
+    width = 1 << shift
+    quota = rng.choice([0, 0, 1, 1, 2, 5, 1 << 20], size=ltot + width)
     seen = np.zeros(n, bool)
-    for d in range((ltot >> shift) + 1):
-        lo, hi = int(T[d * pitch]), int(T[(d + 1) * pitch])
-        p_lo, p_hi = pm.relevant_passes(d, shift, ltot, roff, poff)
-        # no record of the range lies in a pass outside [p_lo, p_hi)
-        assert int(cnt[d, :p_lo].sum()) == 0 and int(cnt[d, p_hi:].sum()) == 0
-        if lo == hi:
+    mask = np.zeros(n, bool)
+    kept_total = 0
+    L_all, kpw_all, amb_all = {}, {}, {}
+    for d in range(n_ranges):
+        g0, n_ws = pm.range_wave_slots(Tp, pitch, d)
+        true_count = int(range_start[d + 1]) - int(range_start[d])
+        if n_ws == 0:
+            assert true_count == 0
             continue
-        assert p_hi > p_lo
-        prev = -1
-        for x in range(lo, hi, max(1, (hi - lo) // 257)):     # sampled by binary search ...
-            P, slot = pm.flat_to_slot(T, lst, pitch, d, x, p_lo, p_hi)
-            assert 0 <= slot < n and slot // pm.PASS == P
-            read = P * pm.PASS + int(idx16[slot])
-            assert read < n and (int(gs[read]) >> shift) == d and int(keys16[slot]) == int(gs[read]) & ((1 << shift) - 1)
-        slots, passes = pm.wave_cursor_walk(T, lst, pitch, d, lo, hi, p_lo, p_hi)   # ... and all of it by the cursor walk
-        assert slots.min() >= 0 and slots.max() < n and np.array_equal(slots // pm.PASS, passes)
-        reads = passes * pm.PASS + idx16[slots].astype(np.int64)
-        assert reads.max() < n and np.all(np.diff(reads) > 0)            # read-index order, no repeats
+        # every record of the range, in read-index order, through the descriptors
+        reads = []
+        for ws in range(n_ws):
+            dsc = int(desc[g0 + ws])
+            slot0, nv = (dsc >> 6) * 64, (dsc & 63) + 1
+            assert slot0 + nv <= pitch * stride
+            P = slot0 // stride
+            r = P * pm.PASS + idx16[slot0:slot0 + nv].astype(np.int64)
+            assert idx16[slot0:slot0 + nv].max() < pm.PASS
+            reads.append(r)
+        reads = np.concatenate(reads)
+        assert reads.size == true_count and reads.max() < n and np.all(np.diff(reads) > 0)
         assert np.all((gs[reads] >> shift) == d)
-        assert np.array_equal(keys16[slots], (gs[reads] & ((1 << shift) - 1)).astype(np.uint16))
         assert not seen[reads].any()
         seen[reads] = True
-    assert seen.all()        # every read is some range's record exactly once
+        # bucket counts
+        hist = pm.offsets(keys16, desc, Tp, pitch, d, shift)
+        assert np.array_equal(hist, np.bincount((gs[reads] & (width - 1)).astype(np.int64), minlength=width))
+        # walk + settle (the tile pass below sees every range's list)
+        L, kpw, amb, kept = pm.walk(keys16, desc, Tp, pitch, d, quota[d * width:(d + 1) * width], range_start, rng)
+        kept_total += kept
+        L_all.update(L)
+        kpw_all.update(kpw)
+        amb_all[d] = amb
+    assert seen.all()
+    mask = pm.tiles(L_all, kpw_all, inv, idx16, used64, n, n_ranges)
+    for d, amb in amb_all.items():
+        kept_total += pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, n_ranges, mask)
+    want = _expected_mask(gs, lambda p: quota[p])
+    assert np.array_equal(mask, want) and kept_total == int(want.sum())
 
 
 def test_skewed_passes_with_long_and_empty_slices():
     """reads sorted by position inside the contig: a pass's records fall into one or two ranges (slices of
-    thousands of records, most slices empty)"""
+    thousands of records, most slices empty); quotas that run out inside chunks"""
     rng = np.random.default_rng(2)
     gs, roff, poff, ltot = _case(rng, [200_000], [5 * 8192 + 1], 10,
-                                 skew=lambda r, k, L: np.sort(r.integers(0, L, size=k)))
-    keys16, idx16, cnt, lst = pm.producer(gs, 10)
-    pitch, n = pm.pitch_for(gs.size), gs.size
-    T = pm.scan_table(cnt)
-    for d in range((ltot >> 10) + 1):
-        lo, hi = int(T[d * pitch]), int(T[(d + 1) * pitch])
-        if lo == hi:
+                                 skew=lambda r, k, L: np.sort(r.integers(0, L // 50, size=k) * 50))
+    n = gs.size
+    n_ranges = (ltot >> 10) + 1
+    keys16, idx16, cntp, lstw = pm.producer(gs, 10, n_ranges)
+    pitch = pm.pitch_for(n)
+    Tp = pm.scan_table(cntp)
+    desc, inv, range_start, used64 = pm.descriptors(Tp, lstw, n, n_ranges)
+    quota = rng.integers(0, 12, size=ltot + 1024)
+    L_all, kpw_all, ambs = {}, {}, {}
+    for d in range(n_ranges):
+        g0, n_ws = pm.range_wave_slots(Tp, pitch, d)
+        if n_ws == 0:
             continue
-        p_lo, p_hi = pm.relevant_passes(d, 10, ltot, roff, poff)
-        slots, passes = pm.wave_cursor_walk(T, lst, pitch, d, lo, hi, p_lo, p_hi)
-        reads = passes * pm.PASS + idx16[slots].astype(np.int64)
-        assert slots.max() < n and np.all(np.diff(reads) > 0) and np.all((gs[reads] >> 10) == d)
+        L, kpw, amb, _ = pm.walk(keys16, desc, Tp, pitch, d, quota[d * 1024:(d + 1) * 1024], range_start, rng)
+        L_all.update(L); kpw_all.update(kpw); ambs[d] = amb
+    assert sum(len(a) for a in ambs.values()) > 0        # the case is meant to produce quota-crossing groups
+    mask = pm.tiles(L_all, kpw_all, inv, idx16, used64, n, n_ranges)
+    for d, amb in ambs.items():
+        pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, n_ranges, mask)
+    assert np.array_equal(mask, _expected_mask(gs, lambda p: quota[p]))
