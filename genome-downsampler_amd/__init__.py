@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB_PATH = os.path.join(LIB_DIR, "libqmcp_hip.so")
+# (QMCP_HIP_LIB: another build of the same library -- lab/variants/<name>/libqmcp_hip.so -- instead of the product's;
+#  lab use only: the host mirror library still links the product's)
+HIP_LIB_PATH = os.environ.get("QMCP_HIP_LIB") or os.path.join(LIB_DIR, "libqmcp_hip.so")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libqmcp_host.so")
 
 # every symbol include/qmcp_hip.h declares

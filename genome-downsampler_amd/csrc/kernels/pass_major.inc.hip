@@ -303,10 +303,12 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
 // k_pm_descr's working words (cleared by k_pm_prepare_sort): [0..255] the rows' true record counts, [256] ticket
 static constexpr uint32_t kPmWorkWords = 260;
 
-// One thread per (range, pass) table entry: the slice's wave-slot descriptors and the inverse map; per range the true
-// record count (one atomic per workgroup and range); the last workgroup to finish scans the 256 counts into the
-// ranges' true flat starts (the bucket offsets' bases, the kept lists' and the ambiguity lists' bases) and the
-// heaviest range's load.
+// One workgroup per range, a thread per (range, pass) table entry in turn: the slice's wave-slot descriptors and the
+// inverse map -- slot group -> where k_pm_walk notes the wave-slot's kept records: kpw[kb + wave * chunks + chunk], kb =
+// the range's first wave-slot + 16 * range, so that the notes of one wave's consecutive chunks are neighbours --; the
+// row's true record count; the last workgroup to finish scans the 256 counts into the ranges' true flat starts (the
+// bucket offsets' bases, the ambiguity lists' bases) and the heaviest range's load.  (A first form had a workgroup per
+// 256 entries, every one ending in an atomic on the same ticket word: 12 288 same-address atomics, 0.49 ms.)
 __global__ __launch_bounds__(256) void k_pm_descr(const uint32_t* __restrict__ Tp, const uint32_t* __restrict__ lstw,
                                                   uint32_t pitch, uint32_t s64 /* stride / 64 */, uint32_t n_groups /* total padded flat / 64 bound */,
                                                   uint32_t* __restrict__ desc, uint32_t* __restrict__ inv,
@@ -314,39 +316,43 @@ __global__ __launch_bounds__(256) void k_pm_descr(const uint32_t* __restrict__ T
                                                   uint32_t* __restrict__ max_load) {
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_last;
-    const uint32_t d = blockIdx.y, P = blockIdx.x * 256u + threadIdx.x;
-    uint32_t cnt = 0;
-    if (P < pitch) {
-        const uint32_t w = lstw[(size_t)d * pitch + P];
-        cnt = w >> 16;
-        if (cnt != 0u) {
+    const uint32_t d = blockIdx.x;
+    const uint32_t lo_p = Tp[(size_t)d * pitch], hi_p = Tp[(size_t)(d + 1) * pitch];
+    const uint32_t g0 = lo_p >> 6, n_chunks = (((hi_p - lo_p) >> 6) + 15u) >> 4;
+    const uint32_t kb = g0 + 16u * d;
+    uint32_t mine = 0;
+    if (hi_p > lo_p)  // (uniform)
+        for (uint32_t P = threadIdx.x; P < pitch; P += 256u) {
+            const uint32_t w = lstw[(size_t)d * pitch + P];
+            const uint32_t cnt = w >> 16;
+            if (cnt == 0u) continue;
+            mine += cnt;
             const uint32_t g = Tp[(size_t)d * pitch + P] >> 6;
             const uint32_t group = P * s64 + (w & 0xFFFFu);
             const uint32_t n_ws = (cnt + 63u) >> 6;
             for (uint32_t j = 0; j < n_ws; ++j) {
                 if (g + j < n_groups) {  // (always: the bound is the buffers' size)
+                    const uint32_t ws = g + j - g0;
                     desc[g + j] = ((group + j) << 6) | (min(64u, cnt - 64u * j) - 1u);
-                    inv[group + j] = g + j;
+                    inv[group + j] = kb + (ws & 15u) * n_chunks + (ws >> 4);
                 }
             }
         }
-    }
-    const uint32_t sum = wave_sum_u32(cnt);
+    const uint32_t sum = wave_sum_u32(mine);
     if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        if (tot != 0u) atomicAdd(&work[d], tot);
+        __hip_atomic_store(&work[d], s_red[0] + s_red[1] + s_red[2] + s_red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         const uint32_t ticket = atomicAdd(&work[256], 1u);
-        s_last = ticket == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+        s_last = ticket == gridDim.x - 1u ? 1u : 0u;
     }
     __syncthreads();
     if (s_last == 0u) return;  // uniform
     __threadfence();
     // the last workgroup: exclusive scan of the 256 row counts
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t c = __hip_atomic_load(&work[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t c = threadIdx.x < gridDim.x ? __hip_atomic_load(&work[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t inc = wave_incl_scan_add(c);
     const uint32_t mx = wave_max_u32(c);
     __syncthreads();
@@ -471,11 +477,14 @@ struct EvQuota { const uint32_t* sev; const uint32_t* lastns; const uint64_t* po
 // LDS, the range's wave-slots in order, sixteen (a CHUNK: one per wave) per step: `old = q[p]--`, barrier, `aft = q[p]`,
 // barrier; kept iff old > 0 -- except where the quota runs out inside the chunk (old > 0 but aft < 0: the draws of one
 // chunk come in no particular order): those groups are listed (chunk, position, -aft) by the record that drew
-// old == 1 and settled by k_pm_settle.  A wave's records are the 64 slots its descriptor names -- one scalar word, asked
-// for two rounds of the unrolled loop ahead -- and their positions are asked for kRankDepth - 1 chunks ahead, issued and
-// waited for by hand (see k_rank_mark).  Kept records: the wave adds its count to the range's running total (one LDS
-// atomic per wave and chunk, its answer picked up a chunk later so that nothing waits for it) and stores the kept
-// records' slots there in the range's kept list; kpw[wave-slot] = {where, how many} is what k_pm_tiles follows.
+// old == 1 and settled by k_pm_settle.  A wave's records are the 64 slots its descriptor names -- one word, asked for
+// fifteen chunks ahead -- and their positions are asked for seven chunks ahead, issued and waited for by hand.
+// Kept records: every wave owns a stretch of the kept list (kept_list[lo_p + 1024 range + wave * 64 chunks ...): what it
+// keeps cannot exceed what it walks) and appends there through a ring of 128 slots in LDS, 64 entries (one 256-byte
+// store) at a time; per chunk it notes {where its entries begin, how many} in a register of the lane chunk % 64 and
+// stores the 64 notes together.  So the loop holds a vector store every ~20 chunks, not two per chunk -- stores share the
+// loads' counter, and a counted wait also waits for every store still on its way (the first form of this kernel, with a
+// shared running total and two small stores per wave and chunk: 0.31 ms at cfg4).
 __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ desc,
                                                   const uint32_t* __restrict__ Tp, uint32_t pitch,
                                                   const uint32_t* __restrict__ range_start /* true flat starts */,
@@ -487,7 +496,8 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
                                                   uint32_t* __restrict__ amb_count /* [256] */,
                                                   unsigned long long* __restrict__ kept_total) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas
-    __shared__ uint32_t s_namb, s_total, s_kept;
+    __shared__ uint32_t s_namb, s_kept;
+    __shared__ uint32_t s_ring[16][128];  // per wave: kept records on their way to the list
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
@@ -537,20 +547,19 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         for (int u = 0; u < 8; ++u)
             if (i0 + u * nthreads < live) s_q[i0 + u * nthreads] = (int32_t)(a[u] - b[u]);
     }
-    if (tid == 0) { s_namb = 0; s_total = 0; s_kept = 0; }
+    if (tid == 0) { s_namb = 0; s_kept = 0; }
     __syncthreads();
 
     // The loads in flight -- positions and descriptors of the chunks ahead -- land in registers the COMPILER NEVER SEES:
-    // v96..v103 (positions of the chunk consumed at slot k of the unrolled loop), v104..v111 (descriptors), v112 (the
-    // answer of the wave's list-space request).  They are named in the assembly, issued and waited for by hand, and every
+    // v96..v103 (positions of the chunk consumed at slot k of the unrolled loop), v104..v111 (descriptors).  They are named in the assembly, issued and waited for by hand, and every
     // assembly statement of the kernel lists all of them as clobbered, so the compiler keeps nothing of its own there.
     // The first form of this kernel held them in compiler-allocated registers, as k_rank_mark does: the compiler then
     // kept a loop-carried descriptor in another register than the one its load writes and COPIED it at the loop's end --
     // a copy of a register whose load is still in flight, i.e. of what was there before: cfg4 came out different from
     // run to run, one run ended in a memory access fault (a stale descriptor's slots); small inputs never showed it.
-    // tools/isa_hazards.py checks the assembly for such reads and that v96..v112 occur in hand-written assembly only
+    // tools/isa_hazards.py checks the assembly for such reads and that v96..v111 occur in hand-written assembly only
     // (tests/test_isa_hazards.py).
-#define QMCP_PM_RING "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112"
+#define QMCP_PM_RING "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
 #define QMCP_PM_KEYREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_KEY_, k))
 #define QMCP_PM_DSCREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_DSC_, k))
 #define QMCP_PM_STR(x) QMCP_PM_STR2(x)
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
 #define QMCP_PM_DSC_6 110
 #define QMCP_PM_DSC_7 111
     static_assert(kRankDepth == 8, "the ring registers are named for eight slots");
-    struct Slot { uint32_t slot0, nv; };  // of a chunk whose positions are in flight or being consumed (uniform; the compiler's)
+    struct Slot { uint32_t slot0, nv; bool has; };  // of a chunk whose positions are in flight or being consumed (uniform; the compiler's)
     auto desc_offset = [&](uint32_t c) -> uint32_t {  // byte offset of the wave's descriptor of chunk c (the range's last beyond it: never used)
         return (g0 + min(16u * c + w, n_ws - 1u)) * 4u;
     };
@@ -583,28 +592,16 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         Slot s;
         s.slot0 = has ? (dsc >> 6) << 6 : 0u;
         s.nv = has ? (dsc & 63u) + 1u : 0u;
+        s.has = has;
         return s;
     };
     uint32_t kept = 0;
-    // what the previous chunk left to do once the answer of its list-space request is in: the wave's kept lanes, their
-    // first slot, the wave-slot
-    uint64_t pend_kb = 0;
-    uint32_t pend_slot0 = 0, pend_g = 0xFFFFFFFFu;
-    bool pend_asked = false;
-    const uint32_t total_addr = (uint32_t)(uintptr_t)&s_total;
-    auto flush = [&]() {
-        if (pend_g == 0xFFFFFFFFu) return;  // uniform
-        uint32_t ans = 0;
-        if (pend_asked) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, v112" : "=v"(ans) : : QMCP_PM_RING, "memory");  // (lane 0's is the answer)
-        const uint32_t cw = (uint32_t)__popcll(pend_kb);
-        const uint32_t base = lo_true + (uint32_t)__builtin_amdgcn_readfirstlane((int)ans);
-        if ((pend_kb >> lane) & 1ull) {
-            const uint32_t below = (uint32_t)__popcll(pend_kb & ((1ull << lane) - 1ull));
-            kept_list[base + below] = pend_slot0 + lane;
-        }
-        if (lane == 0) kpw[pend_g] = make_uint2(base, cw);
-        pend_g = 0xFFFFFFFFu;
-    };
+    // the wave's stretch of the kept list and of the notes; entries appended / stored so far (uniform)
+    const uint32_t list_base = lo_p + 1024u * range + w * 64u * n_chunks;
+    const uint32_t note_base = g0 + 16u * range + w * n_chunks;
+    uint32_t cur = 0, flushed = 0;
+    uint32_t note_x = 0, note_y = 0;  // lane l: the note of the wave's chunk c with c % 64 == l
+    uint32_t* const ring = s_ring[w];
     // One slot of the walk (K: its place in the unrolled loop, KF = (K + 7) % 8): chunk c is consumed from ring slot K;
     // chunk c + 7's positions are asked for into slot KF through slot K's descriptor (asked for eight slots ago), and
     // slot K's descriptor is asked for again, for chunk c + 15.
@@ -628,24 +625,24 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         __syncthreads();                                                                                                      \
         int32_t aft = 0;                                                                                                      \
         if (valid) aft = s_q[key];                                                                                            \
-        flush(); /* (the previous chunk's kept records: its request's answer came in with the LDS reads above) */             \
         const bool keep = valid && old > 0 && aft >= 0;                                                                       \
         if (valid && old == 1 && aft < 0) {                                                                                   \
             const uint32_t k = atomicAdd(&s_namb, 1u);                                                                        \
             amb[k] = make_uint2((c << 15) | key, (uint32_t)(-aft)); /* c < 2^17, key < 2^15 */                                \
         }                                                                                                                     \
         __syncthreads(); /* every q_after is read before the next chunk draws */                                              \
-        const uint64_t kb = __ballot(keep);                                                                                   \
-        if (at.nv != 0u) { /* uniform: the wave has a wave-slot in this chunk */                                              \
+        if (at.has) { /* uniform: the wave has a wave-slot in this chunk */                                                   \
+            const uint64_t kb = __ballot(keep);                                                                               \
             const uint32_t cw = (uint32_t)__popcll(kb);                                                                       \
-            pend_kb = kb;                                                                                                     \
-            pend_slot0 = at.slot0;                                                                                            \
-            pend_g = g0 + 16u * c + w;                                                                                        \
-            pend_asked = cw != 0u;                                                                                            \
-            /* (by hand: the compiler would wait for the answer on the spot) */                                               \
-            if (cw != 0u && lane == 0)                                                                                        \
-                asm volatile("ds_add_rtn_u32 v112, %0, %1" : : "v"(total_addr), "v"(cw) : QMCP_PM_RING, "memory");            \
+            if (lane == (c & 63u)) { note_x = list_base + cur; note_y = cw; }                                                 \
+            if (keep) ring[(cur + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))) & 127u] = at.slot0 + lane;                \
+            cur += cw;                                                                                                        \
             kept += cw;                                                                                                       \
+            if (cur - flushed >= 64u) { /* uniform */                                                                         \
+                kept_list[list_base + flushed + lane] = ring[(flushed + lane) & 127u];                                        \
+                flushed += 64u;                                                                                               \
+            }                                                                                                                 \
+            if ((c & 63u) == 63u) kpw[note_base + (c - 63u) + lane] = make_uint2(note_x, note_y);                             \
         }                                                                                                                     \
     }
     Slot S[kRankDepth];
@@ -658,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         for (int k = 0; k < kRankDepth - 1; ++k) d0[k] = desc[desc_offset((uint32_t)k) / 4u];
 #pragma unroll
         for (int k = 0; k < kRankDepth - 1; ++k) S[k] = slot_of(d0[k], (uint32_t)k);
-        S[kRankDepth - 1] = Slot{0u, 0u};
+        S[kRankDepth - 1] = Slot{0u, 0u, false};
 #define QMCP_PM_ASK_KEYS(K) asm volatile("global_load_ushort " QMCP_PM_KEYREG(K) ", %0, %1" : : "v"((S[K].slot0 + lane) * 2u), "s"(keys16) : QMCP_PM_RING, "memory");
 #define QMCP_PM_ASK_DSC(K) asm volatile("global_load_dword " QMCP_PM_DSCREG(K) ", %0, %1" : : "v"(desc_offset(7u + (uint32_t)(K))), "s"(desc) : QMCP_PM_RING, "memory");
         QMCP_PM_ASK_KEYS(0) QMCP_PM_ASK_KEYS(1) QMCP_PM_ASK_KEYS(2) QMCP_PM_ASK_KEYS(3) QMCP_PM_ASK_KEYS(4) QMCP_PM_ASK_KEYS(5) QMCP_PM_ASK_KEYS(6)
@@ -673,7 +670,11 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     }
 #undef QMCP_PM_STEP
     asm volatile("s_waitcnt vmcnt(0)" : : : QMCP_PM_RING, "memory");  // (the loads asked for beyond the last chunk)
-    flush();
+    if (lane < cur - flushed) kept_list[list_base + flushed + lane] = ring[(flushed + lane) & 127u];
+    if (w < n_ws) {  // (uniform) the notes of the wave's last, partial run of 64 chunks
+        const uint32_t c_last = (n_ws - 1u - w) >> 4;
+        if ((c_last & 63u) != 63u && lane <= (c_last & 63u)) kpw[note_base + (c_last & ~63u) + lane] = make_uint2(note_x, note_y);
+    }
     if (lane == 0 && kept) atomicAdd(&s_kept, kept);
     __syncthreads();
     if (tid == 0) {
@@ -682,59 +683,69 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     }
 }
 
-// The keep mask of one pass (8 192 reads, 128 words) from the kept lists: the pass's slot groups -> wave-slots (inv[]) ->
-// where each wave-slot's kept records went (kpw[]) -> their slots (kept_list[]) -> their read indices inside the pass
-// (idx16[]); bits are gathered in LDS and every word is written once.
-__global__ __launch_bounds__(256) void k_pm_tiles(const uint32_t* __restrict__ used64, const uint32_t* __restrict__ inv,
-                                                  const uint2* __restrict__ kpw, const uint32_t* __restrict__ kept_list,
-                                                  const uint16_t* __restrict__ idx16, uint32_t s64, uint32_t n,
-                                                  unsigned long long* __restrict__ mask) {
-    __shared__ uint32_t s_m[256];        // the pass's 128 mask words, as halves
-    __shared__ uint32_t s_pos[512];      // per slot group: where its kept records are listed
-    __shared__ uint32_t s_pref[513];     // ... and how many kept records the groups before it have
-    __shared__ uint32_t s_wsum[4];
-    const uint32_t P = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if ((uint64_t)P * kPmPass >= n) return;  // (uniform)
-    const uint32_t u = min(used64[P], 512u);  // (at most 8192 / 64 + 256 = 384)
-    s_m[tid] = 0;
-    uint32_t c0 = 0, c1 = 0;
-    {
-        const uint32_t t0 = 2u * tid, t1 = 2u * tid + 1u;
-        if (t0 < u) { const uint2 kp = kpw[inv[(size_t)P * s64 + t0]]; s_pos[t0] = kp.x; c0 = kp.y; }
-        if (t1 < u) { const uint2 kp = kpw[inv[(size_t)P * s64 + t1]]; s_pos[t1] = kp.x; c1 = kp.y; }
+// The keep mask of one pass (8 192 reads, 128 words) from the kept lists: the pass's slot groups -> the notes of their
+// wave-slots (inv[] -> kpw[]: where the wave-slot's kept records are listed, how many) -> their slots (kept_list[]) ->
+// their read indices inside the pass (idx16[]); bits are gathered in LDS and every word is written once.  ONE WAVE per
+// pass: the work is a chain of five dependent trips to memory over a few hundred items, so what matters is how many
+// passes a compute unit has in flight (a first form with four waves per pass and barriers between its phases: 0.056 ms).
+static constexpr uint32_t kPmTileGroups = 384;  // slot groups of a pass: 8192 / 64 + at most 256 partial ones
+__global__ __launch_bounds__(64) void k_pm_tiles(const uint32_t* __restrict__ used64, const uint32_t* __restrict__ inv,
+                                                 const uint2* __restrict__ kpw, const uint32_t* __restrict__ kept_list,
+                                                 const uint16_t* __restrict__ idx16, uint32_t s64, uint32_t n,
+                                                 unsigned long long* __restrict__ mask) {
+    __shared__ uint32_t s_m[256];                   // the pass's 128 mask words, as halves
+    __shared__ uint32_t s_pos[kPmTileGroups];       // per slot group: where its kept records are listed
+    __shared__ uint32_t s_pref[kPmTileGroups + 1];  // ... and how many kept records the groups before it have
+    const uint32_t P = blockIdx.x, lane = threadIdx.x;
+    const uint32_t u = min(used64[P], kPmTileGroups);
+    constexpr int kR = kPmTileGroups / 64;
+    uint32_t note[kR];
+    uint2 kp[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) note[r] = (uint32_t)r * 64u + lane < u ? inv[(size_t)P * s64 + (uint32_t)r * 64u + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) kp[r] = note[r] != 0xFFFFFFFFu ? kpw[note[r]] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_m[r * 64 + lane] = 0;
+    uint32_t run = 0;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        const uint32_t inc = wave_incl_scan_add(kp[r].y);
+        s_pos[r * 64 + lane] = kp[r].x;
+        s_pref[r * 64 + lane] = run + inc - kp[r].y;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
-    const uint32_t inc = wave_incl_scan_add(c0 + c1);
-    if (lane == 63u) s_wsum[wv] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t x = 0; x < wv; ++x) base += s_wsum[x];
-    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    s_pref[2u * tid] = base + inc - c0 - c1;
-    s_pref[2u * tid + 1u] = base + inc - c1;
-    if (tid == 255u) s_pref[512] = total;
-    __syncthreads();
-    for (uint32_t e = tid; e < total; e += 256u) {
-        uint32_t lo = 0, hi = 512;  // last group t with pref[t] <= e (groups beyond u hold no records: pref stays at total)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= e) lo = mid; else hi = mid;
+    if (lane == 0) s_pref[kPmTileGroups] = run;
+    __syncthreads();  // (one wave: orders the LDS writes above before the reads below)
+    const uint32_t total = run;
+    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        if (e < total) {
+            uint32_t lo = 0, hi = kPmTileGroups;  // last group t with pref[t] <= e (groups without records share their successor's prefix)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= e) lo = mid; else hi = mid;
+            }
+            const uint32_t slot = kept_list[s_pos[lo] + (e - s_pref[lo])];
+            const uint32_t i = idx16[slot];
+            atomicOr(&s_m[(i >> 5) & 255u], 1u << (i & 31u));
         }
-        const uint32_t slot = kept_list[s_pos[lo] + (e - s_pref[lo])];
-        const uint32_t i = idx16[slot];
-        atomicOr(&s_m[(i >> 5) & 255u], 1u << (i & 31u));
     }
     __syncthreads();
-    if (tid < 128u) {
-        const uint64_t word = (uint64_t)P * 128u + tid;
-        if (word < ((uint64_t)n + 63u) / 64u) mask[word] = (unsigned long long)s_m[2u * tid] | ((unsigned long long)s_m[2u * tid + 1u] << 32);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t j = (uint32_t)r * 64u + lane;
+        const uint64_t word = (uint64_t)P * 128u + j;
+        if (word < ((uint64_t)n + 63u) / 64u) mask[word] = (unsigned long long)s_m[2u * j] | ((unsigned long long)s_m[2u * j + 1u] << 32);
     }
 }
 
 // The listed (chunk, position) groups of every range: the position's `skip` LAST records of that chunk are the ones the
 // quota did not reach, so a wave walks the chunk's sixteen wave-slots backwards, passes over that many matches and
 // keeps the rest (their bits: the tile pass has written every word by now).  grid (ranges, kPmSettleY), four waves per
-// workgroup: a range's groups are dealt to 4 kPmSettleY waves.
-static constexpr uint32_t kPmSettleY = 16;
+// workgroup: a range's groups are dealt to 4 kPmSettleY waves, and a wave takes two groups at a time (all their loads
+// asked for before either is looked at: a group is three dependent trips to memory and little else).
+static constexpr uint32_t kPmSettleY = 32;
 __global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ keys16, const uint16_t* __restrict__ idx16,
                                                    const uint32_t* __restrict__ desc, const uint32_t* __restrict__ Tp,
                                                    uint32_t pitch, const uint32_t* __restrict__ range_start, uint32_t shift,
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ 
     __shared__ uint32_t s_kept;
     const uint32_t range = blockIdx.x, width = 1u << shift;
     const uint32_t namb = amb_count[range];
-    if (namb == 0u) return;  // uniform
+    if (blockIdx.y * 4u >= namb) return;  // uniform
     if (threadIdx.x == 0) s_kept = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -755,34 +766,43 @@ __global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ 
     const uint2* const amb = amb_lists + (lists_by_records ? (size_t)range_start[range] : (size_t)range * width);
     const uint64_t gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // lanes above this one
     uint32_t kept = 0;
-    for (uint32_t k = blockIdx.y * 4u + w; k < namb; k += 4u * gridDim.y) {
-        const uint2 ent = amb[k];
-        const uint32_t c = ent.x >> 15, p = ent.x & 0x7FFFu;
-        uint32_t skip = ent.y;  // matches still to be passed over, from the chunk's end
-        constexpr int kSteps = 16;
-        uint32_t key[kSteps], slot0[kSteps], nv[kSteps];
+    constexpr int kSteps = 16, kE = 2;
+    const uint32_t stride_k = 4u * gridDim.y;
+    for (uint32_t k0 = blockIdx.y * 4u + w; k0 < namb; k0 += kE * stride_k) {
+        uint32_t key[kE][kSteps], slot0[kE][kSteps], nv[kE][kSteps], p[kE], skip[kE];
 #pragma unroll
-        for (int t = 0; t < kSteps; ++t) {
-            const uint32_t ws = 16u * c + (uint32_t)t;
-            const PmSlot at = pm_unpack(ws < n_ws ? desc[g0 + ws] : 0u, ws < n_ws);
-            slot0[t] = at.slot0;
-            nv[t] = at.nv;
-            key[t] = keys16[at.slot0 + lane];
+        for (int x = 0; x < kE; ++x) {
+            const uint32_t k = k0 + (uint32_t)x * stride_k;
+            const uint2 ent = k < namb ? amb[k] : make_uint2(0u, 0u);
+            const uint32_t c = ent.x >> 15;
+            p[x] = k < namb ? ent.x & 0x7FFFu : 0xFFFFFFFFu;  // (no 16-bit position equals it)
+            skip[x] = ent.y;  // matches still to be passed over, from the chunk's end
+#pragma unroll
+            for (int t = 0; t < kSteps; ++t) {
+                const uint32_t ws = 16u * c + (uint32_t)t;
+                const PmSlot at = pm_unpack(ws < n_ws ? desc[g0 + ws] : 0u, ws < n_ws);
+                slot0[x][t] = at.slot0;
+                nv[x][t] = at.nv;
+                key[x][t] = keys16[at.slot0 + lane];
+            }
         }
 #pragma unroll
-        for (int t = kSteps - 1; t >= 0; --t) {
-            const bool member = lane < nv[t] && key[t] == p;
-            const uint64_t m = __ballot(member);
-            if (m == 0) continue;
-            const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
-            if (member && above >= skip) {
-                const uint32_t pass = (slot0[t] >> 6) / s64;
-                const uint32_t v = pass * (uint32_t)kPmPass + idx16[slot0[t] + lane];
-                atomicOr(&mask[v >> 6], 1ull << (v & 63u));
+        for (int x = 0; x < kE; ++x) {
+#pragma unroll
+            for (int t = kSteps - 1; t >= 0; --t) {
+                const bool member = lane < nv[x][t] && key[x][t] == p[x];
+                const uint64_t m = __ballot(member);
+                if (m == 0) continue;
+                const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
+                if (member && above >= skip[x]) {
+                    const uint32_t pass = (slot0[x][t] >> 6) / s64;
+                    const uint32_t v = pass * (uint32_t)kPmPass + idx16[slot0[x][t] + lane];
+                    atomicOr(&mask[v >> 6], 1ull << (v & 63u));
+                }
+                const uint32_t in_step = (uint32_t)__popcll(m);
+                kept += in_step > skip[x] ? in_step - skip[x] : 0u;
+                skip[x] = skip[x] > in_step ? skip[x] - in_step : 0u;
             }
-            const uint32_t in_step = (uint32_t)__popcll(m);
-            kept += in_step > skip ? in_step - skip : 0u;
-            skip = skip > in_step ? skip - in_step : 0u;
         }
     }
     if (lane == 0 && kept) atomicAdd(&s_kept, kept);
@@ -815,9 +835,8 @@ void launch_pm_descr(hipStream_t st, const uint32_t* Tp, const uint32_t* lstw, u
                      uint32_t* desc, uint32_t* inv, uint32_t* work, uint32_t* range_start, uint32_t* max_load) {
     const uint32_t pitch = pm_pitch(n), n_ranges = (ltot >> shift) + 1u;
     const uint32_t s64 = pm_stride(ltot, shift) / 64u;
-    hipLaunchKernelGGL(k_pm_descr, dim3((pitch + 255u) / 256u, 256), dim3(256), 0, st, Tp, lstw, pitch, s64, pitch * s64,
+    hipLaunchKernelGGL(k_pm_descr, dim3(n_ranges), dim3(256), 0, st, Tp, lstw, pitch, s64, pitch * s64,
                        desc, inv, work, range_start, max_load);
-    (void)n_ranges;
 }
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
                        const uint32_t* range_start, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
@@ -845,7 +864,7 @@ void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint32_t* desc
 void launch_pm_tiles(hipStream_t st, const uint16_t* idx16, const uint32_t* inv, const uint32_t* used64, uint32_t n,
                      uint32_t shift, uint32_t ltot, const uint32_t* kept_list, const void* kpw, unsigned long long* mask) {
     const uint32_t s64 = pm_stride(ltot, shift) / 64u;
-    hipLaunchKernelGGL(k_pm_tiles, dim3((n + (uint32_t)kPmPass - 1u) / (uint32_t)kPmPass), dim3(256), 0, st, used64, inv,
+    hipLaunchKernelGGL(k_pm_tiles, dim3((n + (uint32_t)kPmPass - 1u) / (uint32_t)kPmPass), dim3(64), 0, st, used64, inv,
                        (const uint2*)kpw, kept_list, idx16, s64, n, mask);
 }
 void launch_pm_settle(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,

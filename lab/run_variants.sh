@@ -1,13 +1,11 @@
 #!/bin/bash
 # lab: per-kernel times of cfg4 (one solve alone) for the product library and for each variant under lab/variants/
 #   lab/run_variants.sh <out-file> <script + args> -- <variant names...>   (run on the GPU box)
+# A variant is loaded through QMCP_HIP_LIB (genome-downsampler_amd/__init__.py): the product library is never overwritten.
 OUT="$1"; shift
 CMD=(); while [ "$1" != "--" ]; do CMD+=("$1"); shift; done; shift
-LIB=genome-downsampler_amd/lib/libqmcp_hip.so
-cp $LIB /tmp/product.so
 for v in product "$@"; do
-    if [ "$v" = product ]; then cp /tmp/product.so $LIB; else cp lab/variants/$v/libqmcp_hip.so $LIB; fi
     echo "=== $v" >> "$OUT"
-    python "${CMD[@]}" >> "$OUT" 2>&1
+    if [ "$v" = product ]; then python "${CMD[@]}" >> "$OUT" 2>&1
+    else QMCP_HIP_LIB="$PWD/lab/variants/$v/libqmcp_hip.so" python "${CMD[@]}" >> "$OUT" 2>&1; fi
 done
-cp /tmp/product.so $LIB

@@ -16,10 +16,11 @@ records in read-index order are its slices in pass order, each padded to whole g
 positions (a WAVE-SLOT, g = position / 64) therefore lies in exactly one slice, and a one-word descriptor per
 wave-slot says where: desc[g] = (first slot / 64) << 6 | (records in the group - 1).  The consumers never search:
     k_pm_offsets  walks a range's wave-slots in any order (LDS histogram of the positions);
-    k_pm_walk     walks them in order, sixteen (one chunk) per step, against the per-position quotas; kept records go
-                  to the range's kept list L (their slots), and every wave-slot records where its entries went;
-    k_pm_tiles    builds every pass's 128 mask words from the lists (inv[] maps a pass's slot groups back to
-                  wave-slots), every word written once;
+    k_pm_walk     walks them in order, sixteen (one chunk) per step, against the per-position quotas; every wave owns
+                  a stretch of the kept list (at lo_p + 1024 range + wave * 64 chunks) and appends its kept records'
+                  slots there; per chunk it notes {where, how many} at kpw[g0 + 16 range + wave * chunks + chunk];
+    k_pm_tiles    builds every pass's 128 mask words from the lists (inv[] maps a pass's slot groups to their
+                  wave-slots' notes), every word written once;
     k_pm_settle   decides the (chunk, position) groups whose quota ran out inside a chunk.
 """
 import numpy as np
@@ -74,9 +75,10 @@ def scan_table(cntp):
 
 
 def descriptors(Tp, lstw, n, n_ranges):
-    """k_pm_descr: one thread per (range, pass) table entry -> the slice's wave-slot descriptors, the inverse map, and
-    (row sums of the true counts, scanned) the ranges' TRUE flat starts.  -> desc [G], inv [pitch * stride / 64],
-    range_start [257] (true), used64 [pitch] (slot groups every pass uses)"""
+    """k_pm_descr: one thread per (range, pass) table entry -> the slice's wave-slot descriptors, the inverse map (slot
+    group -> index of the wave-slot's note: g0 + 16 range + wave * chunks + chunk), and (row sums of the true counts,
+    scanned) the ranges' TRUE flat starts.  -> desc [G], inv [pitch * stride / 64], range_start [257] (true), used64
+    [pitch] (slot groups every pass uses)"""
     pitch = pitch_for(n)
     stride = stride_for(n_ranges)
     s64 = stride // 64
@@ -86,6 +88,9 @@ def descriptors(Tp, lstw, n, n_ranges):
     true_rows = np.zeros(256, np.int64)
     used64 = np.zeros(pitch, np.uint32)
     for d in range(256):
+        lo_p, hi_p = int(Tp[d * pitch]), int(Tp[(d + 1) * pitch])
+        g0, n_chunks = lo_p // 64, ((hi_p - lo_p) // 64 + CHUNK_WS - 1) // CHUNK_WS
+        kb = g0 + 16 * d
         for P in range(pitch):
             w = int(lstw[d, P])
             cnt, lst64 = w >> 16, w & 0xFFFF
@@ -101,7 +106,8 @@ def descriptors(Tp, lstw, n, n_ranges):
                 group = P * s64 + lst64 + j
                 assert group < (1 << 26) and g + j < G and desc[g + j] == 0xFFFFFFFF and inv[group] == 0xFFFFFFFF
                 desc[g + j] = (group << 6) | (min(64, cnt - 64 * j) - 1)
-                inv[group] = g + j
+                ws = g + j - g0
+                inv[group] = kb + (ws % CHUNK_WS) * n_chunks + ws // CHUNK_WS
     assert not (desc == 0xFFFFFFFF).any()      # every wave-slot of the padded flat space belongs to a slice
     range_start = np.concatenate([[0], np.cumsum(true_rows)]).astype(np.uint32)
     assert int(range_start[-1]) <= n
@@ -127,16 +133,19 @@ def offsets(keys16, desc, Tp, pitch, d, shift):
     return hist
 
 
-def walk(keys16, desc, Tp, pitch, d, quota, range_start, rng):
+def walk(keys16, desc, Tp, pitch, d, quota, rng):
     """k_pm_walk for one range.  quota: int array [1 << shift] = S(p).  Chunks of 16 wave-slots in order; inside a chunk
-    the draws happen in an arbitrary order (rng permutation: the device's LDS arbitration).  -> L (dict position ->
-    slot, positions from range_start[d]), kpw (dict g -> (position, count)), amb [(chunk, position key, skip)], kept"""
+    the draws happen in an arbitrary order (rng permutation: the device's LDS arbitration).  Wave w appends its kept
+    records' slots at list_base(w) = lo_p + 1024 d + w * 64 * chunks and notes (where, how many) per chunk.
+    -> L (dict list position -> slot), kpw (dict note index -> (position, count)), amb [(chunk, position key, skip)],
+    kept"""
     g0, n_ws = range_wave_slots(Tp, pitch, d)
+    lo_p = g0 * 64
     q = quota.astype(np.int64).copy()
     L, kpw, amb = {}, {}, []
-    total = 0
     kept = 0
     n_chunks = (n_ws + CHUNK_WS - 1) // CHUNK_WS
+    cur = [0] * CHUNK_WS
     for c in range(n_chunks):
         recs = []          # (wave, lane, key, slot)
         for w in range(CHUNK_WS):
@@ -159,17 +168,21 @@ def walk(keys16, desc, Tp, pitch, d, quota, range_start, rng):
                 per_wave.setdefault(w, []).append(slot)
             if old[i] == 1 and aft < 0:
                 amb.append((c, key, int(-aft)))
-        for w in rng.permutation(CHUNK_WS):          # the waves' appends come in any order
-            ws = c * CHUNK_WS + int(w)
+        for w in range(CHUNK_WS):
+            ws = c * CHUNK_WS + w
             if ws >= n_ws:
                 continue
-            ent = per_wave.get(int(w), [])
-            pos = int(range_start[d]) + total
-            kpw[g0 + ws] = (pos, len(ent))
+            ent = per_wave.get(w, [])
+            list_base = lo_p + 1024 * d + w * 64 * n_chunks
+            pos = list_base + cur[w]
+            assert cur[w] + len(ent) <= 64 * n_chunks       # a wave keeps at most what it walks
+            note = g0 + 16 * d + w * n_chunks + c
+            assert note not in kpw
+            kpw[note] = (pos, len(ent))
             for k, slot in enumerate(ent):
-                assert pos + k < int(range_start[d + 1])      # the list has room for every record of the range
+                assert pos + k not in L
                 L[pos + k] = slot
-            total += len(ent)
+            cur[w] += len(ent)
             kept += len(ent)
     return L, kpw, amb, kept
 
@@ -180,9 +193,9 @@ def tiles(L, kpw, inv, idx16, used64, n, n_ranges):
     mask = np.zeros(n, bool)
     for P in range((n + PASS - 1) // PASS):
         for t in range(int(used64[P])):
-            g = int(inv[P * s64 + t])
-            assert g != 0xFFFFFFFF
-            pos, cnt = kpw[g]
+            note = int(inv[P * s64 + t])
+            assert note != 0xFFFFFFFF
+            pos, cnt = kpw[note]
             for e in range(cnt):
                 slot = L[pos + e]
                 assert slot // (s64 * 64) == P
