@@ -16,16 +16,14 @@
 //   (scan)              exclusive scan over the padded count table: Tp[d][P] = the PADDED FLAT position of the slice --
 //                       range d's records in read-index order are its slices in pass order, each padded to whole
 //                       groups, so a group of 64 padded flat positions (a WAVE-SLOT) lies in exactly one slice.
-//   k_pm_descr          one thread per table entry: one descriptor word per wave-slot, (first slot / 64) << 6 |
-//                       (records in the group - 1), and the inverse map slot group -> wave-slot; the rows' true counts
-//                       added up and scanned: the ranges' true flat starts (the bucket offsets' bases) + heaviest load.
+//   k_pm_descr          one thread per table entry: one descriptor word per wave-slot -- pass << 15 | slot group inside the
+//                       pass << 6 | (records in the group - 1) --; the rows' true record counts (k_pm_range_table scans
+//                       them: the ranges' true flat starts -- the bucket offsets' bases -- and the heaviest load).
 //   k_pm_offsets        per range: LDS histogram of its wave-slots' positions -> bucket offsets (k_range_offsets' job).
 //   k_pm_walk           per range: k_rank_mark's ordered walk, a chunk of sixteen wave-slots per step, each wave's
-//                       records found through ONE scalar descriptor (round 3 searched the table's row with a cursor in
+//                       records found through ONE descriptor word (round 3 searched the table's row with a cursor in
 //                       LDS: 57 vector instructions per wave and chunk against the range-major walk's 21).  Kept
-//                       records are not marked one atomic at a time (32 B of HBM writes per kept bit): their slots go
-//                       to the range's kept list, every wave-slot notes where.
-//   k_pm_tiles          per pass: the pass's 128 mask words from the lists, every word written once.
+//                       records' read indices collect in a ring in LDS, per wave, and are marked 64 at a time.
 //   k_pm_settle         the (chunk, position) groups whose quota ran out inside a chunk, one wave per group, chip-wide.
 // A range's records in read-index order are its slices in pass order, so nothing about the selection changes: the
 // kept set is bit for bit the first form's.  One-level genomes only (<= 256 ranges); longer ones keep the two-level
@@ -36,7 +34,7 @@ __host__ __device__ inline uint32_t pm_stride_of(uint32_t n_ranges) { return (ui
 static constexpr int kPmThreads = 512;           // 8 waves: wave w owns records [1024 w, 1024 (w + 1)) of the pass
 static constexpr int kPmWaves = kPmThreads / 64;
 static constexpr int kPmPassesPerWg = 4;         // a workgroup's passes leave their table entries as 16-byte runs
-static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 2 * 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 128 + kPmPassesPerWg) * sizeof(uint32_t);
+static constexpr size_t kPmSortLds = ((size_t)kPmPass + kPmWaves * 256 + 2 * 256 + 16 + 2 * kPmPassesPerWg * 256 + kPmWaves * 3 * 128) * sizeof(uint32_t);
 static constexpr uint32_t kPmExcPerWave = 128;  // list slots per wave and pass: an eighth of the wave's 1 024 reads
 
 #ifndef QMCP_PM_MIN_WAVES
@@ -48,7 +46,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t shift, uint32_t stride /* pm_stride_of(ranges of the genome) */,
     uint16_t* __restrict__ keys16, uint16_t* __restrict__ idx16,
     uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ lst_tab, uint32_t pitch /* multiple of 4 */,
-    uint32_t* __restrict__ used64 /* [pitch]: slot groups every pass uses */,
     uint32_t* __restrict__ work /* 260 words k_pm_descr adds into: cleared here */,
     uint32_t* __restrict__ stats, unsigned long long* __restrict__ zero_mask,
     // near-uniform route (kernels/near_uniform.inc.hip): reads whose span is not ell_reg are left out of the sorted
@@ -67,7 +64,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     uint32_t* s_tabc = s_wave + 16;                     // [4][256] the workgroup's table entries
     uint32_t* s_tabl = s_tabc + kPmPassesPerWg * 256;   // [4][256]
     uint32_t* s_exc = s_tabl + kPmPassesPerWg * 256;    // [8][128][3] every wave's exceptions of the pass, until the pass is written out
-    uint32_t* s_used = s_exc + kPmWaves * 3 * 128;      // [4] slot groups the workgroup's passes use
     if (blockIdx.x == 0 && threadIdx.x < 260) work[threadIdx.x] = 0;  // (k_pm_descr's row sums and ticket)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t mn = 0xFFFFFFFFu, mx = 0, bad = 0;
@@ -84,7 +80,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
         const uint64_t base64 = (uint64_t)P * kPmPass;
         if (base64 >= n) {  // (uniform) a pass beyond the reads: zero table entries, the scan runs over the padding too
             if (threadIdx.x < 256) { s_tabc[g * 256 + threadIdx.x] = 0; s_tabl[g * 256 + threadIdx.x] = 0; }
-            if (threadIdx.x == 0) s_used[g] = 0;
             if (ell_reg != 0u && lane == 0 && P < pitch) exc_cnt[P * kPmWaves + w] = 0;
             continue;
         }
@@ -223,7 +218,6 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             s_gbase[d] = tile_off;
             s_pbase[d] = ptile_off;
             s_tabl[g * 256 + d] |= ptile_off >> 6;   // (< 2^16: a pass has at most 8192 / 64 + 256 slot groups)
-            if (d == 255) s_used[g] = (ptile_off + s_tabc[g * 256 + 255]) >> 6;
         }
         __syncthreads();
 #pragma unroll
@@ -283,8 +277,7 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             *reinterpret_cast<uint4*>(lst_tab + (size_t)threadIdx.x * pitch + P0) = b;
         }
     }
-    if (threadIdx.x < kPmPassesPerWg && blockIdx.x * kPmPassesPerWg + threadIdx.x < pitch)
-        used64[blockIdx.x * kPmPassesPerWg + threadIdx.x] = s_used[threadIdx.x];
+
     // statistics: block reduction, at most one atomic per statistic per workgroup (k_prepare)
     __shared__ uint32_t s_red[3][kPmWaves];
     mn = wave_min_u32(mn);
@@ -300,62 +293,74 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
     }
 }
 
-// k_pm_descr's working words (cleared by k_pm_prepare_sort): [0..255] the rows' true record counts, [256] ticket
+// k_pm_descr's working words (cleared by k_pm_prepare_sort): [0..255] the rows' true record counts
 static constexpr uint32_t kPmWorkWords = 260;
+static constexpr uint32_t kPmDescrY = 8;  // workgroups per range
 
-// One workgroup per range, a thread per (range, pass) table entry in turn: the slice's wave-slot descriptors and the
-// inverse map -- slot group -> where k_pm_walk notes the wave-slot's kept records: kpw[kb + wave * chunks + chunk], kb =
-// the range's first wave-slot + 16 * range, so that the notes of one wave's consecutive chunks are neighbours --; the
-// row's true record count; the last workgroup to finish scans the 256 counts into the ranges' true flat starts (the
-// bucket offsets' bases, the ambiguity lists' bases) and the heaviest range's load.  (A first form had a workgroup per
-// 256 entries, every one ending in an atomic on the same ticket word: 12 288 same-address atomics, 0.49 ms.)
+// A wave-slot's descriptor: pass << 15 | slot group inside the pass << 6 | (records - 1).  (2^17 passes: 2^30 reads; 512
+// slot groups: a pass holds at most 8192 / 64 + 256.)
+struct PmSlot { uint32_t slot0, nv, pass; };
+// (kVector: the descriptor sits in a vector register -- the 24-bit multiply is the full-rate one there; a uniform
+//  descriptor goes through the scalar unit, which has the plain multiply only)
+template <bool kVector>
+__device__ __forceinline__ PmSlot pm_unpack(uint32_t dsc, bool has, uint32_t stride) {
+    PmSlot s;
+    s.pass = dsc >> 15;
+    s.slot0 = has ? (kVector ? __umul24(s.pass, stride) : s.pass * stride) + (((dsc >> 6) & 511u) << 6) : 0u;
+    s.nv = has ? (dsc & 63u) + 1u : 0u;
+    return s;
+}
+
+// A thread per (range, pass) table entry: the slice's wave-slot descriptors; per range the true record count (one atomic
+// per workgroup; kPmDescrY workgroups a range).  (A first form had a workgroup per 256 entries, every one ending in an
+// atomic on one ticket word: 12 288 same-address atomics, 0.49 ms; one workgroup per range with a ticket: 0.044 ms, a
+// serial loop of dependent loads per thread.)
 __global__ __launch_bounds__(256) void k_pm_descr(const uint32_t* __restrict__ Tp, const uint32_t* __restrict__ lstw,
-                                                  uint32_t pitch, uint32_t s64 /* stride / 64 */, uint32_t n_groups /* total padded flat / 64 bound */,
-                                                  uint32_t* __restrict__ desc, uint32_t* __restrict__ inv,
-                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ range_start /* [257] */,
-                                                  uint32_t* __restrict__ max_load) {
+                                                  uint32_t pitch, uint32_t n_groups /* total padded flat / 64 bound */,
+                                                  uint32_t* __restrict__ desc, uint32_t* __restrict__ work) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_last;
     const uint32_t d = blockIdx.x;
-    const uint32_t lo_p = Tp[(size_t)d * pitch], hi_p = Tp[(size_t)(d + 1) * pitch];
-    const uint32_t g0 = lo_p >> 6, n_chunks = (((hi_p - lo_p) >> 6) + 15u) >> 4;
-    const uint32_t kb = g0 + 16u * d;
+    const uint32_t per = (pitch + gridDim.y - 1u) / gridDim.y;
+    const uint32_t P_end = min(pitch, (blockIdx.y + 1u) * per);
     uint32_t mine = 0;
-    if (hi_p > lo_p)  // (uniform)
-        for (uint32_t P = threadIdx.x; P < pitch; P += 256u) {
-            const uint32_t w = lstw[(size_t)d * pitch + P];
-            const uint32_t cnt = w >> 16;
+    for (uint32_t P0 = blockIdx.y * per + threadIdx.x; P0 < P_end; P0 += 4u * 256u) {
+        uint32_t w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t P = min(P0 + (uint32_t)u * 256u, P_end - 1u);  // clamped: every load is issued
+            w[u] = lstw[(size_t)d * pitch + P];
+            t[u] = Tp[(size_t)d * pitch + P];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t P = P0 + (uint32_t)u * 256u;
+            const uint32_t cnt = P < P_end ? w[u] >> 16 : 0u;
             if (cnt == 0u) continue;
             mine += cnt;
-            const uint32_t g = Tp[(size_t)d * pitch + P] >> 6;
-            const uint32_t group = P * s64 + (w & 0xFFFFu);
+            const uint32_t g = t[u] >> 6;
             const uint32_t n_ws = (cnt + 63u) >> 6;
-            for (uint32_t j = 0; j < n_ws; ++j) {
-                if (g + j < n_groups) {  // (always: the bound is the buffers' size)
-                    const uint32_t ws = g + j - g0;
-                    desc[g + j] = ((group + j) << 6) | (min(64u, cnt - 64u * j) - 1u);
-                    inv[group + j] = kb + (ws & 15u) * n_chunks + (ws >> 4);
-                }
-            }
+            for (uint32_t j = 0; j < n_ws; ++j)
+                if (g + j < n_groups)  // (always: the bound is the buffer's size)
+                    desc[g + j] = (P << 15) | (((w[u] & 0xFFFFu) + j) << 6) | (min(64u, cnt - 64u * j) - 1u);
         }
+    }
     const uint32_t sum = wave_sum_u32(mine);
     if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&work[d], s_red[0] + s_red[1] + s_red[2] + s_red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const uint32_t ticket = atomicAdd(&work[256], 1u);
-        s_last = ticket == gridDim.x - 1u ? 1u : 0u;
+        const uint32_t tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (tot != 0u) atomicAdd(&work[d], tot);
     }
-    __syncthreads();
-    if (s_last == 0u) return;  // uniform
-    __threadfence();
-    // the last workgroup: exclusive scan of the 256 row counts
+}
+
+// the ranges' true flat starts (257 entries) and the heaviest range's load, from the rows' true counts
+__global__ __launch_bounds__(256) void k_pm_range_table(const uint32_t* __restrict__ work, uint32_t* __restrict__ range_start,
+                                                        uint32_t* __restrict__ max_load) {
+    __shared__ uint32_t s_red[4];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t c = threadIdx.x < gridDim.x ? __hip_atomic_load(&work[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t c = work[threadIdx.x];
     const uint32_t inc = wave_incl_scan_add(c);
     const uint32_t mx = wave_max_u32(c);
-    __syncthreads();
     if (lane == 63u) s_red[wv] = inc;
     __syncthreads();
     uint32_t base = 0;
@@ -368,22 +373,13 @@ __global__ __launch_bounds__(256) void k_pm_descr(const uint32_t* __restrict__ T
     if (threadIdx.x == 0) max_load[0] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-// A wave-slot's descriptor, unpacked (uniform)
-struct PmSlot { uint32_t slot0, nv; };
-__device__ __forceinline__ PmSlot pm_unpack(uint32_t dsc, bool has) {
-    PmSlot s;
-    s.slot0 = has ? (dsc >> 6) << 6 : 0u;
-    s.nv = has ? (dsc & 63u) + 1u : 0u;
-    return s;
-}
-
 // k_range_offsets for the pass-major layout: the range's positions come as wave-slots, in any order.  A wave takes four
 // wave-slots at a time -- sixteen lanes each, four records (8 bytes) per lane: one 512-byte request -- and keeps kU
 // such requests in flight.
 __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ desc,
                                                      const uint32_t* __restrict__ Tp, uint32_t pitch,
                                                      const uint32_t* __restrict__ range_start /* true flat starts */,
-                                                     uint32_t shift, uint32_t ltot, uint32_t* __restrict__ boff,
+                                                     uint32_t shift, uint32_t stride, uint32_t ltot, uint32_t* __restrict__ boff,
                                                      uint32_t* __restrict__ empty_positions) {
     extern __shared__ uint32_t s_cnt32[];  // [(1 << shift) padded] counters
 #define PADDED(i) ((i) + ((i) >> 5))
@@ -417,9 +413,9 @@ __global__ __launch_bounds__(1024) void k_pm_offsets(const uint16_t* __restrict_
                 dsc = sub == 0 ? d0 : sub == 1 ? d1 : sub == 2 ? d2 : d3;
                 has = ws + sub < n_ws;
             }
-            const uint32_t slot0 = has ? (dsc >> 6) << 6 : 0u;
-            nv[u] = has ? (dsc & 63u) + 1u : 0u;
-            v[u] = *reinterpret_cast<const uint2*>(keys16 + slot0 + 4u * l16);   // (inside the slice's padded group: always readable)
+            const PmSlot at = pm_unpack<true>(dsc, has, stride);
+            nv[u] = at.nv;
+            v[u] = *reinterpret_cast<const uint2*>(keys16 + at.slot0 + 4u * l16);   // (inside the slice's padded group: always readable)
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -478,26 +474,24 @@ struct EvQuota { const uint32_t* sev; const uint32_t* lastns; const uint64_t* po
 // barrier; kept iff old > 0 -- except where the quota runs out inside the chunk (old > 0 but aft < 0: the draws of one
 // chunk come in no particular order): those groups are listed (chunk, position, -aft) by the record that drew
 // old == 1 and settled by k_pm_settle.  A wave's records are the 64 slots its descriptor names -- one word, asked for
-// fifteen chunks ahead -- and their positions are asked for seven chunks ahead, issued and waited for by hand.
-// Kept records: every wave owns a stretch of the kept list (kept_list[lo_p + 1024 range + wave * 64 chunks ...): what it
-// keeps cannot exceed what it walks) and appends there through a ring of 128 slots in LDS, 64 entries (one 256-byte
-// store) at a time; per chunk it notes {where its entries begin, how many} in a register of the lane chunk % 64 and
-// stores the 64 notes together.  So the loop holds a vector store every ~20 chunks, not two per chunk -- stores share the
-// loads' counter, and a counted wait also waits for every store still on its way (the first form of this kernel, with a
-// shared running total and two small stores per wave and chunk: 0.31 ms at cfg4).
-__global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ desc,
+// fifteen chunks ahead -- and their positions and read indices are asked for seven chunks ahead, issued and waited for by
+// hand.  Kept records: the wave collects their read indices in a ring of 128 words in LDS and marks them 64 at a time --
+// one atomic instruction every ~20 chunks instead of one per chunk: atomics and stores share the loads' counter, and a
+// counted wait also waits for everything of theirs that is still on its way.
+__global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ keys16, const uint16_t* __restrict__ idx16,
+                                                  const uint32_t* __restrict__ desc,
                                                   const uint32_t* __restrict__ Tp, uint32_t pitch,
                                                   const uint32_t* __restrict__ range_start /* true flat starts */,
-                                                  uint32_t shift, uint32_t ltot,
+                                                  uint32_t shift, uint32_t stride, uint32_t ltot,
                                                   const uint32_t* __restrict__ boff, const uint32_t* __restrict__ selend,
                                                   EvQuota evq,
-                                                  uint32_t* __restrict__ kept_list, uint2* __restrict__ kpw,
+                                                  unsigned long long* __restrict__ mask,
                                                   uint2* __restrict__ amb_lists, int lists_by_records,
                                                   uint32_t* __restrict__ amb_count /* [256] */,
                                                   unsigned long long* __restrict__ kept_total) {
     extern __shared__ int32_t s_q[];  // [(1 << shift) + 1] quotas
     __shared__ uint32_t s_namb, s_kept;
-    __shared__ uint32_t s_ring[16][128];  // per wave: kept records on their way to the list
+    __shared__ uint32_t s_ring[16][128];  // per wave: kept records' read indices on their way to the mask
     const uint32_t range = blockIdx.x, width = 1u << shift, pos0 = range << shift;
     const uint32_t live = pos0 < ltot ? min(width, ltot - pos0) : 0u;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
@@ -551,17 +545,19 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     __syncthreads();
 
     // The loads in flight -- positions and descriptors of the chunks ahead -- land in registers the COMPILER NEVER SEES:
-    // v96..v103 (positions of the chunk consumed at slot k of the unrolled loop), v104..v111 (descriptors).  They are named in the assembly, issued and waited for by hand, and every
+    // v96..v103 (positions of the chunk consumed at slot k of the unrolled loop), v104..v111 (descriptors), v112..v119 (read
+    // indices inside the pass).  They are named in the assembly, issued and waited for by hand, and every
     // assembly statement of the kernel lists all of them as clobbered, so the compiler keeps nothing of its own there.
     // The first form of this kernel held them in compiler-allocated registers, as k_rank_mark does: the compiler then
     // kept a loop-carried descriptor in another register than the one its load writes and COPIED it at the loop's end --
     // a copy of a register whose load is still in flight, i.e. of what was there before: cfg4 came out different from
     // run to run, one run ended in a memory access fault (a stale descriptor's slots); small inputs never showed it.
-    // tools/isa_hazards.py checks the assembly for such reads and that v96..v111 occur in hand-written assembly only
+    // tools/isa_hazards.py checks the assembly for such reads and that v96..v119 occur in hand-written assembly only
     // (tests/test_isa_hazards.py).
-#define QMCP_PM_RING "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
+#define QMCP_PM_RING "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119"
 #define QMCP_PM_KEYREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_KEY_, k))
 #define QMCP_PM_DSCREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_DSC_, k))
+#define QMCP_PM_IDXREG(k) "v" QMCP_PM_STR(QMCP_PM_CAT(QMCP_PM_IDX_, k))
 #define QMCP_PM_STR(x) QMCP_PM_STR2(x)
 #define QMCP_PM_STR2(x) #x
 #define QMCP_PM_CAT(a, b) QMCP_PM_CAT2(a, b)
@@ -582,45 +578,54 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
 #define QMCP_PM_DSC_5 109
 #define QMCP_PM_DSC_6 110
 #define QMCP_PM_DSC_7 111
+#define QMCP_PM_IDX_0 112
+#define QMCP_PM_IDX_1 113
+#define QMCP_PM_IDX_2 114
+#define QMCP_PM_IDX_3 115
+#define QMCP_PM_IDX_4 116
+#define QMCP_PM_IDX_5 117
+#define QMCP_PM_IDX_6 118
+#define QMCP_PM_IDX_7 119
     static_assert(kRankDepth == 8, "the ring registers are named for eight slots");
-    struct Slot { uint32_t slot0, nv; bool has; };  // of a chunk whose positions are in flight or being consumed (uniform; the compiler's)
+    struct Slot { uint32_t slot0, nv, read0; bool has; };  // of a chunk whose records are in flight or being consumed (uniform; the compiler's)
     auto desc_offset = [&](uint32_t c) -> uint32_t {  // byte offset of the wave's descriptor of chunk c (the range's last beyond it: never used)
         return (g0 + min(16u * c + w, n_ws - 1u)) * 4u;
     };
     auto slot_of = [&](uint32_t dsc, uint32_t c) -> Slot {
         const bool has = 16u * c + w < n_ws;  // uniform
+        const PmSlot at = pm_unpack<true>(dsc, has, stride);
         Slot s;
-        s.slot0 = has ? (dsc >> 6) << 6 : 0u;
-        s.nv = has ? (dsc & 63u) + 1u : 0u;
+        s.slot0 = at.slot0;
+        s.nv = at.nv;
+        s.read0 = at.pass * (uint32_t)kPmPass;  // the pass's first read
         s.has = has;
         return s;
     };
-    uint32_t kept = 0;
-    // the wave's stretch of the kept list and of the notes; entries appended / stored so far (uniform)
-    const uint32_t list_base = lo_p + 1024u * range + w * 64u * n_chunks;
-    const uint32_t note_base = g0 + 16u * range + w * n_chunks;
+    uint32_t kept = 0;  // (set from `cur` after the walk)
+    // kept read indices collected / marked so far (uniform)
     uint32_t cur = 0, flushed = 0;
-    uint32_t note_x = 0, note_y = 0;  // lane l: the note of the wave's chunk c with c % 64 == l
     uint32_t* const ring = s_ring[w];
     // One slot of the walk (K: its place in the unrolled loop, KF = (K + 7) % 8): chunk c is consumed from ring slot K;
     // chunk c + 7's positions are asked for into slot KF through slot K's descriptor (asked for eight slots ago), and
     // slot K's descriptor is asked for again, for chunk c + 15.
-    // Loads complete in issue order.  Per slot two are issued: positions, then a descriptor.  The positions of chunk c
-    // were asked for seven slots ago and 13 loads have been issued since; the descriptor read with them is older still.
-    // (Younger stores only make the wait longer.)
+    // Loads complete in issue order.  Per slot three are issued: positions, read indices, a descriptor.  The read indices
+    // of chunk c were asked for seven slots ago and 19 loads have been issued since; its positions and the descriptor read
+    // with them are older.  (Younger stores and atomics only make the wait longer.)
 #define QMCP_PM_STEP(K, KF)                                                                                                   \
     {                                                                                                                         \
         const uint32_t c = c0 + (uint32_t)(K);                                                                                \
-        uint32_t key, dsc;                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(13)\n\tv_mov_b32 %0, " QMCP_PM_KEYREG(K) "\n\tv_mov_b32 %1, " QMCP_PM_DSCREG(K)          \
-                     : "=v"(key), "=v"(dsc) : : QMCP_PM_RING, "memory");                                                      \
+        uint32_t key, dsc, idx;                                                                                               \
+        asm volatile("s_waitcnt vmcnt(19)\n\tv_mov_b32 %0, " QMCP_PM_KEYREG(K) "\n\tv_mov_b32 %1, " QMCP_PM_DSCREG(K)          \
+                     "\n\tv_mov_b32 %2, " QMCP_PM_IDXREG(K)                                                                   \
+                     : "=v"(key), "=v"(dsc), "=v"(idx) : : QMCP_PM_RING, "memory");                                                      \
         const Slot at = S[K];                                                                                                 \
         const bool valid = lane < at.nv;                                                                                      \
         int32_t old = 0;                                                                                                      \
         if (valid) old = atomicSub(&s_q[key], 1); /* (the 16-bit load zero-extends) */                                        \
         S[KF] = slot_of(dsc, c + 7u);                                                                                         \
-        asm volatile("global_load_ushort " QMCP_PM_KEYREG(KF) ", %0, %1\n\tglobal_load_dword " QMCP_PM_DSCREG(K) ", %2, %3"     \
-                     : : "v"((S[KF].slot0 + lane) * 2u), "s"(keys16), "v"(desc_offset(c + 15u)), "s"(desc)                    \
+        asm volatile("global_load_ushort " QMCP_PM_KEYREG(KF) ", %0, %1\n\tglobal_load_ushort " QMCP_PM_IDXREG(KF) ", %0, %2"   \
+                     "\n\tglobal_load_dword " QMCP_PM_DSCREG(K) ", %3, %4"                                                    \
+                     : : "v"((S[KF].slot0 + lane) * 2u), "s"(keys16), "s"(idx16), "v"(desc_offset(c + 15u)), "s"(desc)        \
                      : QMCP_PM_RING, "memory");                                                                               \
         __syncthreads();                                                                                                      \
         int32_t aft = 0;                                                                                                      \
@@ -634,15 +639,13 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         if (at.has) { /* uniform: the wave has a wave-slot in this chunk */                                                   \
             const uint64_t kb = __ballot(keep);                                                                               \
             const uint32_t cw = (uint32_t)__popcll(kb);                                                                       \
-            if (lane == (c & 63u)) { note_x = list_base + cur; note_y = cw; }                                                 \
-            if (keep) ring[(cur + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))) & 127u] = at.slot0 + lane;                \
+            if (keep) ring[(cur + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))) & 127u] = at.read0 + idx;                 \
             cur += cw;                                                                                                        \
-            kept += cw;                                                                                                       \
             if (cur - flushed >= 64u) { /* uniform */                                                                         \
-                kept_list[list_base + flushed + lane] = ring[(flushed + lane) & 127u];                                        \
+                const uint32_t v = ring[(flushed + lane) & 127u];                                                             \
+                atomicOr(&mask[v >> 6], 1ull << (v & 63u));                                                                   \
                 flushed += 64u;                                                                                               \
             }                                                                                                                 \
-            if ((c & 63u) == 63u) kpw[note_base + (c - 63u) + lane] = make_uint2(note_x, note_y);                             \
         }                                                                                                                     \
     }
     Slot S[kRankDepth];
@@ -655,8 +658,8 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         for (int k = 0; k < kRankDepth - 1; ++k) d0[k] = desc[desc_offset((uint32_t)k) / 4u];
 #pragma unroll
         for (int k = 0; k < kRankDepth - 1; ++k) S[k] = slot_of(d0[k], (uint32_t)k);
-        S[kRankDepth - 1] = Slot{0u, 0u, false};
-#define QMCP_PM_ASK_KEYS(K) asm volatile("global_load_ushort " QMCP_PM_KEYREG(K) ", %0, %1" : : "v"((S[K].slot0 + lane) * 2u), "s"(keys16) : QMCP_PM_RING, "memory");
+        S[kRankDepth - 1] = Slot{0u, 0u, 0u, false};
+#define QMCP_PM_ASK_KEYS(K) asm volatile("global_load_ushort " QMCP_PM_KEYREG(K) ", %0, %1\n\tglobal_load_ushort " QMCP_PM_IDXREG(K) ", %0, %2" : : "v"((S[K].slot0 + lane) * 2u), "s"(keys16), "s"(idx16) : QMCP_PM_RING, "memory");
 #define QMCP_PM_ASK_DSC(K) asm volatile("global_load_dword " QMCP_PM_DSCREG(K) ", %0, %1" : : "v"(desc_offset(7u + (uint32_t)(K))), "s"(desc) : QMCP_PM_RING, "memory");
         QMCP_PM_ASK_KEYS(0) QMCP_PM_ASK_KEYS(1) QMCP_PM_ASK_KEYS(2) QMCP_PM_ASK_KEYS(3) QMCP_PM_ASK_KEYS(4) QMCP_PM_ASK_KEYS(5) QMCP_PM_ASK_KEYS(6)
         QMCP_PM_ASK_DSC(0) QMCP_PM_ASK_DSC(1) QMCP_PM_ASK_DSC(2) QMCP_PM_ASK_DSC(3) QMCP_PM_ASK_DSC(4) QMCP_PM_ASK_DSC(5) QMCP_PM_ASK_DSC(6) QMCP_PM_ASK_DSC(7)
@@ -670,11 +673,11 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     }
 #undef QMCP_PM_STEP
     asm volatile("s_waitcnt vmcnt(0)" : : : QMCP_PM_RING, "memory");  // (the loads asked for beyond the last chunk)
-    if (lane < cur - flushed) kept_list[list_base + flushed + lane] = ring[(flushed + lane) & 127u];
-    if (w < n_ws) {  // (uniform) the notes of the wave's last, partial run of 64 chunks
-        const uint32_t c_last = (n_ws - 1u - w) >> 4;
-        if ((c_last & 63u) != 63u && lane <= (c_last & 63u)) kpw[note_base + (c_last & ~63u) + lane] = make_uint2(note_x, note_y);
+    if (lane < cur - flushed) {
+        const uint32_t v = ring[(flushed + lane) & 127u];
+        atomicOr(&mask[v >> 6], 1ull << (v & 63u));
     }
+    kept = cur;
     if (lane == 0 && kept) atomicAdd(&s_kept, kept);
     __syncthreads();
     if (tid == 0) {
@@ -683,80 +686,26 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     }
 }
 
-// The keep mask of one pass (8 192 reads, 128 words) from the kept lists: the pass's slot groups -> the notes of their
-// wave-slots (inv[] -> kpw[]: where the wave-slot's kept records are listed, how many) -> their slots (kept_list[]) ->
-// their read indices inside the pass (idx16[]); bits are gathered in LDS and every word is written once.  ONE WAVE per
-// pass: the work is a chain of five dependent trips to memory over a few hundred items, so what matters is how many
-// passes a compute unit has in flight (a first form with four waves per pass and barriers between its phases: 0.056 ms).
-static constexpr uint32_t kPmTileGroups = 384;  // slot groups of a pass: 8192 / 64 + at most 256 partial ones
-__global__ __launch_bounds__(64) void k_pm_tiles(const uint32_t* __restrict__ used64, const uint32_t* __restrict__ inv,
-                                                 const uint2* __restrict__ kpw, const uint32_t* __restrict__ kept_list,
-                                                 const uint16_t* __restrict__ idx16, uint32_t s64, uint32_t n,
-                                                 unsigned long long* __restrict__ mask) {
-    __shared__ uint32_t s_m[256];                   // the pass's 128 mask words, as halves
-    __shared__ uint32_t s_pos[kPmTileGroups];       // per slot group: where its kept records are listed
-    __shared__ uint32_t s_pref[kPmTileGroups + 1];  // ... and how many kept records the groups before it have
-    const uint32_t P = blockIdx.x, lane = threadIdx.x;
-    const uint32_t u = min(used64[P], kPmTileGroups);
-    constexpr int kR = kPmTileGroups / 64;
-    uint32_t note[kR];
-    uint2 kp[kR];
-#pragma unroll
-    for (int r = 0; r < kR; ++r) note[r] = (uint32_t)r * 64u + lane < u ? inv[(size_t)P * s64 + (uint32_t)r * 64u + lane] : 0xFFFFFFFFu;
-#pragma unroll
-    for (int r = 0; r < kR; ++r) kp[r] = note[r] != 0xFFFFFFFFu ? kpw[note[r]] : make_uint2(0u, 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s_m[r * 64 + lane] = 0;
-    uint32_t run = 0;
-#pragma unroll
-    for (int r = 0; r < kR; ++r) {
-        const uint32_t inc = wave_incl_scan_add(kp[r].y);
-        s_pos[r * 64 + lane] = kp[r].x;
-        s_pref[r * 64 + lane] = run + inc - kp[r].y;
-        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    }
-    if (lane == 0) s_pref[kPmTileGroups] = run;
-    __syncthreads();  // (one wave: orders the LDS writes above before the reads below)
-    const uint32_t total = run;
-    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
-        const uint32_t e = e0 + lane;
-        if (e < total) {
-            uint32_t lo = 0, hi = kPmTileGroups;  // last group t with pref[t] <= e (groups without records share their successor's prefix)
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_pref[mid] <= e) lo = mid; else hi = mid;
-            }
-            const uint32_t slot = kept_list[s_pos[lo] + (e - s_pref[lo])];
-            const uint32_t i = idx16[slot];
-            atomicOr(&s_m[(i >> 5) & 255u], 1u << (i & 31u));
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t j = (uint32_t)r * 64u + lane;
-        const uint64_t word = (uint64_t)P * 128u + j;
-        if (word < ((uint64_t)n + 63u) / 64u) mask[word] = (unsigned long long)s_m[2u * j] | ((unsigned long long)s_m[2u * j + 1u] << 32);
-    }
-}
-
 // The listed (chunk, position) groups of every range: the position's `skip` LAST records of that chunk are the ones the
 // quota did not reach, so a wave walks the chunk's sixteen wave-slots backwards, passes over that many matches and
-// keeps the rest (their bits: the tile pass has written every word by now).  grid (ranges, kPmSettleY), four waves per
-// workgroup: a range's groups are dealt to 4 kPmSettleY waves, and a wave takes two groups at a time (all their loads
-// asked for before either is looked at: a group is three dependent trips to memory and little else).
-static constexpr uint32_t kPmSettleY = 32;
-__global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ keys16, const uint16_t* __restrict__ idx16,
+// keeps the rest.  grid (ranges, kPmSettleY), sixteen waves per
+// workgroup: a range's groups (a few dozen at cfg4: 20 000 in all) are dealt to 16 kPmSettleY waves, and a wave takes two
+// groups at a time (all their loads asked for before either is looked at: a group is four dependent trips to memory and
+// little else).  Few, large workgroups: every workgroup ends in one atomic on the kept count, and same-address atomics
+// queue up behind one another (a first form with 32 small workgroups per range: 5 000 of them, 0.07 ms for 0.006 of work).
+static constexpr uint32_t kPmSettleY = 2;
+static constexpr uint32_t kPmSettleWaves = 16;
+__global__ __launch_bounds__(1024) void k_pm_settle(const uint16_t* __restrict__ keys16, const uint16_t* __restrict__ idx16,
                                                    const uint32_t* __restrict__ desc, const uint32_t* __restrict__ Tp,
                                                    uint32_t pitch, const uint32_t* __restrict__ range_start, uint32_t shift,
-                                                   uint32_t s64, const uint2* __restrict__ amb_lists, int lists_by_records,
+                                                   uint32_t stride, const uint2* __restrict__ amb_lists, int lists_by_records,
                                                    const uint32_t* __restrict__ amb_count,
                                                    unsigned long long* __restrict__ mask,
                                                    unsigned long long* __restrict__ kept_total) {
     __shared__ uint32_t s_kept;
     const uint32_t range = blockIdx.x, width = 1u << shift;
     const uint32_t namb = amb_count[range];
-    if (blockIdx.y * 4u >= namb) return;  // uniform
+    if (blockIdx.y * kPmSettleWaves >= namb) return;  // uniform
     if (threadIdx.x == 0) s_kept = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -767,36 +716,39 @@ __global__ __launch_bounds__(256) void k_pm_settle(const uint16_t* __restrict__ 
     const uint64_t gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // lanes above this one
     uint32_t kept = 0;
     constexpr int kSteps = 16, kE = 2;
-    const uint32_t stride_k = 4u * gridDim.y;
-    for (uint32_t k0 = blockIdx.y * 4u + w; k0 < namb; k0 += kE * stride_k) {
-        uint32_t key[kE][kSteps], slot0[kE][kSteps], nv[kE][kSteps], p[kE], skip[kE];
+    const uint32_t stride_k = kPmSettleWaves * gridDim.y;
+    for (uint32_t k0 = blockIdx.y * kPmSettleWaves + w; k0 < namb; k0 += kE * stride_k) {
+        uint32_t key[kE][kSteps], dscv[kE] /* lane t < 16: the descriptor of the chunk's wave-slot t */, p[kE], skip[kE], c_of[kE];
 #pragma unroll
         for (int x = 0; x < kE; ++x) {
             const uint32_t k = k0 + (uint32_t)x * stride_k;
             const uint2 ent = k < namb ? amb[k] : make_uint2(0u, 0u);
-            const uint32_t c = ent.x >> 15;
+            c_of[x] = ent.x >> 15;
             p[x] = k < namb ? ent.x & 0x7FFFu : 0xFFFFFFFFu;  // (no 16-bit position equals it)
             skip[x] = ent.y;  // matches still to be passed over, from the chunk's end
+            const uint32_t ws = 16u * c_of[x] + (lane & 15u);
+            dscv[x] = ws < n_ws ? desc[g0 + ws] : 0u;
+        }
+#pragma unroll
+        for (int x = 0; x < kE; ++x) {
 #pragma unroll
             for (int t = 0; t < kSteps; ++t) {
-                const uint32_t ws = 16u * c + (uint32_t)t;
-                const PmSlot at = pm_unpack(ws < n_ws ? desc[g0 + ws] : 0u, ws < n_ws);
-                slot0[x][t] = at.slot0;
-                nv[x][t] = at.nv;
-                key[x][t] = keys16[at.slot0 + lane];
+                const uint32_t dsc = (uint32_t)__builtin_amdgcn_readlane((int)dscv[x], t);
+                key[x][t] = keys16[pm_unpack<false>(dsc, 16u * c_of[x] + (uint32_t)t < n_ws, stride).slot0 + lane];
             }
         }
 #pragma unroll
         for (int x = 0; x < kE; ++x) {
 #pragma unroll
             for (int t = kSteps - 1; t >= 0; --t) {
-                const bool member = lane < nv[x][t] && key[x][t] == p[x];
+                const uint32_t dsc = (uint32_t)__builtin_amdgcn_readlane((int)dscv[x], t);
+                const PmSlot at = pm_unpack<false>(dsc, 16u * c_of[x] + (uint32_t)t < n_ws, stride);
+                const bool member = lane < at.nv && key[x][t] == p[x];
                 const uint64_t m = __ballot(member);
                 if (m == 0) continue;
                 const uint32_t above = (uint32_t)__popcll(m & gt_mask);  // matches after this one in the step
                 if (member && above >= skip[x]) {
-                    const uint32_t pass = (slot0[x][t] >> 6) / s64;
-                    const uint32_t v = pass * (uint32_t)kPmPass + idx16[slot0[x][t] + lane];
+                    const uint32_t v = at.pass * (uint32_t)kPmPass + idx16[at.slot0 + lane];
                     atomicOr(&mask[v >> 6], 1ull << (v & 63u));
                 }
                 const uint32_t in_step = (uint32_t)__popcll(m);
@@ -819,7 +771,7 @@ uint32_t pm_work_words() { return kPmWorkWords; }
 uint32_t pm_exc_slots(uint32_t n) { return pm_pitch(n) * kPmWaves * kPmExcPerWave + kNuOverflow; }  // the exception list's slots: 128 per wave and pass, and the overflow region
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
-                            uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab, uint32_t* used64,
+                            uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
                             uint32_t* work, uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg, uint32_t* exc,
                             uint32_t exc_cap, uint32_t* exc_cnt) {
     const uint32_t pitch = pm_pitch(n);
@@ -827,16 +779,16 @@ void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32
     (void)hipFuncSetAttribute((const void*)k_pm_prepare_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPmSortLds);
     hipLaunchKernelGGL(k_pm_prepare_sort, dim3(pitch / kPmPassesPerWg), dim3(kPmThreads), kPmSortLds, st, starts, ends, n,
                        d_roff, d_poff, n_contigs, shift, pm_stride(ltot, shift), keys16, idx16, cnt_tab, lst_tab, pitch,
-                       used64, work, stats, zero_mask, exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
+                       work, stats, zero_mask, exc != nullptr ? ell_reg : 0u, exc, exc_cap, exc_cnt);
     if (exc != nullptr && ell_reg != 0u)
         hipLaunchKernelGGL(k_nu_count_groups, dim3(32), dim3(256), 0, st, exc_cnt, pitch * kPmWaves, stats);
 }
 void launch_pm_descr(hipStream_t st, const uint32_t* Tp, const uint32_t* lstw, uint32_t n, uint32_t ltot, uint32_t shift,
-                     uint32_t* desc, uint32_t* inv, uint32_t* work, uint32_t* range_start, uint32_t* max_load) {
+                     uint32_t* desc, uint32_t* work, uint32_t* range_start, uint32_t* max_load) {
     const uint32_t pitch = pm_pitch(n), n_ranges = (ltot >> shift) + 1u;
     const uint32_t s64 = pm_stride(ltot, shift) / 64u;
-    hipLaunchKernelGGL(k_pm_descr, dim3(n_ranges), dim3(256), 0, st, Tp, lstw, pitch, s64, pitch * s64,
-                       desc, inv, work, range_start, max_load);
+    hipLaunchKernelGGL(k_pm_descr, dim3(n_ranges, kPmDescrY), dim3(256), 0, st, Tp, lstw, pitch, pitch * s64, desc, work);
+    hipLaunchKernelGGL(k_pm_range_table, dim3(1), dim3(256), 0, st, work, range_start, max_load);
 }
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
                        const uint32_t* range_start, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions) {
@@ -845,34 +797,28 @@ void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* d
     const size_t lds = (width + width / 32 + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_offsets, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_pm_offsets, dim3(n_ranges), dim3(1024), lds, st, keys16, desc, Tp, pm_pitch(n), range_start, shift,
-                       ltot, boff, empty_positions);
+                       pm_stride(ltot, shift), ltot, boff, empty_positions);
 }
-// The ranking: walk, tile pass, settling -- three launches, in this order.
-void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
-                    const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
-                    uint32_t* kept_list, void* kpw, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                    uint32_t* amb_count, const uint32_t* ev_sev, const uint32_t* ev_lastns, const uint64_t* d_poff,
-                    uint32_t n_contigs, uint32_t ell) {
+// The ranking: walk, then the settling of the groups it listed -- two launches, in this order.
+void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,
+                    uint32_t n, const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
+                    const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total, void* scratch,
+                    bool scratch_by_records, uint32_t* amb_count, const uint32_t* ev_sev, const uint32_t* ev_lastns,
+                    const uint64_t* d_poff, uint32_t n_contigs, uint32_t ell) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
     const EvQuota evq{ev_sev, ev_lastns, d_poff, n_contigs, ell};
     const size_t lds = (((size_t)1 << shift) + 1) * sizeof(uint32_t);
     (void)hipFuncSetAttribute((const void*)k_pm_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pm_walk, dim3(n_ranges), dim3(1024), lds, st, keys16, desc, Tp, pm_pitch(n), range_start, shift, ltot,
-                       boff, selend, evq, kept_list, (uint2*)kpw, (uint2*)scratch, scratch_by_records ? 1 : 0, amb_count,
-                       kept_total);
-}
-void launch_pm_tiles(hipStream_t st, const uint16_t* idx16, const uint32_t* inv, const uint32_t* used64, uint32_t n,
-                     uint32_t shift, uint32_t ltot, const uint32_t* kept_list, const void* kpw, unsigned long long* mask) {
-    const uint32_t s64 = pm_stride(ltot, shift) / 64u;
-    hipLaunchKernelGGL(k_pm_tiles, dim3((n + (uint32_t)kPmPass - 1u) / (uint32_t)kPmPass), dim3(64), 0, st, used64, inv,
-                       (const uint2*)kpw, kept_list, idx16, s64, n, mask);
+    hipLaunchKernelGGL(k_pm_walk, dim3(n_ranges), dim3(1024), lds, st, keys16, idx16, desc, Tp, pm_pitch(n), range_start, shift,
+                       pm_stride(ltot, shift), ltot, boff, selend, evq, mask, (uint2*)scratch, scratch_by_records ? 1 : 0,
+                       amb_count, kept_total);
 }
 void launch_pm_settle(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,
                       uint32_t n, const uint32_t* range_start, uint32_t shift, uint32_t ltot, const void* scratch,
                       bool scratch_by_records, const uint32_t* amb_count, unsigned long long* mask,
                       unsigned long long* kept_total) {
     const uint32_t n_ranges = (ltot >> shift) + 1;
-    const uint32_t s64 = pm_stride(ltot, shift) / 64u;
-    hipLaunchKernelGGL(k_pm_settle, dim3(n_ranges, kPmSettleY), dim3(256), 0, st, keys16, idx16, desc, Tp, pm_pitch(n),
-                       range_start, shift, s64, (const uint2*)scratch, scratch_by_records ? 1 : 0, amb_count, mask, kept_total);
+    hipLaunchKernelGGL(k_pm_settle, dim3(n_ranges, kPmSettleY), dim3(64 * kPmSettleWaves), 0, st, keys16, idx16, desc, Tp, pm_pitch(n),
+                       range_start, shift, pm_stride(ltot, shift), (const uint2*)scratch, scratch_by_records ? 1 : 0, amb_count,
+                       mask, kept_total);
 }

@@ -93,10 +93,9 @@ struct qmcp_hip_ctx {
     DevBuf f_starts, f_ends, f_map, f_words, f_mask;  // filter -> solve pipeline
     DevBuf ranges;     // range-ranked path: 257 range starts + heaviest load
     DevBuf rankamb;    // range-ranked path: per-range lists of quota-crossing groups settled after the walk
-    // pass-major form (kernels/pass_major.inc.hip): one descriptor word per wave-slot and the inverse map, where every
-    // wave-slot's kept records were listed, slot groups used per pass, k_pm_descr's working words + the ranges' counts of
-    // quota-crossing groups
-    DevBuf pm_desc, pm_inv, pm_kpw, pm_used, pm_work, pm_list;
+    // pass-major form (kernels/pass_major.inc.hip): one descriptor word per wave-slot; k_pm_descr's working words + the
+    // ranges' counts of quota-crossing groups
+    DevBuf pm_desc, pm_work;
     // near-uniform route (kernels/near_uniform.inc.hip): the dominant span of the last call that took it -- the next
     // call's head filters on it at once -- and the route's buffers
     uint32_t nu_ell = 0;
@@ -611,20 +610,6 @@ bool pm_route_ok(const uint64_t* roff, const Problem& pr, uint32_t shift) {
     }
     return slots <= 1.3 * ((double)n / 64.0);
 }
-// Padded flat positions of a call at most: every read, and up to 63 slots of padding for every (pass, range) pair that
-// can hold a slice -- a contig's passes times the ranges the contig spans.
-size_t pm_flat_bound(const uint64_t* roff, const Problem& pr, uint32_t shift) {
-    size_t pad = 0;
-    for (uint32_t k = 0; k < pr.n_contigs; ++k) {
-        if (roff[k + 1] == roff[k] || pr.poff[k + 1] == pr.poff[k]) continue;
-        const size_t ranges = (size_t)(((pr.poff[k + 1] - 1) >> shift) - (pr.poff[k] >> shift) + 1);
-        const size_t passes = (size_t)((roff[k + 1] - 1) / qmcp::pm_pass() - roff[k] / qmcp::pm_pass() + 1);
-        pad += 63 * ranges * passes;
-    }
-    const size_t all = qmcp::pm_slots((uint32_t)pr.n, (uint32_t)pr.ltot, shift);
-    return std::min((size_t)pr.n + pad, all);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // One solve = enqueue_head (everything that depends only on the reads' start positions: prepare, the
 // range partition and the bucket offsets; nothing in it waits for the device on large calls) +
@@ -675,11 +660,6 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         if (may_pm) {
             const size_t groups = pm_bytes / (64 * sizeof(uint16_t));
             TRY(ensure(c, c->pm_desc, groups * sizeof(uint32_t)));
-            TRY(ensure(c, c->pm_inv, groups * sizeof(uint32_t)));
-            TRY(ensure(c, c->pm_kpw, (groups + 8192) * 2 * sizeof(uint32_t)));   // (+ 16 notes per range: every wave's stretch is whole chunks)
-            // the kept lists: a stretch per range and wave inside the range's padded flat span (+ 1024 per range)
-            TRY(ensure(c, c->pm_list, (pm_flat_bound(roff, pr, qmcp::range_shift_for(ltot)) + 1024 * 258) * sizeof(uint32_t)));
-            TRY(ensure(c, c->pm_used, (size_t)qmcp::pm_pitch(n) * sizeof(uint32_t)));
             TRY(ensure(c, c->pm_work, 1024 * sizeof(uint32_t)));
         }
         TRY(ensure(c, c->vals[0], (size_t)n * sizeof(uint32_t)));
@@ -861,7 +841,7 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
         KernelSpan sp(c, "k_pm_prepare_sort", st);
         qmcp::launch_pm_prepare_sort(st, run.d_starts, run.d_ends, n, (const uint64_t*)c->roff.p, (const uint64_t*)c->poff.p,
                                      n_contigs, run.range_shift, ltot, (uint16_t*)c->keys[0].p, (uint16_t*)c->keys[1].p,
-                                     (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p, (uint32_t*)c->pm_used.p,
+                                     (uint32_t*)c->hist2.p, (uint32_t*)c->hist.p,
                                      (uint32_t*)c->pm_work.p, d_stats, (unsigned long long*)run.d_mask, filter,
                                      filter ? (uint32_t*)c->nu_exc.p : nullptr, nu_cap_for(n),
                                      filter ? qmcp::nu_exc_counts((uint32_t*)c->nu_exc.p, nu_cap_for(n)) : nullptr);
@@ -874,9 +854,9 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
                                     (uint32_t*)c->spine2.p, true);
     }
     {
-        KernelSpan sp(c, "k_pm_descr", st);
+        KernelSpan sp(c, "k_pm_descr + k_pm_range_table", st);
         qmcp::launch_pm_descr(st, (const uint32_t*)c->hist2.p, (const uint32_t*)c->hist.p, n, ltot, run.range_shift,
-                              (uint32_t*)c->pm_desc.p, (uint32_t*)c->pm_inv.p, (uint32_t*)c->pm_work.p, d_range_start, d_max_load);
+                              (uint32_t*)c->pm_desc.p, (uint32_t*)c->pm_work.p, d_range_start, d_max_load);
     }
     HIP_TRY(hipEventRecord(c->ev_fork, st));  // statistics and heaviest load are final here
     {
@@ -889,7 +869,7 @@ int queue_pm_head(qmcp_hip_ctx* c, hipStream_t st, uint32_t filter) {
     return QMCP_OK;
 }
 
-// The ranking of the pass-major form on `st`: the ordered walk, the tile pass, the settling of quota-crossing groups.
+// The ranking of the pass-major form on `st`: the ordered walk, then the settling of the quota-crossing groups it listed.
 void queue_pm_rank(qmcp_hip_ctx* c, hipStream_t st, const uint32_t* ev_sev, const uint32_t* ev_lastns, uint32_t ell) {
     SolveRun& run = c->run;
     const uint32_t n = (uint32_t)run.pr.n, ltot = (uint32_t)run.pr.ltot;
@@ -899,19 +879,13 @@ void queue_pm_rank(qmcp_hip_ctx* c, hipStream_t st, const uint32_t* ev_sev, cons
     const uint32_t* desc = (const uint32_t*)c->pm_desc.p;
     const uint32_t* Tp = (const uint32_t*)c->hist2.p;
     const uint32_t* range_start = (const uint32_t*)c->ranges.p;
-    uint32_t* kept_list = (uint32_t*)c->pm_list.p;
     uint32_t* amb_count = (uint32_t*)c->pm_work.p + 512;
     unsigned long long* kept_total = (unsigned long long*)c->scalars.p;
     {
         KernelSpan sp(c, "k_pm_walk", st);
-        qmcp::launch_pm_walk(st, keys16, desc, Tp, n, range_start, run.range_shift, ltot, (const uint32_t*)c->boff.p,
-                             (const uint32_t*)c->selend.p, kept_list, c->pm_kpw.p, kept_total, c->rankamb.p, by_records,
+        qmcp::launch_pm_walk(st, keys16, idx16, desc, Tp, n, range_start, run.range_shift, ltot, (const uint32_t*)c->boff.p,
+                             (const uint32_t*)c->selend.p, (unsigned long long*)run.d_mask, kept_total, c->rankamb.p, by_records,
                              amb_count, ev_sev, ev_lastns, (const uint64_t*)c->poff.p, run.n_contigs, ell);
-    }
-    {
-        KernelSpan sp(c, "k_pm_tiles", st);
-        qmcp::launch_pm_tiles(st, idx16, (const uint32_t*)c->pm_inv.p, (const uint32_t*)c->pm_used.p, n, run.range_shift, ltot,
-                              kept_list, c->pm_kpw.p, (unsigned long long*)run.d_mask);
     }
     KernelSpan sp(c, "k_pm_settle", st);
     qmcp::launch_pm_settle(st, keys16, idx16, desc, Tp, n, range_start, run.range_shift, ltot, c->rankamb.p, by_records,
@@ -1682,7 +1656,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_desc, &c->pm_inv, &c->pm_kpw, &c->pm_used, &c->pm_work, &c->pm_list, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_desc, &c->pm_work, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -192,27 +192,25 @@ uint32_t pm_work_words();          // words of k_pm_descr's working buffer
 void launch_pm_prepare_sort(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n,
                             const uint64_t* d_roff, const uint64_t* d_poff, uint32_t n_contigs, uint32_t shift, uint32_t ltot,
                             uint16_t* keys16, uint16_t* idx16, uint32_t* cnt_tab, uint32_t* lst_tab,
-                            uint32_t* used64 /* pm_pitch(n) words */, uint32_t* work /* pm_work_words() */,
+                            uint32_t* work /* pm_work_words() */,
                             uint32_t* stats, unsigned long long* zero_mask, uint32_t ell_reg = 0, uint32_t* exc = nullptr,
                             uint32_t exc_cap = 0, uint32_t* exc_cnt = nullptr);
 uint32_t pm_exc_slots(uint32_t n);  // slots of the near-uniform route's exception list (groups of 64, one per wave and pass)
-// wave-slot descriptors + inverse map (pm_slots / 64 words each), the ranges' true flat starts (257 words), heaviest load
+// wave-slot descriptors (pm_slots / 64 words), the ranges' true flat starts (257 words), heaviest load
 void launch_pm_descr(hipStream_t st, const uint32_t* Tp, const uint32_t* lstw, uint32_t n, uint32_t ltot, uint32_t shift,
-                     uint32_t* desc, uint32_t* inv, uint32_t* work, uint32_t* range_start, uint32_t* max_load);
+                     uint32_t* desc, uint32_t* work, uint32_t* range_start, uint32_t* max_load);
 void launch_pm_offsets(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
                        const uint32_t* range_start, uint32_t shift, uint32_t ltot, uint32_t* boff, uint32_t* empty_positions);
-// the ranking: ordered walk (kept lists), tile pass (every mask word written once), settling of quota-crossing groups --
-// three launches, in this order on one stream.  kept_list: n words; kpw: pm_slots / 64 x 8 bytes; amb_count: 256 words
-void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint32_t* desc, const uint32_t* Tp, uint32_t n,
-                    const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff, const uint32_t* selend,
-                    uint32_t* kept_list, void* kpw, unsigned long long* kept_total, void* scratch, bool scratch_by_records,
-                    uint32_t* amb_count,
+// the ranking: ordered walk (kept reads marked 64 at a time), then the settling of the quota-crossing groups it listed --
+// two launches, in this order on one stream.  amb_count: 256 words
+void launch_pm_walk(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,
+                    uint32_t n, const uint32_t* range_start, uint32_t shift, uint32_t ltot, const uint32_t* boff,
+                    const uint32_t* selend, unsigned long long* mask, unsigned long long* kept_total, void* scratch,
+                    bool scratch_by_records, uint32_t* amb_count,
                     // quotas straight from the event-driven sweep's output (whole contigs, no stretch table), instead
                     // of selend[] - boff[]: the changed blocks' kept counts, the last changed block per block
                     const uint32_t* ev_sev = nullptr, const uint32_t* ev_lastns = nullptr,
                     const uint64_t* d_poff = nullptr, uint32_t n_contigs = 0, uint32_t ell = 0);
-void launch_pm_tiles(hipStream_t st, const uint16_t* idx16, const uint32_t* inv, const uint32_t* used64, uint32_t n,
-                     uint32_t shift, uint32_t ltot, const uint32_t* kept_list, const void* kpw, unsigned long long* mask);
 void launch_pm_settle(hipStream_t st, const uint16_t* keys16, const uint16_t* idx16, const uint32_t* desc, const uint32_t* Tp,
                       uint32_t n, const uint32_t* range_start, uint32_t shift, uint32_t ltot, const void* scratch,
                       bool scratch_by_records, const uint32_t* amb_count, unsigned long long* mask,

@@ -1,7 +1,7 @@
 """CPU model of the pass-major layout (tests/pass_major_model.py, round 4 form: slices padded to whole groups of 64
-slots, one descriptor word per wave-slot, kept lists + tile pass): the producer's slots and tables, the scanned table,
-the descriptors and their inverse, the three consumers -- every index in bounds, every range's records recovered in
-read-index order, and the keep mask of walk + tiles + settle equal to "the S(p) lowest read indices of every start
+slots, one descriptor word per wave-slot): the producer's slots and tables, the scanned table,
+the descriptors, the three consumers -- every index in bounds, every range's records recovered in
+read-index order, and the keep mask of walk + settle equal to "the S(p) lowest read indices of every start
 position p" for random quotas -- on ragged inputs (last pass partial, ranges straddling contig borders, empty ranges
 and empty slices, one range holding everything, slices of a few records)."""
 import numpy as np
@@ -61,21 +61,15 @@ def test_layout_round_trip_bounds_and_mask(lengths, counts, shift):
     stride = pm.stride_for(n_ranges)
     Tp = pm.scan_table(cntp)
     assert Tp.size == 256 * pitch + 1 and int(Tp[-1]) % 64 == 0 and int(Tp[-1]) >= n
-    desc, inv, range_start, used64 = pm.descriptors(Tp, lstw, n, n_ranges)
+    desc, range_start = pm.descriptors(Tp, lstw, n, n_ranges)
     assert int(range_start[-1]) == n
-    # the slot-group <-> wave-slot maps are inverse to each other, and a pass's groups are used from 0 on
-    assert np.unique(inv[inv != 0xFFFFFFFF]).size == desc.size     # every wave-slot has a note of its own
-    for P in range(pitch):
-        s64 = stride // 64
-        assert not (inv[P * s64:P * s64 + int(used64[P])] == 0xFFFFFFFF).any()
-        assert (inv[P * s64 + int(used64[P]):(P + 1) * s64] == 0xFFFFFFFF).all()
     # random quotas: 0, 1, a few, everything
     width = 1 << shift
     quota = rng.choice([0, 0, 1, 1, 2, 5, 1 << 20], size=ltot + width)
     seen = np.zeros(n, bool)
     mask = np.zeros(n, bool)
     kept_total = 0
-    L_all, kpw_all, amb_all = {}, {}, {}
+    amb_all = {}
     for d in range(n_ranges):
         g0, n_ws = pm.range_wave_slots(Tp, pitch, d)
         true_count = int(range_start[d + 1]) - int(range_start[d])
@@ -85,10 +79,8 @@ def test_layout_round_trip_bounds_and_mask(lengths, counts, shift):
         # every record of the range, in read-index order, through the descriptors
         reads = []
         for ws in range(n_ws):
-            dsc = int(desc[g0 + ws])
-            slot0, nv = (dsc >> 6) * 64, (dsc & 63) + 1
-            assert slot0 + nv <= pitch * stride
-            P = slot0 // stride
+            slot0, nv, P = pm.unpack(desc[g0 + ws], stride)
+            assert slot0 + nv <= pitch * stride and slot0 // stride == P
             r = P * pm.PASS + idx16[slot0:slot0 + nv].astype(np.int64)
             assert idx16[slot0:slot0 + nv].max() < pm.PASS
             reads.append(r)
@@ -98,18 +90,15 @@ def test_layout_round_trip_bounds_and_mask(lengths, counts, shift):
         assert not seen[reads].any()
         seen[reads] = True
         # bucket counts
-        hist = pm.offsets(keys16, desc, Tp, pitch, d, shift)
+        hist = pm.offsets(keys16, desc, Tp, pitch, d, shift, stride)
         assert np.array_equal(hist, np.bincount((gs[reads] & (width - 1)).astype(np.int64), minlength=width))
-        # walk + settle (the tile pass below sees every range's list)
-        L, kpw, amb, kept = pm.walk(keys16, desc, Tp, pitch, d, quota[d * width:(d + 1) * width], rng)
+        # walk (settled below)
+        amb, kept = pm.walk(keys16, idx16, desc, Tp, pitch, d, quota[d * width:(d + 1) * width], stride, n, mask, rng)
         kept_total += kept
-        L_all.update(L)
-        kpw_all.update(kpw)
         amb_all[d] = amb
     assert seen.all()
-    mask = pm.tiles(L_all, kpw_all, inv, idx16, used64, n, n_ranges)
     for d, amb in amb_all.items():
-        kept_total += pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, n_ranges, mask)
+        kept_total += pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, stride, mask)
     want = _expected_mask(gs, lambda p: quota[p])
     assert np.array_equal(mask, want) and kept_total == int(want.sum())
 
@@ -125,17 +114,17 @@ def test_skewed_passes_with_long_and_empty_slices():
     keys16, idx16, cntp, lstw = pm.producer(gs, 10, n_ranges)
     pitch = pm.pitch_for(n)
     Tp = pm.scan_table(cntp)
-    desc, inv, range_start, used64 = pm.descriptors(Tp, lstw, n, n_ranges)
+    desc, range_start = pm.descriptors(Tp, lstw, n, n_ranges)
+    stride = pm.stride_for(n_ranges)
     quota = rng.integers(0, 12, size=ltot + 1024)
-    L_all, kpw_all, ambs = {}, {}, {}
+    mask = np.zeros(n, bool)
+    ambs = {}
     for d in range(n_ranges):
         g0, n_ws = pm.range_wave_slots(Tp, pitch, d)
         if n_ws == 0:
             continue
-        L, kpw, amb, _ = pm.walk(keys16, desc, Tp, pitch, d, quota[d * 1024:(d + 1) * 1024], rng)
-        L_all.update(L); kpw_all.update(kpw); ambs[d] = amb
+        ambs[d], _ = pm.walk(keys16, idx16, desc, Tp, pitch, d, quota[d * 1024:(d + 1) * 1024], stride, n, mask, rng)
     assert sum(len(a) for a in ambs.values()) > 0        # the case is meant to produce quota-crossing groups
-    mask = pm.tiles(L_all, kpw_all, inv, idx16, used64, n, n_ranges)
     for d, amb in ambs.items():
-        pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, n_ranges, mask)
+        pm.settle(amb, keys16, idx16, desc, Tp, pitch, d, n, stride, mask)
     assert np.array_equal(mask, _expected_mask(gs, lambda p: quota[p]))

@@ -19,7 +19,7 @@ def assembly(keep=False):
     return open(OUT).read()
 
 
-RING = ["v%d" % i for i in range(96, 113)]   # k_pm_walk's ring registers: hand-written assembly only
+RING = ["v%d" % i for i in range(96, 120)]   # k_pm_walk's ring registers: hand-written assembly only
 
 
 def hazards(asm, name, ring_only_in_asm=False):
