@@ -230,25 +230,39 @@ __global__ __launch_bounds__(kPmThreads, QMCP_PM_MIN_WAVES) void k_pm_prepare_so
             }
         }
         __syncthreads();
-        // out, slice by slice: wave w takes the digits w, w + 8, ...; two records per lane and store (a dword of two
-        // positions, a dword of two indices: slices begin at multiples of 64 slots, so every store is aligned)
+        // out, slice by slice: wave w takes the digits w, w + 8, ..., two at a time -- one per half-wave --, four records
+        // per lane and store (8 bytes of positions, 8 of indices: slices begin at multiples of 64 slots, so every store is
+        // aligned and a half-wave's store is one 256-byte run)
         {
             const uint32_t my_d = (uint32_t)w + 8u * ((uint32_t)lane & 31u);
             const uint32_t my_tot = lane < 32 ? s_tabl[g * 256 + my_d] >> 16 : 0u;
             const uint32_t my_gb = s_gbase[my_d], my_pb = s_pbase[my_d];
+            const bool upper = lane >= 32;
+            const uint32_t hl = (uint32_t)lane & 31u;
             uint64_t todo = __ballot(my_tot != 0u);
             while (todo != 0ull) {  // uniform
-                const int l = __builtin_ctzll(todo);
+                const int l0 = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)my_tot, l);
-                const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)my_gb, l);
-                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)my_pb, l);
+                int l1 = l0;
+                bool two = false;
+                if (todo != 0ull) { l1 = __builtin_ctzll(todo); todo &= todo - 1ull; two = true; }
+                const uint32_t cnt0 = (uint32_t)__builtin_amdgcn_readlane((int)my_tot, l0);
+                const uint32_t cnt1 = two ? (uint32_t)__builtin_amdgcn_readlane((int)my_tot, l1) : 0u;
+                const uint32_t cnt = upper ? cnt1 : cnt0;
+                const uint32_t gb = upper ? (uint32_t)__builtin_amdgcn_readlane((int)my_gb, l1) : (uint32_t)__builtin_amdgcn_readlane((int)my_gb, l0);
+                const uint32_t pb = upper ? (uint32_t)__builtin_amdgcn_readlane((int)my_pb, l1) : (uint32_t)__builtin_amdgcn_readlane((int)my_pb, l0);
                 const size_t out0 = (size_t)P * stride + pb;
-                for (uint32_t j = 2u * (uint32_t)lane; j < cnt; j += 128u) {
-                    const uint32_t v0 = s_stage[gb + j];
-                    const uint32_t v1 = j + 1 < cnt ? s_stage[gb + j + 1] : 0u;
-                    *reinterpret_cast<uint32_t*>(keys16 + out0 + j) = (v0 & 0xFFFFu) | (v1 << 16);
-                    *reinterpret_cast<uint32_t*>(idx16 + out0 + j) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+                const uint32_t most = max(cnt0, cnt1);
+                for (uint32_t j0 = 0; j0 < most; j0 += 128u) {  // uniform
+                    const uint32_t j = j0 + 4u * hl;
+                    if (j < cnt) {
+                        const uint32_t v0 = s_stage[gb + j];
+                        const uint32_t v1 = j + 1 < cnt ? s_stage[gb + j + 1] : 0u;
+                        const uint32_t v2 = j + 2 < cnt ? s_stage[gb + j + 2] : 0u;
+                        const uint32_t v3 = j + 3 < cnt ? s_stage[gb + j + 3] : 0u;
+                        *reinterpret_cast<uint2*>(keys16 + out0 + j) = make_uint2((v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16));
+                        *reinterpret_cast<uint2*>(idx16 + out0 + j) = make_uint2((v0 >> 16) | (v1 & 0xFFFF0000u), (v2 >> 16) | (v3 & 0xFFFF0000u));
+                    }
                 }
             }
         }
