@@ -99,6 +99,10 @@ struct qmcp_hip_ctx {
     // near-uniform route (kernels/near_uniform.inc.hip): the dominant span of the last call that took it -- the next
     // call's head filters on it at once -- and the route's buffers
     uint32_t nu_ell = 0;
+    // a call of this shape did not settle within its budget of rounds (or met a run the replay does not model): the next
+    // one goes straight to the mixed-span route instead of burning the budget again
+    uint64_t nu_failed_n = 0, nu_failed_ltot = 0;
+    uint32_t nu_failed_ell = 0, nu_failed_M = 0;
     DevBuf nu_exc, nu_nadj, nu_ce, nu_state, nu_sus, nu_ckpt;
     uint32_t* h_nu = nullptr;       // pinned landing zone of the route's state words (8)
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
@@ -580,6 +584,13 @@ int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_c
     TRY(ensure(c, c->nu_ce, ((size_t)ltot + 4) * sizeof(uint32_t)));
     TRY(ensure(c, c->nu_state, 64 + (size_t)n_contigs * 20 + 16));
     TRY(ensure(c, c->nu_sus, (size_t)kNuSuspects * 8));
+    if (c->nu_ell != 0) {
+        // (the route's sweep scratch depends on the span: known from the last call that took the route, so a second call
+        //  of the shape grows nothing after its first launch)
+        TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, c->nu_ell, n_contigs + 768)));
+        TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, c->nu_ell, n_contigs + 768)));
+        TRY(ensure(c, c->nu_ckpt, qmcp::sweep_ev_ckpt_bytes(ltot, c->nu_ell, n_contigs + 768)));
+    }
     TRY(ensure(c, c->spine, (size_t)(qmcp::scan_spine_entries(ltot + 2) + 1) * sizeof(uint32_t) + 16));
     if (!c->h_nu) HIP_TRY(hipHostMalloc((void**)&c->h_nu, 8 * sizeof(uint32_t), hipHostMallocDefault));
     return QMCP_OK;
@@ -903,6 +914,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const Problem& pr = run.pr;
     qmcp_hip_stats& local = run.local;
     const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot, n_contigs = run.n_contigs, M = run.M;
+    local.near_uniform_giveup = QMCP_NU_GIVEUP_NOT_TRIED;
     if (const char* e = std::getenv("QMCP_HIP_NEAR"))
         if (e[0] == '0') return QMCP_OK;
     const uint32_t ell = max_span;
@@ -923,13 +935,18 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
         if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;
     }
+    if (c->nu_failed_n == run.n64 && c->nu_failed_ltot == pr.ltot && c->nu_failed_ell == ell && c->nu_failed_M == M) {
+        local.near_uniform_giveup = QMCP_NU_GIVEUP_REMEMBERED;
+        c->nu_ell = 0;
+        return QMCP_OK;
+    }
     hipStream_t st = c->stream;
     const uint32_t cap = nu_cap_for(n);
     uint32_t n_exc = 0;
     uint32_t* d_stats = (uint32_t*)c->stats.p;
     if (run.nu_filter == ell) {
         n_exc = c->h_head[5];  // (read back beside the statistics)
-        if (c->h_head[6] != 0) { c->nu_ell = 0; return QMCP_OK; }  // a pass held more exceptions than it can stage
+        if (c->h_head[6] != 0) { c->nu_ell = 0; local.near_uniform_giveup = QMCP_NU_GIVEUP_TOO_MANY; return QMCP_OK; }  // a pass held more exceptions than it can stage
     } else {
         // how many reads have the longest span?  (one pass over the spans; the host waits for the count)
         TRY(ensure_near_uniform(c, n, ltot, n_contigs));
@@ -939,7 +956,13 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         HIP_TRY(hipStreamSynchronize(st));
         n_exc = n - c->h_nu[0];
         if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
-        if (n_exc > n / 10u) { c->nu_ell = 0; return QMCP_OK; }
+        if (n_exc > n / 10u) {
+            // (fewer than nine tenths of the reads have the LONGEST span: either many exceptions, or -- nearly all reads
+            //  shorter than a few -- the dominant span is not the longest: reads lengthened by a deletion)
+            c->nu_ell = 0;
+            local.near_uniform_giveup = n_exc > n - n / 10u ? QMCP_NU_GIVEUP_LONGER_READS : QMCP_NU_GIVEUP_TOO_MANY;
+            return QMCP_OK;
+        }
         // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
         c->nu_ell = ell;
         if (run.pm) TRY(queue_pm_head(c, st, ell));
@@ -949,11 +972,12 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         HIP_TRY(hipMemcpyAsync(c->h_nu + 1, d_stats + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         max_load = c->h_nu[0];
-        if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; return QMCP_OK; }  // (a pass held more than it can stage)
+        if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; local.near_uniform_giveup = QMCP_NU_GIVEUP_TOO_MANY; return QMCP_OK; }  // (a pass held more than it can stage)
     }
     local.near_uniform_exceptions = n_exc;
     if (n_exc == 0 || n_exc > n / 10u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
         if (n_exc > n / 10u) c->nu_ell = 0;
+        local.near_uniform_giveup = n_exc > n / 10u ? QMCP_NU_GIVEUP_TOO_MANY : n_exc == 0 ? QMCP_NU_GIVEUP_NOT_TRIED : QMCP_NU_GIVEUP_HEAVY_RANGE;
         return QMCP_OK;
     }
     // scratch of the event-driven sweep (launch_uniform_sweep)
@@ -1030,7 +1054,14 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     if (settled) rounds = c->h_nu[6] + 1;    // (the rounds that did something, and the one that found nothing left)
     local.near_uniform_rounds = rounds;
     local.near_uniform_selected = c->h_nu[3];
-    if (!settled) return QMCP_OK;
+    if (!settled) {
+        // (the head must not filter on this span again, and the next call of this shape must not burn the budget again)
+        local.near_uniform_giveup = c->h_nu[2] != 0 ? QMCP_NU_GIVEUP_UNMODELLED : QMCP_NU_GIVEUP_BUDGET;
+        c->nu_ell = 0;
+        c->nu_failed_n = run.n64; c->nu_failed_ltot = pr.ltot; c->nu_failed_ell = ell; c->nu_failed_M = M;
+        return QMCP_OK;
+    }
+    local.near_uniform_giveup = QMCP_NU_GIVEUP_NONE;
     HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], st));
     if (run.pm) {
         queue_pm_rank(c, st, nullptr, nullptr, 0);

@@ -207,7 +207,14 @@ int qmcp_hip_solve_device(qmcp_hip_ctx* ctx,
  * few compute units -- run beside the bandwidth-bound stages of the next).  _begin orders the solve
  * after `hip_stream`, enqueues all of it and returns without waiting for the device (it does wait
  * for one 16-byte read-back that picks the kernels; the device keeps working on other contexts
- * meanwhile).  _end waits for the solve and fills `stats`.  One pending solve per context: a second
+ * meanwhile).  That holds for calls whose reads have ONE length (QMCP_PATH_UNIFORM).  A call with other
+ * lengths is decided by what the device finds: on QMCP_PATH_NEAR_UNIFORM _begin waits for the device two to
+ * three times and once more per pair of rounds (each round's outcome decides whether another is queued), on
+ * QMCP_PATH_GENERAL once more where it samples the lengths -- _begin then returns when most of the solve has
+ * RUN, and a pipelined caller gets little overlap out of it (bench.py reports both rates for cfg4 with 1 % of
+ * the reads shortened: other_configs.cfg4_1pct_clipped.pipelined_ms against device_ms).  A context's first call
+ * of a shape may also grow its arena after work is queued (stats.arena_grown_mid_solve), which waits for every
+ * stream of the context; the second call of the shape does not.  _end waits for the solve and fills `stats`.  One pending solve per context: a second
  * _begin, or any other entry point of the same context, before _end fails with QMCP_EINVAL.
  * The reference has no counterpart: its solve is one blocking call (src/app.cpp:132-139). */
 int qmcp_hip_solve_device_begin(qmcp_hip_ctx* ctx,

@@ -61,7 +61,7 @@ def test_cfg5_shape_sparse_multi_contig(pkg, oracle, solver):
 def test_cfg4_full_size_properties(pkg, oracle, solver):
     """configs[3] at full size (100 M reads, 8 contigs, M = 100): size-independent properties --
     validity everywhere (device coverage probes), determinism, contig independence, and exact
-    oracle parity on the first contig"""
+    oracle parity on every contig"""
     pairs, L, M = 6_250_000, 1_000_000, 100
     ss, ee = zip(*[pkg.reads_gen(0, pairs, L, seed=12345 + c) for c in range(8)])
     s, e = np.concatenate(ss), np.concatenate(ee)
@@ -76,8 +76,8 @@ def test_cfg4_full_size_properties(pkg, oracle, solver):
     for c in (0, 5):  # contigs are independent solves
         one = np.unpackbits(solver.solve(ss[c], ee[c], L, M).view(np.uint8), bitorder="little")[:n_c]
         assert np.array_equal(one, bits[c * n_c:(c + 1) * n_c])
-    want0 = np.unpackbits(oracle.solve(ss[0], ee[0], L, M).view(np.uint8), bitorder="little")[:n_c]
-    assert np.array_equal(want0, bits[:n_c])
+    # exact oracle parity on ALL eight contigs (the oracle takes ~14 s for the 10^8 reads)
+    assert np.array_equal(got, oracle.solve(s, e, lengths, M, contig_read_offsets=offs))
     # minimum cardinality on deep uniform data: M reads per read length of genome, per contig
     assert n_kept == int(bits.sum()) and abs(n_kept - 8 * M * L / 150) < 8 * 2 * M
 

@@ -61,6 +61,9 @@ def test_near_uniform_equals_the_oracle(pkg, oracle, solver, lengths, counts, sp
     # the same call again: the head filters on the remembered span at once -- same mask
     again = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(again, want) and solver.last_stats.path == pkg.PATH_NEAR_UNIFORM
+    # ... and nothing of the arena grows after the second call's first launch (the route's sweep scratch is sized with the
+    # remembered span, in the head)
+    assert solver.last_stats.arena_grown_mid_solve == 0 and solver.last_stats.near_uniform_giveup == 0
 
 
 def test_route_switches_between_calls(pkg, oracle, solver):
@@ -94,13 +97,15 @@ def test_gives_way_to_the_mixed_route(pkg, oracle, solver):
     rng = np.random.default_rng(11)
     L = 40_000
     lengths = np.array([L], np.uint32)
-    for kwargs, M, n in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000),
-                         (dict(fraction=0.2, max_clip=30), 100, 330_000),
-                         (dict(fraction=0.01, max_clip=30), 400, 135_000)):     # 1.27 x M
+    # (give-up reasons: include/qmcp_hip.h QMCP_NU_GIVEUP_*: 2 longer reads, 3 too many exceptions, 1 not tried)
+    for kwargs, M, n, why in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000, 2),
+                              (dict(fraction=0.2, max_clip=30), 100, 330_000, 3),
+                              (dict(fraction=0.01, max_clip=30), 400, 135_000, 1)):     # 1.27 x M
         s, e, _ = _contigs(rng, [L], [n], 150, **kwargs)
         got = solver.solve(s, e, lengths, M)
         assert np.array_equal(got, oracle.solve(s, e, lengths, M)), (kwargs, M, solver.last_stats.as_dict())
         assert solver.last_stats.path == pkg.PATH_GENERAL, (kwargs, M, solver.last_stats.as_dict())
+        assert solver.last_stats.near_uniform_giveup == why, (kwargs, solver.last_stats.as_dict())
 
 
 def test_many_wanted_exceptions(pkg, oracle, solver):
