@@ -25,7 +25,7 @@ $(LIBDIR)/qmcp_kernels.o: $(CSRC)/qmcp_kernels.hip $(CSRC)/qmcp_kernels.h $(wild
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/qmcp_api.o: $(CSRC)/qmcp_api.hip $(CSRC)/qmcp_kernels.h include/qmcp_hip.h
+$(LIBDIR)/qmcp_api.o: $(CSRC)/qmcp_api.hip $(wildcard $(CSRC)/api/*.inc.hip) $(CSRC)/qmcp_kernels.h include/qmcp_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

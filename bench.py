@@ -159,17 +159,10 @@ def clipped_configs(pkg, torch, dev, solver, stream, d_starts, d_ends, n_reads, 
                                 "note": "cfg4 with 1 % of the reads shortened by 1...50 bases: near-uniform route (path 3: "
                                         "the one-span sweep over the regular reads, the short ones it is seen to want "
                                         "selected and certified against the next sweep); mixed_route_device_ms is the same "
-                                        "call on the mixed-span event sweep (QMCP_HIP_NEAR=0), same kept set"}
-    prev_near = os.environ.get("QMCP_HIP_NEAR")
-    os.environ["QMCP_HIP_NEAR"] = "0"
-    try:
+                                        "call on the mixed-span event sweep (options.near_uniform = -1), same kept set"}
+    with solver.options(near_uniform=-1):
         st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n_reads, lengths, M, d_m.data_ptr(),
                                  contig_read_offsets=offs, stream=stream)
-    finally:
-        if prev_near is None:
-            del os.environ["QMCP_HIP_NEAR"]
-        else:
-            os.environ["QMCP_HIP_NEAR"] = prev_near
     out["cfg4_1pct_clipped"]["mixed_route_device_ms"] = round(float(st.ms_total), 3)
     out["cfg4_1pct_clipped"]["mixed_route_kept"] = int(st.n_kept)
     del d_s, d_e, d_m

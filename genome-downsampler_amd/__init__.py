@@ -7,6 +7,7 @@ The directory name has a hyphen, so import it with
 There is no CPU fallback anywhere in this package: if the HIP library is missing it raises at
 import, and without a GPU every solver call raises :class:`QmcpError`.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -28,6 +29,7 @@ ABI_SYMBOLS = (
     "qmcp_hip_kernel_times", "qmcp_hip_filter_solve_host", "qmcp_hip_solve_device_begin",
     "qmcp_hip_solve_end", "qmcp_hip_demand_host", "qmcp_hip_solve_host64", "qmcp_hip_multi_create",
     "qmcp_hip_multi_destroy", "qmcp_hip_multi_solve_host", "qmcp_hip_kept_indices_host",
+    "qmcp_hip_default_options", "qmcp_hip_set_options", "qmcp_hip_get_options",
 )
 
 QMCP_OK = 0
@@ -71,6 +73,22 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class Options(C.Structure):
+    """qmcp_hip_options (include/qmcp_hip.h): 0 = the library chooses"""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("pass_major", C.c_int32), ("sweep", C.c_int32), ("cut_points", C.c_int32),
+        ("speculation", C.c_int32), ("speculation_run_in", C.c_uint32), ("near_uniform", C.c_int32),
+        ("near_uniform_rounds", C.c_uint32), ("near_uniform_min_depth", C.c_float), ("near_uniform_debug", C.c_int32),
+        ("force_sort_route", C.c_int32), ("keep_expand", C.c_int32), ("mixed_sweep_in_lds", C.c_int32),
+        ("rank_min_reads", C.c_uint32), ("host_threads", C.c_uint32), ("copy_streams", C.c_uint32),
+        ("host_both_columns", C.c_int32),
+    ]
+
+
+SWEEP_AUTO, SWEEP_FAST, SWEEP_GENERAL, SWEEP_EVENTS = 0, 1, 2, 3
+_SWEEP_NAMES = {None: 0, "auto": 0, "fast": 1, "gen": 2, "general": 2, "ev": 3, "events": 3}
+
+
 if not os.path.exists(HIP_LIB_PATH):
     raise ImportError(
         f"{HIP_LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
@@ -85,6 +103,10 @@ _hip.qmcp_hip_last_error.restype = C.c_char_p
 _hip.qmcp_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 _hip.qmcp_hip_destroy.argtypes = [C.c_void_p]
 _hip.qmcp_hip_destroy.restype = None
+_hip.qmcp_hip_default_options.argtypes = [C.POINTER(Options)]
+_hip.qmcp_hip_default_options.restype = None
+_hip.qmcp_hip_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
+_hip.qmcp_hip_get_options.argtypes = [C.c_void_p, C.POINTER(Options)]
 _hip.qmcp_hip_solve_host.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint64, _u64p, _u32p,
                                      C.c_uint32, C.c_uint32, _u64p, C.POINTER(Stats)]
 _hip.qmcp_hip_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, _u32p,
@@ -281,6 +303,38 @@ class Solver:
                                           C.c_void_p(stream), C.byref(st)))
         self.last_stats = st
         return st
+
+    def get_options(self):
+        o = Options()
+        _check(_hip.qmcp_hip_get_options(self._ctx, C.byref(o)))
+        return o
+
+    def set_options(self, options=None, **fields):
+        """qmcp_hip_set_options: `options` (an Options; default: the library's defaults) with `fields` set on top --
+        e.g. set_options(sweep="ev", cut_points=1); sweep takes "fast" | "gen" | "ev" or a SWEEP_* number"""
+        o = Options()
+        if options is not None:
+            C.memmove(C.byref(o), C.byref(options), C.sizeof(Options))
+        else:
+            _hip.qmcp_hip_default_options(C.byref(o))
+        for k, v in fields.items():
+            if k == "sweep" and not isinstance(v, int):
+                v = _SWEEP_NAMES[v]
+            if not hasattr(o, k) or k == "struct_size":
+                raise AttributeError(f"qmcp_hip_options has no field {k!r}")
+            setattr(o, k, v)
+        o.struct_size = C.sizeof(Options)
+        _check(_hip.qmcp_hip_set_options(self._ctx, C.byref(o)))
+
+    @contextlib.contextmanager
+    def options(self, **fields):
+        """with solver.options(sweep="ev"): ...   -- the fields on top of the current options, restored afterwards"""
+        old = self.get_options()
+        self.set_options(old, **fields)
+        try:
+            yield self
+        finally:
+            self.set_options(old)
 
     def solve_device_begin(self, d_starts, d_ends, n_reads, contig_lengths, max_coverage, d_mask,
                            contig_read_offsets=None, stream=0):

@@ -1,0 +1,178 @@
+// near_uniform_route.inc.hip -- part of qmcp_api.hip (one translation unit).
+// The near-uniform route's half of the tail (kernels/near_uniform.inc.hip).  Called when the call's spans differ.
+// done = true: the keep mask is written (sweep, ranking and the selected exceptions); false: the caller takes the
+// mixed-span route (nothing has touched the mask).  The head's producer may already have filtered on c->nu_ell
+// (run.nu_filter); otherwise the reads are counted first and, if the longest span is the dominant one, the head's
+// stages are queued again with the filter on.
+int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uint32_t max_load, uint32_t* d_iters, bool& done) {
+    done = false;
+    SolveRun& run = c->run;
+    const Problem& pr = run.pr;
+    qmcp_hip_stats& local = run.local;
+    const uint32_t n = (uint32_t)pr.n, ltot = (uint32_t)pr.ltot, n_contigs = run.n_contigs, M = run.M;
+    local.near_uniform_giveup = QMCP_NU_GIVEUP_NOT_TRIED;
+    if (c->opt.near_uniform < 0) return QMCP_OK;
+    const uint32_t ell = max_span;
+    const double depth = (double)n * (double)ell / ((double)ltot * (double)(M ? M : 1));
+    const bool dbg = c->opt.near_uniform_debug != 0;
+    if (dbg) fprintf(stderr, "[near] pm %d may_rank %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
+                     (int)run.may_rank, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
+    double min_depth = kNuMinDepth;
+    if (c->opt.near_uniform_min_depth > 0.f) min_depth = c->opt.near_uniform_min_depth;  // (lab)
+    if (!run.may_rank || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
+        depth < min_depth || min_span == 0)
+        return QMCP_OK;
+    {
+        // The route's sweep is one chain per contig (the event-driven form).  On data deeper than 11 x M that is what
+        // the one-span route runs too; shallower, the one-span and mixed-span routes split contigs into stretches, and a
+        // whole chain per round only pays while contigs are short (cfg4's 10^6 positions at 1.5 x M: 7 ms a sweep).
+        uint32_t longest = 0;
+        for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
+        if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;
+    }
+    if (c->nu_failed_n == run.n64 && c->nu_failed_ltot == pr.ltot && c->nu_failed_ell == ell && c->nu_failed_M == M) {
+        local.near_uniform_giveup = QMCP_NU_GIVEUP_REMEMBERED;
+        c->nu_ell = 0;
+        return QMCP_OK;
+    }
+    hipStream_t st = c->stream;
+    const uint32_t cap = nu_cap_for(n);
+    uint32_t n_exc = 0;
+    uint32_t* d_stats = (uint32_t*)c->stats.p;
+    if (run.nu_filter == ell) {
+        n_exc = c->h_head[5];  // (read back beside the statistics)
+        if (c->h_head[6] != 0) { c->nu_ell = 0; local.near_uniform_giveup = QMCP_NU_GIVEUP_TOO_MANY; return QMCP_OK; }  // a pass held more exceptions than it can stage
+    } else {
+        // how many reads have the longest span?  (one pass over the spans; the host waits for the count)
+        TRY(ensure_near_uniform(c, n, ltot, n_contigs));
+        HIP_TRY(hipMemsetAsync(d_stats + 7, 0, sizeof(uint32_t), st));
+        qmcp::launch_nu_count_span(st, run.d_starts, run.d_ends, n, ell, d_stats + 7);
+        HIP_TRY(hipMemcpyAsync(c->h_nu, d_stats + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_exc = n - c->h_nu[0];
+        if (dbg) fprintf(stderr, "[near] reads of span %u: %u of %u, list holds %u\n", ell, c->h_nu[0], n, cap);
+        if (n_exc > n / 10u) {
+            // (fewer than nine tenths of the reads have the LONGEST span: either many exceptions, or -- nearly all reads
+            //  shorter than a few -- the dominant span is not the longest: reads lengthened by a deletion)
+            c->nu_ell = 0;
+            local.near_uniform_giveup = n_exc > n - n / 10u ? QMCP_NU_GIVEUP_LONGER_READS : QMCP_NU_GIVEUP_TOO_MANY;
+            return QMCP_OK;
+        }
+        // the head again, regular reads only (exceptions listed): producer, scan, range table, bucket offsets
+        c->nu_ell = ell;
+        if (run.pm) TRY(queue_pm_head(c, st, ell));
+        else TRY(queue_rm_head(c, st, ell, true));
+        uint32_t* d_max_load = (uint32_t*)c->ranges.p + 65540;
+        HIP_TRY(hipMemcpyAsync(c->h_nu, d_max_load, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(c->h_nu + 1, d_stats + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        max_load = c->h_nu[0];
+        if (c->h_nu[1] != n_exc || c->h_nu[2] != 0) { c->nu_ell = 0; local.near_uniform_giveup = QMCP_NU_GIVEUP_TOO_MANY; return QMCP_OK; }  // (a pass held more than it can stage)
+    }
+    local.near_uniform_exceptions = n_exc;
+    if (n_exc == 0 || n_exc > n / 10u || (uint64_t)max_load * kRankBalance > (uint64_t)n) {
+        if (n_exc > n / 10u) c->nu_ell = 0;
+        local.near_uniform_giveup = n_exc > n / 10u ? QMCP_NU_GIVEUP_TOO_MANY : n_exc == 0 ? QMCP_NU_GIVEUP_NOT_TRIED : QMCP_NU_GIVEUP_HEAVY_RANGE;
+        return QMCP_OK;
+    }
+    // scratch of the event-driven sweep (launch_uniform_sweep)
+    TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ell, n_contigs + 768)));
+    TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ell, n_contigs + 768)));
+    const uint32_t* boff = (const uint32_t*)c->boff.p;
+    const uint64_t* poff = (const uint64_t*)c->poff.p;
+    uint32_t* selend = (uint32_t*)c->selend.p;
+    uint32_t* exc = (uint32_t*)c->nu_exc.p;
+    int32_t* nadj = (int32_t*)c->nu_nadj.p;
+    uint32_t* state = (uint32_t*)c->nu_state.p;
+    unsigned long long* viol_key = (unsigned long long*)((char*)c->nu_state.p + 64);
+    uint32_t* viol_idx = (uint32_t*)(viol_key + n_contigs);
+    uint32_t* sweep_from[2] = {viol_idx + n_contigs, viol_idx + 2 * (size_t)n_contigs};  // this round's, the next round's
+    TRY(ensure(c, c->nu_ckpt, qmcp::sweep_ev_ckpt_bytes(ltot, ell, n_contigs + 768)));
+    HIP_TRY(hipMemsetAsync(sweep_from[0], 0, (size_t)n_contigs * sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], st));
+    HIP_TRY(hipEventRecord(c->ev[EV_SORT], st));
+    {
+        KernelSpan sp(c, "near-uniform setup (exception coverage, need, pre-selection)");
+        qmcp::launch_nu_setup(st, exc, cap, n_exc, d_stats + 6, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
+                              nadj, state);
+    }
+    // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
+    // all settled is eight launches that return at once (the chain sweeps nothing, the verification skips every
+    // exception: ~0.1 ms), about what one more host round trip costs; measured at cfg4 with 1 % clipped reads (7 rounds),
+    // batches of 1 / 2 / 2 + 4 + 4: 4.62 / 4.5 / 4.60 ms.
+    uint32_t rounds = 0;
+    bool settled = false;
+    const uint32_t budget = nu_round_budget(c, run.lengths, n_contigs);
+    while (rounds < budget && !settled) {
+        const uint32_t batch = 2u;
+        for (uint32_t r = 0; r < batch; ++r) {
+            ++rounds;
+            {
+                KernelSpan sp(c, "k_sweep_pack", st);
+                qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (uint32_t*)c->evpk.p, nadj, sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "k_sweep_uniform_ev", st);
+                qmcp::launch_sweep_ev_chain(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->evpk.p,
+                                            (uint32_t*)c->cstart.p, (uint32_t*)c->evlast.p, d_iters, nadj, (uint32_t*)c->nu_ckpt.p,
+                                            sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "k_sweep_expand", st);
+                qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->cstart.p,
+                                             (const uint32_t*)c->evlast.p, selend, sweep_from[0]);
+            }
+            {
+                KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
+                qmcp::launch_nu_round(st, exc, cap, n_exc, d_stats + 6, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
+                                      (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
+                std::swap(sweep_from[0], sweep_from[1]);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_nu, state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (dbg) {
+            uint32_t more[8];
+            (void)hipMemcpy(more, state + 8, sizeof(more), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[near] open question: s %u u1 %u S(u1-1) %u C(u1-1) %u b %u c0 %u\n", more[0], more[1], more[2], more[3], more[4], more[5]);
+            fprintf(stderr, "[near] after %u rounds: last round selected %u, flags %u (read %u), selected in all %u, suspects %u, rounds that selected %u; next sweeps from block",
+                    rounds, c->h_nu[1], c->h_nu[2], c->h_nu[5], c->h_nu[3], c->h_nu[4], c->h_nu[6]);
+            std::vector<uint32_t> from(n_contigs);
+            (void)hipMemcpy(from.data(), sweep_from[0], (size_t)n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            for (uint32_t k = 0; k < n_contigs && k < 16; ++k) fprintf(stderr, " %d", (int)from[k]);
+            fprintf(stderr, "\n");
+        }
+        if (c->h_nu[2] != 0) break;          // a run the replay does not model, or too many suspects
+        settled = c->h_nu[1] == 0;           // the last round wanted no exception: the sweep's counts are the greedy's
+    }
+    if (settled) rounds = c->h_nu[6] + 1;    // (the rounds that did something, and the one that found nothing left)
+    local.near_uniform_rounds = rounds;
+    local.near_uniform_selected = c->h_nu[3];
+    if (!settled) {
+        // (the head must not filter on this span again, and the next call of this shape must not burn the budget again)
+        local.near_uniform_giveup = c->h_nu[2] != 0 ? QMCP_NU_GIVEUP_UNMODELLED : QMCP_NU_GIVEUP_BUDGET;
+        c->nu_ell = 0;
+        c->nu_failed_n = run.n64; c->nu_failed_ltot = pr.ltot; c->nu_failed_ell = ell; c->nu_failed_M = M;
+        return QMCP_OK;
+    }
+    local.near_uniform_giveup = QMCP_NU_GIVEUP_NONE;
+    HIP_TRY(hipEventRecord(c->ev[EV_SWEEP], st));
+    if (run.pm) {
+        queue_pm_rank(c, st, nullptr, nullptr, 0);
+    } else {
+        KernelSpan sp(c, "k_rank_mark");
+        qmcp::launch_rank_mark(st, (const uint16_t*)c->keys[0].p, (const uint32_t*)c->vals[0].p, (const uint32_t*)c->ranges.p,
+                               run.range_shift, ltot, boff, selend, (unsigned long long*)run.d_mask,
+                               (unsigned long long*)c->scalars.p, c->rankamb.p,
+                               qmcp::rank_scratch_by_records(run.range_shift, ltot, n));
+    }
+    {
+        KernelSpan sp(c, "k_nu_mark_selected");
+        qmcp::launch_nu_mark_selected(st, exc, cap, n_exc, d_stats + 6, (unsigned long long*)run.d_mask,
+                                      (unsigned long long*)c->scalars.p);
+    }
+    HIP_TRY(hipGetLastError());
+    done = true;
+    return QMCP_OK;
+}

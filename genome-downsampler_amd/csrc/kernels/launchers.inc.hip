@@ -386,7 +386,6 @@ bool launch_sweep_general_reg(hipStream_t st, bool wide, const uint32_t* boff, c
     // entering chunk's three trips to memory; many workgroups (stretches) fill the chip by themselves
     // and extra waves only get in the walkers' way
     int loaders = n_wg <= 64 ? 4 : 1;  // (769 stretches, cfg3-like mix: 1 loader 2.52 ms, 8 loaders 4.92 ms; one contig: 1.19 vs 1.09 ms)
-    if (const char* e = std::getenv("QMCP_HIP_REG_LOADERS")) loaders = std::atoi(e);  // lab
 #define QMCP_GEN_REG(BB)                                                                              \
     if (loaders >= 8) { QMCP_GEN_REG_K(BB, 8) }                                                        \
     else if (loaders >= 4) { QMCP_GEN_REG_K(BB, 4) }                                                   \
@@ -480,8 +479,7 @@ uint32_t range_shift_for(uint32_t ltot) {
         // two levels: any shift with <= 65 536 ranges (and so <= 256 super-ranges) will do
         uint32_t lowest = 0;
         while ((ltot >> lowest) >= 65536u) ++lowest;
-        uint32_t want = kTwoLevelRangeShift;
-        if (const char* e = std::getenv("QMCP_HIP_RANGE_SHIFT")) want = (uint32_t)std::atoi(e);  // lab
+        const uint32_t want = kTwoLevelRangeShift;
         shift = want < lowest ? lowest : (want > kMaxRangeShift ? kMaxRangeShift : want);
     }
     return shift;

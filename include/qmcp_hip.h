@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMCP_HIP_ABI_VERSION 4
+#define QMCP_HIP_ABI_VERSION 5
 
 enum {
     QMCP_OK = 0,
@@ -133,6 +133,40 @@ int qmcp_hip_device_count(void);
 
 int qmcp_hip_create(int device, qmcp_hip_ctx** out_ctx);
 void qmcp_hip_destroy(qmcp_hip_ctx* ctx);
+
+/* Per-context options: which of the (all exact) kernels and routes a solve takes where the library would otherwise
+ * choose by the data, and the host entries' threads -- the counterpart of the reference solver's setters
+ * (libs/qmcp-solver/include/qmcp-solver/quasi_mcp_cuda_max_flow_solver.hpp:30-31: set_block_size, set_kernel_cycles).
+ * Every choice gives the same keep mask; the options exist for tests (every route is forced and compared with the
+ * oracle), measurements and debugging.  0 means "the library chooses" in every field.
+ * qmcp_hip_create initialises a context's options from the defaults and then from the environment variables named below
+ * (a debug override, read once, there and nowhere else); qmcp_hip_set_options replaces them. */
+typedef struct qmcp_hip_options {
+    uint32_t struct_size;         /* sizeof(qmcp_hip_options) of the caller's build (the struct may grow at its end)      */
+    int32_t pass_major;           /* range-ranked route: -1 the range-major form, +1 the pass-major form wherever its hard
+                                     limits allow (QMCP_HIP_PM=0|1)                                                       */
+    int32_t sweep;                /* one-length sweep: QMCP_SWEEP_* (QMCP_HIP_SWEEP=fast|gen|ev)                          */
+    int32_t cut_points;           /* split contigs at cut points: -1 never, +1 always (QMCP_HIP_CUTS=0|1)                 */
+    int32_t speculation;          /* speculative stretch boundaries: -1 never, +1 at any depth (QMCP_HIP_SPEC=0|1)        */
+    uint32_t speculation_run_in;  /* blocks of run-in of the first tier (QMCP_HIP_SPEC_BURN)                              */
+    int32_t near_uniform;         /* near-uniform route: -1 off (QMCP_HIP_NEAR=0)                                         */
+    uint32_t near_uniform_rounds; /* its budget of rounds (QMCP_HIP_NEAR_ROUNDS)                                          */
+    float near_uniform_min_depth; /* mean coverage / M below which it is not tried (QMCP_HIP_NEAR_MIN_DEPTH)              */
+    int32_t near_uniform_debug;   /* 1: what every pair of rounds did, to stderr (QMCP_HIP_NEAR_DEBUG)                    */
+    int32_t force_sort_route;     /* 1: the keep mask from the radix sort even where the ranked route applies
+                                     (QMCP_HIP_NO_RANK)                                                                   */
+    int32_t keep_expand;          /* 1: the event-driven sweep always expands its output (QMCP_HIP_EXPAND)                */
+    int32_t mixed_sweep_in_lds;   /* 1: the LDS-cached mixed-span sweep instead of the register-resident one
+                                     (QMCP_HIP_GENERAL_LDS)                                                               */
+    uint32_t rank_min_reads;      /* calls below this many reads take the sort-based route (QMCP_HIP_RANK_MIN; 2^17)      */
+    uint32_t host_threads;        /* host entries: threads that narrow / check the columns (QMCP_HIP_HOST_THREADS; 8)     */
+    uint32_t copy_streams;        /* host entries: copy streams (QMCP_HIP_COPY_STREAMS)                                   */
+    int32_t host_both_columns;    /* 1: host entries always send starts AND ends (QMCP_HIP_HOST_BOTH_COLUMNS)             */
+} qmcp_hip_options;
+enum { QMCP_SWEEP_AUTO = 0, QMCP_SWEEP_FAST = 1, QMCP_SWEEP_GENERAL = 2, QMCP_SWEEP_EVENTS = 3 };
+void qmcp_hip_default_options(qmcp_hip_options* out);            /* all zero but struct_size                          */
+int qmcp_hip_set_options(qmcp_hip_ctx* ctx, const qmcp_hip_options* options);
+int qmcp_hip_get_options(qmcp_hip_ctx* ctx, qmcp_hip_options* out);
 
 /* Instrumentation (the reference's only timing is the "solve took" wall-clock log line,
  * src/app.cpp:132-139).  With profiling on, kernel launches of a solve are bracketed by HIP events

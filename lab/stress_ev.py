@@ -10,7 +10,7 @@ import oracle_py
 pkg = importlib.import_module("genome-downsampler_amd")
 sol = pkg.Solver(0)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-os.environ["QMCP_HIP_SWEEP"] = "ev"
+sol.set_options(sweep="ev")
 bad = ran = 0
 kinds = {}
 
@@ -59,7 +59,7 @@ for seed in range(lo, hi):
     kind, s, e, lengths, offs, M = case(rng)
     if s.size == 0:
         continue
-    os.environ["QMCP_HIP_CUTS"] = str(int(rng.integers(0, 2)))
+    sol.set_options(sweep="ev", cut_points=1 if int(rng.integers(0, 2)) else -1)
     got = sol.solve(s, e, lengths, M, contig_read_offsets=offs)
     want = oracle_py.solve(s, e, lengths, M, contig_read_offsets=offs)
     ran += 1

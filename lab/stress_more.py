@@ -27,9 +27,9 @@ def check(tag, seed, s, e, lengths, offs, M):
 
 
 for seed in range(lo, hi):
-    os.environ.pop("QMCP_HIP_CUTS", None)
+    sol.set_options()
     check("deep", seed, *_case(np.random.default_rng(seed)))
-    os.environ["QMCP_HIP_CUTS"] = "1"
+    sol.set_options(cut_points=1)
     s, e, lengths, offs, M = _shallow_case(np.random.default_rng(1_000_000 + seed))
     check("shallow", seed, s, e, lengths, offs, M)
     rng = np.random.default_rng(2_000_000 + seed)

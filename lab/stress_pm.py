@@ -8,9 +8,9 @@ import numpy as np
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
 import oracle_py
-os.environ["QMCP_HIP_PM"] = "1"
 pkg = importlib.import_module("genome-downsampler_amd")
 sol = pkg.Solver(0)
+sol.set_options(pass_major=1)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 routes = collections.Counter()

@@ -14,7 +14,7 @@ n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 sol = pkg.Solver(0)
-os.environ["QMCP_HIP_SPEC"] = "1"
+sol.set_options(speculation=1)
 accepted = rejected = none = bad = second = 0
 acc_boundaries = 0
 t0 = time.time()
@@ -43,7 +43,7 @@ for it in range(n_inst):
     else:
         e = s + np.uint32(span - 1)
     offs = np.asarray(offs, np.uint64)
-    os.environ["QMCP_HIP_SPEC_BURN"] = str(burn)
+    sol.set_options(speculation=1, speculation_run_in=int(burn))
     got = sol.solve(s, e, lengths, M, contig_read_offsets=offs)
     st = sol.last_stats
     want = oracle_py.solve(s, e, lengths, M, contig_read_offsets=offs)

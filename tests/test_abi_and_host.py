@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     nm = subprocess.run(["nm", "-D", "--defined-only", pkg.HIP_LIB_PATH], capture_output=True, text=True)
     exported = set(re.findall(r" T (qmcp_hip_\w+)", nm.stdout))
     assert exported == set(declared)
-    assert pkg.abi_version() == 4
+    assert pkg.abi_version() == 5
 
 
 def test_signatures_are_plain_c(pkg):
@@ -180,3 +180,21 @@ def test_a_share_is_priced_by_the_predicate_the_solver_uses():
     owned = sh.assign_contigs([shallow_reads, deep_reads, shallow_reads], 2, contig_lengths=[L, L, L],
                               read_length=rl, max_coverage=M)
     assert owned == [[1], [0, 2]]
+
+
+def test_options_struct_matches_the_header(pkg, tmp_path):
+    """qmcp_hip_options as the Python wrapper lays it out == as a C compiler lays out the header's; the defaults call
+    fills in the size and nothing else"""
+    import ctypes as C
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "qmcp_hip.h"\nint main(void){ printf("%zu %zu %zu\\n", sizeof(qmcp_hip_options), '
+           'offsetof(qmcp_hip_options, near_uniform_min_depth), offsetof(qmcp_hip_options, host_both_columns)); return 0; }\n')
+    exe = tmp_path / "opt_size"
+    out = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", str(exe)],
+                         input=src, text=True, capture_output=True)
+    assert out.returncode == 0, out.stderr
+    size, off_depth, off_last = map(int, subprocess.run([str(exe)], capture_output=True, text=True).stdout.split())
+    assert size == C.sizeof(pkg.Options)
+    assert off_depth == pkg.Options.near_uniform_min_depth.offset and off_last == pkg.Options.host_both_columns.offset
+    o = pkg.Options()
+    pkg._hip.qmcp_hip_default_options(C.byref(o))
+    assert o.struct_size == size and all(getattr(o, name) == 0 for name, _ in pkg.Options._fields_[1:])

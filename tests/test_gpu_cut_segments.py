@@ -2,31 +2,13 @@
 (SURVEY.md section 7), so the uniform-span sweep may restart behind it.  The solver splits contigs
 there into stretches swept side by side (shallow or gapped data, where a contig's serial chain is the
 whole cost).  The kept set must not change by a bit: segmented == unsegmented == oracle."""
-import os
-from contextlib import contextmanager
 
 import numpy as np
 import pytest
 
+from forcing import forced
+
 pytestmark = pytest.mark.gpu
-
-
-@contextmanager
-def _env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    try:
-        for k, v in kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _reads(rng, n, L, span, lo=0, hi=None):
@@ -36,11 +18,11 @@ def _reads(rng, n, L, span, lo=0, hi=None):
 
 
 def _check(pkg, oracle, solver, s, e, lengths, M, offs=None, sweep=None, expect_split=True):
-    with _env(QMCP_HIP_CUTS="0", QMCP_HIP_SWEEP=sweep):
+    with forced(solver, QMCP_HIP_CUTS="0", QMCP_HIP_SWEEP=sweep):
         whole = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         assert solver.last_stats.path == pkg.PATH_UNIFORM
         chains_whole = solver.last_stats.sweep_stretches
-    with _env(QMCP_HIP_CUTS="1", QMCP_HIP_SWEEP=sweep):
+    with forced(solver, QMCP_HIP_CUTS="1", QMCP_HIP_SWEEP=sweep):
         split = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         chains_split = solver.last_stats.sweep_stretches
     assert np.array_equal(split, whole)
@@ -119,7 +101,7 @@ def test_deep_data_has_only_the_contig_ends(pkg, oracle, solver):
 def test_default_is_on_for_shallow_data_and_off_for_deep(pkg, oracle, solver):
     rng = np.random.default_rng(8)
     L, span = 400_000, 100
-    with _env(QMCP_HIP_CUTS=None, QMCP_HIP_SWEEP=None):
+    with forced(solver, QMCP_HIP_CUTS=None, QMCP_HIP_SWEEP=None):
         s, e = _reads(rng, 60_000, L, span)              # coverage 15 = 1.5 M
         got = solver.solve(s, e, L, 10)
         assert solver.last_stats.sweep_stretches > 1
@@ -141,11 +123,11 @@ def _mixed_reads(rng, n, L, lo_span, hi_span, lo=0, hi=None):
 
 
 def _check_mixed(pkg, oracle, solver, s, e, lengths, M, offs=None, lds=False, expect_split=True):
-    with _env(QMCP_HIP_CUTS="0", QMCP_HIP_GENERAL_LDS="1" if lds else None):
+    with forced(solver, QMCP_HIP_CUTS="0", QMCP_HIP_GENERAL_LDS="1" if lds else None):
         whole = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         assert solver.last_stats.path == pkg.PATH_GENERAL
         chains_whole = solver.last_stats.sweep_stretches
-    with _env(QMCP_HIP_CUTS="1", QMCP_HIP_GENERAL_LDS="1" if lds else None):
+    with forced(solver, QMCP_HIP_CUTS="1", QMCP_HIP_GENERAL_LDS="1" if lds else None):
         split = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         chains_split = solver.last_stats.sweep_stretches
     assert np.array_equal(split, whole)
@@ -248,7 +230,7 @@ def test_single_read_and_cap_above_every_coverage(pkg, oracle, solver):
     rng = np.random.default_rng(2)
     L, span = 500_000, 100
     s, e = _reads(rng, 40_000, L, span)
-    with _env(QMCP_HIP_CUTS="1"):
+    with forced(solver, QMCP_HIP_CUTS="1"):
         got = solver.solve(s, e, L, 1_000_000)
         assert solver.last_stats.n_kept == s.size and solver.last_stats.sweep_stretches > 50
         assert np.array_equal(got, oracle.solve(s, e, L, 1_000_000))

@@ -3,27 +3,13 @@ with QMCP_HIP_SWEEP=ev on every kind of input -- deep (where the host picks it b
 gapped, split at cut points, every lane layout E = 1..4 -- must equal the oracle bit for bit, and must
 equal what the block-scan kernels (QMCP_HIP_SWEEP=fast / gen) produce.  The selection it replaces:
 SimpleMaxFlow::Solve at libs/qmcp-solver/src/quasi_mcp_cpu_max_flow_solver.cpp:19-20."""
-import os
-from contextlib import contextmanager
 
 import numpy as np
 import pytest
 
+from forcing import forced
+
 pytestmark = pytest.mark.gpu
-
-
-@contextmanager
-def env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update({k: str(v) for k, v in kv.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _reads(rng, n, L, span, hot=False):
@@ -45,7 +31,7 @@ def _check(solver, oracle, s, e, lengths, M, offs=None, expect_ev=True, **extra_
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     solver.set_profiling(1)
     try:
-        with env(QMCP_HIP_SWEEP="ev", **extra_env):
+        with forced(solver, QMCP_HIP_SWEEP="ev", **extra_env):
             got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         ran = _ran_event_sweep(solver)
     finally:
@@ -127,9 +113,9 @@ def test_equals_the_block_scan_kernels_on_a_ranked_call(pkg, oracle, solver):
         assert solver.last_stats.sort_passes == 1
     finally:
         solver.set_profiling(0)
-    with env(QMCP_HIP_SWEEP="fast"):
+    with forced(solver, QMCP_HIP_SWEEP="fast"):
         fast = solver.solve(s, e, lengths, 100, contig_read_offsets=offs)
-    with env(QMCP_HIP_SWEEP="gen"):
+    with forced(solver, QMCP_HIP_SWEEP="gen"):
         gen = solver.solve(s, e, lengths, 100, contig_read_offsets=offs)
     assert np.array_equal(own, fast) and np.array_equal(own, gen)
     assert np.array_equal(own, oracle.solve(s, e, lengths, 100, contig_read_offsets=offs))

@@ -4,7 +4,6 @@ libs/bam-api/src/read.cpp:11-13) keep the one-span machinery: the shorter reads 
 runs over the regular reads, and every exception the greedy would take is found from the sweep's counts and selected,
 one event per contig and round.  The keep mask must be the oracle's bit for bit whichever route a call ends on;
 tests/test_near_uniform_model.py checks the scheme itself on the CPU."""
-import os
 
 import numpy as np
 import pytest
@@ -137,11 +136,11 @@ def test_env_switch_off(pkg, oracle, solver):
     rng = np.random.default_rng(23)
     lengths = np.array([60_000], np.uint32)
     s, e, _ = _contigs(rng, [60_000], [500_000], 150, 0.01, 50)
-    os.environ["QMCP_HIP_NEAR"] = "0"
+    solver.set_options(near_uniform=-1)
     try:
         got = solver.solve(s, e, lengths, 100)
     finally:
-        del os.environ["QMCP_HIP_NEAR"]
+        solver.set_options()
     assert solver.last_stats.path == pkg.PATH_GENERAL
     assert np.array_equal(got, oracle.solve(s, e, lengths, 100))
 
@@ -153,12 +152,12 @@ def test_range_major_form_and_long_genomes(pkg, oracle, solver):
     rng = np.random.default_rng(41)
     lengths = np.array([50_000, 61_000], np.uint32)
     s, e, offs = _contigs(rng, lengths, [400_000, 500_000], 150, 0.02, 40)
-    os.environ["QMCP_HIP_PM"] = "0"
+    solver.set_options(pass_major=-1)
     try:
         got = solver.solve(s, e, lengths, 100, contig_read_offsets=offs)
         st = solver.last_stats
     finally:
-        del os.environ["QMCP_HIP_PM"]
+        solver.set_options()
     assert np.array_equal(got, oracle.solve(s, e, lengths, 100, offs)), st.as_dict()
     assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int(((e - s + 1) != 150).sum()), st.as_dict()
     # two levels: 9.2 M positions in three contigs, 12 x M deep at M = 12

@@ -5,7 +5,6 @@ oracle's, on ragged inputs: last pass partial, ranges that straddle contig borde
 of a few hundred positions, one range that holds everything, an odd number of reads.  QMCP_HIP_PM=0 / 1 picks the
 form (default: pass-major where every range's row of passes fits the kernels' share of LDS).  The layout's index
 arithmetic has a host-side model of its own: tests/test_pass_major_model.py."""
-import os
 
 import numpy as np
 import pytest
@@ -18,16 +17,9 @@ def _uniform_reads(rng, n, L, span):
     return s, (s + np.uint32(span - 1)).astype(np.uint32)
 
 
-def _with_pm(v, fn):
-    old = os.environ.get("QMCP_HIP_PM")
-    os.environ["QMCP_HIP_PM"] = v
-    try:
+def _with_pm(solver, v, fn):
+    with solver.options(pass_major=1 if v == "1" else -1):
         return fn()
-    finally:
-        if old is None:
-            del os.environ["QMCP_HIP_PM"]
-        else:
-            os.environ["QMCP_HIP_PM"] = old
 
 
 CASES = [
@@ -52,9 +44,9 @@ def test_both_forms_equal_the_oracle(pkg, oracle, solver, lengths, counts, span,
     s, e = np.concatenate(ss), np.concatenate(ee)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     solve = lambda: solver.solve(s, e, lengths, M, contig_read_offsets=offs)
-    pm = _with_pm("1", solve)
+    pm = _with_pm(solver, "1", solve)
     st_pm = solver.last_stats
-    rm = _with_pm("0", solve)
+    rm = _with_pm(solver, "0", solve)
     st_rm = solver.last_stats
     assert np.array_equal(pm, rm)
     assert st_pm.n_kept == st_rm.n_kept and st_pm.sort_passes == st_rm.sort_passes
@@ -67,10 +59,10 @@ def test_pass_major_form_runs_where_it_should(pkg, solver):
     s, e = _uniform_reads(rng, 500_000, 200_000, 150)
     with pkg.Solver(0) as sv:
         sv.set_profiling(True)
-        _with_pm("1", lambda: sv.solve(s, e, 200_000, 30))
+        _with_pm(sv, "1", lambda: sv.solve(s, e, 200_000, 30))
         assert "k_pm_prepare_sort" in sv.kernel_times() and "k_range_partition" not in sv.kernel_times()
         sv.set_profiling(True)
-        _with_pm("0", lambda: sv.solve(s, e, 200_000, 30))
+        _with_pm(sv, "0", lambda: sv.solve(s, e, 200_000, 30))
         assert "k_range_partition" in sv.kernel_times() and "k_pm_prepare_sort" not in sv.kernel_times()
 
 
@@ -83,6 +75,6 @@ def test_invalid_read_fails_the_call_in_the_pass_major_form(pkg, oracle, solver)
     bad_s[123_456] = 4_000_000_000
     bad_e[123_456] = 4_000_000_100
     with pytest.raises(pkg.QmcpError):
-        _with_pm("1", lambda: solver.solve(bad_s, bad_e, 100_000, 20))
-    got = _with_pm("1", lambda: solver.solve(s, e, 100_000, 20))
+        _with_pm(solver, "1", lambda: solver.solve(bad_s, bad_e, 100_000, 20))
+    got = _with_pm(solver, "1", lambda: solver.solve(s, e, 100_000, 20))
     assert np.array_equal(got, oracle.solve(s, e, 100_000, 20))

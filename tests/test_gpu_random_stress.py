@@ -75,10 +75,9 @@ def _shallow_case(rng):
 def test_random_shallow_case_split_at_cut_points(pkg, oracle, solver, seed, monkeypatch):
     rng = np.random.default_rng(70_000 + seed)
     s, e, lengths, offs, M = _shallow_case(rng)
-    monkeypatch.setenv("QMCP_HIP_CUTS", "1")
-    if seed % 3 == 0:
-        monkeypatch.setenv("QMCP_HIP_SWEEP", "fast")   # the checked fast form with its fallbacks, segmented
-    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    # (seed % 3 == 0: the checked fast form with its fallbacks, segmented)
+    with solver.options(cut_points=1, sweep="fast" if seed % 3 == 0 else None):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
 
@@ -91,10 +90,8 @@ def test_random_shallow_mixed_span_case_split_at_cut_points(pkg, oracle, solver,
     span = int(e[0] - s[0]) + 1
     cut = rng.integers(0, max(span // 2, 1), size=s.size).astype(np.uint32)   # shorten: ends stay inside the contig
     e = (e - cut).astype(np.uint32)
-    monkeypatch.setenv("QMCP_HIP_CUTS", "1")
-    if seed % 4 == 0:
-        monkeypatch.setenv("QMCP_HIP_GENERAL_LDS", "1")
-    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    with solver.options(cut_points=1, mixed_sweep_in_lds=1 if seed % 4 == 0 else 0):
+        got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert solver.last_stats.path == pkg.PATH_GENERAL
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, s.size, lengths.tolist(), M, solver.last_stats.sweep_stretches)
@@ -121,7 +118,7 @@ def test_random_wide_mixed_spans(pkg, oracle, solver, seed, monkeypatch):
     s, e = np.concatenate(ss), np.concatenate(ee)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     M = int(rng.choice([1, 3, 20, 150]))
-    monkeypatch.setenv("QMCP_HIP_CUTS", "1" if seed % 2 else "0")
-    got = solver.solve(s, e, np.array(lengths, np.uint32), M, contig_read_offsets=offs)
+    with solver.options(cut_points=1 if seed % 2 else -1):
+        got = solver.solve(s, e, np.array(lengths, np.uint32), M, contig_read_offsets=offs)
     want = oracle.solve(s, e, np.array(lengths, np.uint32), M, contig_read_offsets=offs)
     assert np.array_equal(got, want), (seed, lo, hi, lengths, counts, M)

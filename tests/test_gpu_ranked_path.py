@@ -2,7 +2,6 @@
 per-range LDS counts, sweep, per-range ordered ranking against S(p).  The kept set must be the
 S(p) lowest read indices of every start bucket -- bit-identical to the oracle -- whatever order the
 LDS arbitrates colliding lanes in, and identical to what the radix-sort route produces."""
-import os
 
 import numpy as np
 import pytest
@@ -20,12 +19,9 @@ def _uniform_reads(rng, n, L, span):
 def _solve_both_routes(solver, s, e, lengths, M, offs=None):
     got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
     passes = solver.last_stats.sort_passes
-    os.environ["QMCP_HIP_NO_RANK"] = "1"
-    try:
+    with solver.options(force_sort_route=1):
         sorted_route = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         sorted_passes = solver.last_stats.sort_passes
-    finally:
-        del os.environ["QMCP_HIP_NO_RANK"]
     return got, passes, sorted_route, sorted_passes
 
 

@@ -3,31 +3,13 @@ there are hardly any cut points, but two sweeps of the same positions from diffe
 some point on.  Windows without a cut therefore start a stretch with a run-in from the state of a cut
 point; where it meets the stretch before it the two outputs are compared, and one disagreement anywhere
 re-runs the exact sweep.  Whatever happens the kept set must be the oracle's, bit for bit."""
-import os
-from contextlib import contextmanager
 
 import numpy as np
 import pytest
 
+from forcing import forced
+
 pytestmark = pytest.mark.gpu
-
-
-@contextmanager
-def _env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    try:
-        for k, v in kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _uniform_contigs(rng, lengths, depth_in_m, M, span):
@@ -46,7 +28,7 @@ def _uniform_contigs(rng, lengths, depth_in_m, M, span):
 def test_speculative_boundaries_hold_and_change_nothing(pkg, oracle, solver, span, M, depth):
     rng = np.random.default_rng(span + M)
     s, e, offs, lengths = _uniform_contigs(rng, [2_400_000, 700_000, 1_300_000], depth, M, span)
-    with _env(QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
+    with forced(solver, QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
         got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.path == pkg.PATH_UNIFORM and st.spec_mismatches == 0, st.as_dict()
@@ -54,7 +36,7 @@ def test_speculative_boundaries_hold_and_change_nothing(pkg, oracle, solver, spa
         assert st.spec_boundaries >= 2, st.as_dict()
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want)
-    with _env(QMCP_HIP_SPEC="0"):
+    with forced(solver, QMCP_HIP_SPEC="0"):
         plain = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         assert solver.last_stats.spec_boundaries == 0
     assert np.array_equal(plain, want)
@@ -64,16 +46,16 @@ def test_a_run_in_that_is_too_short_is_noticed_and_the_exact_sweep_takes_over(pk
     rng = np.random.default_rng(8)
     s, e, offs, lengths = _uniform_contigs(rng, [3_000_000], 2.0, 50, 150)
     want = oracle.solve(s, e, lengths, 50, contig_read_offsets=offs)
-    with _env(QMCP_HIP_SPEC_BURN="4"):
+    with forced(solver, QMCP_HIP_SPEC_BURN="4"):
         got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.spec_boundaries > 0 and st.spec_mismatches > 0, st.as_dict()
     assert np.array_equal(got, want)
     assert st.spec_retry_mismatches > 0          # three times four blocks is not enough either: the exact sweep ran
-    with _env(QMCP_HIP_SPEC_BURN="2"):
+    with forced(solver, QMCP_HIP_SPEC_BURN="2"):
         assert np.array_equal(solver.solve(s, e, lengths, 50, contig_read_offsets=offs), want)
     # 64 blocks: a good part of the boundaries disagree; the second tier (192 blocks) settles it
-    with _env(QMCP_HIP_SPEC_BURN="64"):
+    with forced(solver, QMCP_HIP_SPEC_BURN="64"):
         got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.spec_mismatches > 0 and st.spec_retry_mismatches == 0, st.as_dict()
@@ -92,7 +74,7 @@ def test_speculation_beside_real_cut_points_and_gaps(pkg, oracle, solver):
     s = np.concatenate(parts)
     s = s[rng.permutation(s.size)]
     e = s + np.uint32(span - 1)
-    with _env(QMCP_HIP_SPEC="1"):
+    with forced(solver, QMCP_HIP_SPEC="1"):
         got = solver.solve(s, e, L, M)
         st = solver.last_stats
     assert st.spec_boundaries > 0
@@ -103,7 +85,7 @@ def test_deeper_data_forced_to_speculate_falls_back_exactly(pkg, oracle, solver)
     """at 6 x M the sweep does not forget its start within the run-in: every boundary disagrees"""
     rng = np.random.default_rng(5)
     s, e, offs, lengths = _uniform_contigs(rng, [1_500_000], 6.0, 20, 150)
-    with _env(QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="64"):
+    with forced(solver, QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="64"):
         got = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.spec_boundaries > 0 and st.spec_mismatches > 0
@@ -133,7 +115,7 @@ def test_mixed_spans_speculate_too(pkg, oracle, solver, lo, hi, M, depth):
     assert st.path == pkg.PATH_GENERAL and st.spec_boundaries >= 2 and st.spec_mismatches == 0, st.as_dict()
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want)
-    with _env(QMCP_HIP_SPEC="0"):
+    with forced(solver, QMCP_HIP_SPEC="0"):
         assert np.array_equal(solver.solve(s, e, lengths, M, contig_read_offsets=offs), want)
         assert solver.last_stats.spec_boundaries == 0
 
@@ -143,7 +125,7 @@ def test_mixed_spans_with_a_run_in_that_is_too_short(pkg, oracle, solver):
     s, e, offs, lengths = _mixed_contigs(rng, [2_000_000], 2.0, 40, 100, 150)
     want = oracle.solve(s, e, lengths, 40, contig_read_offsets=offs)
     for burn in ("3", "16"):
-        with _env(QMCP_HIP_SPEC_BURN=burn):
+        with forced(solver, QMCP_HIP_SPEC_BURN=burn):
             got = solver.solve(s, e, lengths, 40, contig_read_offsets=offs)
             st = solver.last_stats
         assert st.spec_boundaries > 0
@@ -163,7 +145,7 @@ def test_a_deep_island_in_a_shallow_genome_is_swept_again_alone(pkg, oracle, sol
     s = np.concatenate(parts)
     s = s[rng.permutation(s.size)]
     e = s + np.uint32(span - 1)
-    with _env(QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="160"):
+    with forced(solver, QMCP_HIP_SPEC="1", QMCP_HIP_SPEC_BURN="160"):
         got = solver.solve(s, e, L, M)
         st = solver.last_stats
     # boundaries outside the island hold, those inside disagree in both speculative tiers
@@ -203,7 +185,7 @@ def test_mixed_spans_with_more_than_a_thousand_stretches(pkg, oracle, solver, de
     s, e, offs, lengths = _mixed_contigs(rng, [11_000_000, 5_000_000], depth, M, 100, 150)
     # (at 2 x M the run-in is forced short, so that boundaries are close enough together for a table this
     #  large on a genome this small; those that then disagree are settled by the later tiers)
-    with _env(QMCP_HIP_SPEC_BURN="20" if depth >= 2.0 else None):
+    with forced(solver, QMCP_HIP_SPEC_BURN="20" if depth >= 2.0 else None):
         got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.path == pkg.PATH_GENERAL and st.sweep_stretches > 1024, st.as_dict()
@@ -220,13 +202,13 @@ def test_depths_between_4_and_11_times_m_are_swept_as_stretches_too(pkg, oracle,
     oracle's"""
     rng = np.random.default_rng(1000 + M)
     s, e, offs, lengths = _uniform_contigs(rng, [3_200_000, 900_000], depth, M, 150)
-    with _env(QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
+    with forced(solver, QMCP_HIP_SPEC=None, QMCP_HIP_SPEC_BURN=None):
         got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         st = solver.last_stats
     assert st.path == pkg.PATH_UNIFORM and st.spec_boundaries >= 1, st.as_dict()
     want = oracle.solve(s, e, lengths, M, contig_read_offsets=offs)
     assert np.array_equal(got, want)
-    with _env(QMCP_HIP_SPEC="0"):
+    with forced(solver, QMCP_HIP_SPEC="0"):
         plain = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
         assert solver.last_stats.spec_boundaries == 0
     assert np.array_equal(plain, want)
