@@ -599,6 +599,19 @@ def check_bam(path):
     return rc == 0, int(n.value) if rc == 0 else 0, buf.value.decode(errors="replace")
 
 
+def copy_records(in_path, out_path, ids):
+    """BamApi::write_bam: the header and the records with the given running ids, to a BAM (".bam") or to SAM text"""
+    _need_host()
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    _host.qmcp_host_copy_records.restype = C.c_int64
+    _host.qmcp_host_copy_records.argtypes = [C.c_char_p, C.c_char_p, _u64p, C.c_uint64, C.c_char_p, C.c_size_t]
+    n = _host.qmcp_host_copy_records(str(in_path).encode(), str(out_path).encode(), _p64(ids), ids.size, err, 512)
+    if n < 0:
+        raise OSError(err.value.decode())
+    return int(n)
+
+
 def downsample_bam(solver_name, in_path, out_path, max_coverage, filtered_path=None, min_length=0, min_mapq=0):
     """BamApi(in) -> solve -> find_pairs -> write_paired_reads(out): App::execute's file-to-file flow"""
     _need_host()

@@ -605,9 +605,11 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     auto desc_offset = [&](uint32_t c) -> uint32_t {  // byte offset of the wave's descriptor of chunk c (the range's last beyond it: never used)
         return (g0 + min(16u * c + w, n_ws - 1u)) * 4u;
     };
-    auto slot_of = [&](uint32_t dsc, uint32_t c) -> Slot {
+    auto slot_of = [&](uint32_t dsc_v, uint32_t c) -> Slot {
         const bool has = 16u * c + w < n_ws;  // uniform
-        const PmSlot at = pm_unpack<true>(dsc, has, stride);
+        // (every lane holds the same word: through the scalar unit, whose instructions do not take the vector unit's slots)
+        const uint32_t dsc = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsc_v);
+        const PmSlot at = pm_unpack<false>(dsc, has, stride);
         Slot s;
         s.slot0 = at.slot0;
         s.nv = at.nv;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
         if (at.has) { /* uniform: the wave has a wave-slot in this chunk */                                                   \
             const uint64_t kb = __ballot(keep);                                                                               \
             const uint32_t cw = (uint32_t)__popcll(kb);                                                                       \
-            if (keep) ring[(cur + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))) & 127u] = at.read0 + idx;                 \
+            if (keep) ring[(cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u))) & 127u] = at.read0 + idx; \
             cur += cw;                                                                                                        \
             if (cur - flushed >= 64u) { /* uniform */                                                                         \
                 const uint32_t v = ring[(flushed + lane) & 127u];                                                             \

@@ -351,6 +351,33 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         ++n_changed;
     };
 
+    // The same for a deep block that lies whole inside the stretch and whose lanes' slots are whole (ell a multiple of E:
+    // a lane has all E slots or none): no partial lanes, no per-slot stores.  The lane's byte offset inside a block is a
+    // constant; lanes without slots store to the spare words behind the table.
+    const bool lane_has_slots = lane * E + E <= ell;
+    auto commit_plain = [&](uint32_t k, const uint32_t (&S)[E], uint32_t cword) {
+        gp = 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            g[r] = S[r];
+            gp |= S[r] << (r * P::kW);   // S <= M < the field maximum (the launcher checks M)
+        }
+        uint32_t* const at = sev + (lane_has_slots ? (size_t)base + (size_t)k * ell : (size_t)ltot);  // (uniform part + the lane's constant)
+        if constexpr (E == 1) {
+            at[lane_has_slots ? lane : 0u] = S[0];
+        } else {
+            typedef typename RowVec<E>::type V;
+            V v;
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = S[r];
+            *reinterpret_cast<V*>(at + (lane_has_slots ? lane * E : 0u)) = v;
+        }
+        cprevw = cword;
+        last_ns = k;
+        lastv = lane >= (k & 63) ? k : lastv;
+        ++n_changed;
+    };
+
     // one block that is not known to be unchanged
     auto general_block = [&](uint32_t k, uint32_t word) {
         uint32_t c[E];
@@ -358,24 +385,28 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         if (word & P::kPlain) {
             // Deep block: the demand is the profile itself.  Nearly always whatever a position cannot
             // serve is taken by the position just before it: one shifted read instead of two scans.
-            int32_t t[E], ex[E];
+            //   ex = what the slot cannot serve = max(g - c, 0) (one saturating subtract), S = min(g, c) + ex of the
+            //   slot after it; valid iff no receiving slot overflows in turn -- S <= c everywhere: where nothing comes in
+            //   S = min(g, c) <= c, where something does S <= c means g + in <= c -- and nothing is handed back past the
+            //   block's first position (lane 0's first ex).  One maximum over the differences and one ballot decide.
+            uint32_t ex[E], mn[E];
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 c[r] = (word >> (r * P::kW)) & P::kSat;
-                t[r] = (int32_t)g[r] - (int32_t)c[r];
-                ex[r] = max(t[r], 0);
+                ex[r] = __builtin_elementwise_sub_sat(g[r], c[r]);
+                mn[r] = g[r] - ex[r];
             }
-            const int32_t up = __builtin_amdgcn_update_dpp(0, ex[0], 0x130, 0xF, 0xF, false);  // next lane's first slot
-            bool ok = true;
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ex[0], 0x130, 0xF, 0xF, false);  // next lane's first slot
+            int32_t viol = lane == 0 ? (int32_t)ex[0] : 0;
 #pragma unroll
             for (int r = 0; r < E; ++r) {
-                const int32_t in = r + 1 < E ? ex[r + 1 < E ? r + 1 : r] : up;
-                ok = ok && (in == 0 || in + t[r] <= 0);
-                S[r] = (uint32_t)((int32_t)g[r] - ex[r] + in);
+                const uint32_t in = r + 1 < E ? ex[r + 1 < E ? r + 1 : r] : up;
+                S[r] = mn[r] + in;
+                viol = max(viol, (int32_t)S[r] - (int32_t)c[r]);
             }
-            const bool first_ok = __builtin_amdgcn_readfirstlane(ex[0]) == 0;  // nothing handed back past the block
-            if (first_ok && __builtin_amdgcn_ballot_w64(!ok) == 0) {
-                commit(k, S, word);
+            if (__builtin_amdgcn_ballot_w64(viol > 0) == 0) {
+                if (ell % E == 0 && (uint64_t)(k + 1) * ell <= Lrun) commit_plain(k, S, word);  // (uniform)
+                else commit(k, S, word);
                 return;
             }
         }

@@ -40,8 +40,9 @@ bool read_bam(const std::filesystem::path& path, const BamFilters& filters, Pair
               std::vector<BAMReadId>& filtered_out, BamIngestStats* stats, std::string* err);
 
 // Copies the header and the records whose running id is in `bam_ids` (sorted in place, as the reference does)
-// to a new BAM.  Returns the number of records written, or UINT32_MAX + *err on failure.  Output is always
-// BAM (the reference also writes SAM text when the extension is not .bam).
+// to a new file: BAM if the output's extension is ".bam", SAM text otherwise (bam_api.cpp:564).  BGZF blocks are
+// deflated on several threads (QMCP_BAM_THREADS; the reference: hts_set_thread_pool(outfile), bam_api.cpp:569-586).
+// Returns the number of records written, or UINT32_MAX + *err on failure.
 std::uint32_t write_bam(const std::filesystem::path& input, const std::filesystem::path& output,
                         std::vector<BAMReadId>& bam_ids, std::string* err);
 

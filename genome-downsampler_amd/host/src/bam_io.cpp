@@ -28,6 +28,16 @@ bool set_err(std::string* err, const std::string& msg) {
     return false;
 }
 
+// threads for BGZF blocks (inflate on ingest, deflate on emit): QMCP_BAM_THREADS, default up to 8 of the host's cores
+// (the reference hands both files one HTSlib thread pool: bam_api.cpp:386-397, 569-586)
+unsigned bgzf_threads() {
+    unsigned t = 8;
+    if (const char* e = std::getenv("QMCP_BAM_THREADS")) t = (unsigned)std::strtoul(e, nullptr, 10);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw != 0 && t > hw) t = hw;
+    return t < 1 ? 1 : t;
+}
+
 // Sequential reader of the uncompressed stream of a BGZF file.  The file is a sequence of gzip members whose extra
 // subfield "BC" gives the member's size (SAM specification 4.1); every member inflates on its own, so the calling
 // thread reads a batch of members from the file (about 8 MiB of compressed bytes) and several threads inflate it,
@@ -39,11 +49,7 @@ class BgzfReader {
     ~BgzfReader() { if (f_) std::fclose(f_); }
     bool open(const std::filesystem::path& p) {
         f_ = std::fopen(p.c_str(), "rb");
-        threads_ = 8;
-        if (const char* e = std::getenv("QMCP_BAM_THREADS")) threads_ = (unsigned)std::strtoul(e, nullptr, 10);
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw != 0 && threads_ > hw) threads_ = hw;
-        if (threads_ < 1) threads_ = 1;
+        threads_ = bgzf_threads();
         return f_ != nullptr;
     }
     // reads exactly n bytes; false at a clean end of file before the first byte (eof() tells) or on error
@@ -151,55 +157,89 @@ class BgzfReader {
     std::string error_;
 };
 
+// Writer of a BGZF file: the payload is cut into blocks of kBgzfFill bytes, every block deflates on its own, so a batch
+// of blocks (4 MiB of payload) is deflated by several threads, one block per task, and written out in order -- what
+// HTSlib's thread pool does for the reference's output file (bam_api.cpp:569-586, hts_set_thread_pool(outfile)).
 class BgzfWriter {
    public:
     ~BgzfWriter() { if (f_) std::fclose(f_); }
     bool open(const std::filesystem::path& p) {
         f_ = std::fopen(p.c_str(), "wb");
+        threads_ = bgzf_threads();
         return f_ != nullptr;
     }
     bool write(const void* src, std::size_t n) {
         const unsigned char* in = static_cast<const unsigned char*>(src);
-        while (n != 0) {
-            const std::size_t take = std::min(n, kBgzfFill - buf_.size());
-            buf_.insert(buf_.end(), in, in + take);
-            in += take; n -= take;
-            if (buf_.size() == kBgzfFill && !flush_block()) return false;
-        }
+        buf_.insert(buf_.end(), in, in + n);
+        while (buf_.size() >= kBatchBlocks * kBgzfFill)
+            if (!flush_blocks(kBatchBlocks)) return false;
         return true;
     }
     bool close() {
         if (!f_) return false;
-        bool ok = buf_.empty() || flush_block();
-        ok = ok && flush_block();  // the empty block that marks the end of a BGZF file
+        bool ok = flush_blocks((buf_.size() + kBgzfFill - 1) / kBgzfFill);
+        static const unsigned char eof_block[28] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0,
+                                                    0x1B, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the empty block that ends a BGZF file
+        ok = ok && std::fwrite(eof_block, 1, sizeof(eof_block), f_) == sizeof(eof_block);
         ok = (std::fclose(f_) == 0) && ok;
         f_ = nullptr;
         return ok;
     }
 
    private:
-    bool flush_block() {
-        std::vector<unsigned char> comp(compressBound((uLong)buf_.size()) + 64);
+    static constexpr std::size_t kBatchBlocks = 64;
+    // one block: gzip member header with the BC field, raw deflate, CRC32 and ISIZE
+    static bool deflate_block(const unsigned char* in, std::size_t n, std::vector<unsigned char>& out) {
+        std::vector<unsigned char> comp(compressBound((uLong)n) + 64);
         z_stream zs;
         std::memset(&zs, 0, sizeof(zs));
         if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
+        zs.next_in = const_cast<unsigned char*>(in); zs.avail_in = (uInt)n;
         zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
         const int rc = deflate(&zs, Z_FINISH);
         const std::size_t clen = comp.size() - zs.avail_out;
         deflateEnd(&zs);
-        if (rc != Z_STREAM_END) return false;
-        std::vector<unsigned char> out;
+        if (rc != Z_STREAM_END || 18 + clen + 8 > kBgzfMaxBlock) return false;
+        out.clear();
         const unsigned char head[] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0};
         out.insert(out.end(), head, head + sizeof(head));
         put16(out, (std::uint16_t)(18 + clen + 8 - 1));  // BSIZE = total block size - 1
         out.insert(out.end(), comp.begin(), comp.begin() + (std::ptrdiff_t)clen);
-        put32(out, (std::uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size()));
-        put32(out, (std::uint32_t)buf_.size());
-        buf_.clear();
-        return std::fwrite(out.data(), 1, out.size(), f_) == out.size();
+        put32(out, (std::uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n));
+        put32(out, (std::uint32_t)n);
+        return true;
+    }
+    // deflates and writes the first `blocks` blocks of the buffer (the last may be short)
+    bool flush_blocks(std::size_t blocks) {
+        if (blocks == 0) return true;
+        std::vector<std::vector<unsigned char>> out(blocks);
+        std::atomic<std::size_t> next{0};
+        std::atomic<int> failed{0};
+        const std::size_t total = std::min(buf_.size(), blocks * kBgzfFill);
+        auto work = [&]() {
+            for (std::size_t i = next.fetch_add(1); i < blocks && failed.load() == 0; i = next.fetch_add(1)) {
+                const std::size_t off = i * kBgzfFill, n = std::min(kBgzfFill, total - off);
+                if (!deflate_block(buf_.data() + off, n, out[i])) failed.store(1);
+            }
+        };
+        const unsigned t = (unsigned)std::min<std::size_t>(threads_, blocks);
+        if (t <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            pool.reserve(t - 1);
+            for (unsigned k = 1; k < t; ++k) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        if (failed.load() != 0) return false;
+        for (const auto& b : out)
+            if (std::fwrite(b.data(), 1, b.size(), f_) != b.size()) return false;
+        buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)total);
+        return true;
     }
     std::FILE* f_ = nullptr;
+    unsigned threads_ = 1;
     std::vector<unsigned char> buf_;
 };
 
@@ -214,6 +254,8 @@ struct BamHeader {
     std::vector<unsigned char> raw;
     std::uint32_t n_ref = 0;
     std::uint32_t first_ref_length = 0;
+    std::string text;                                               // the SAM header text (l_text bytes)
+    std::vector<std::pair<std::string, std::uint32_t>> references;  // name, length
 };
 
 bool read_header(BgzfReader& in, BamHeader& h, std::string* err) {
@@ -227,6 +269,8 @@ bool read_header(BgzfReader& in, BamHeader& h, std::string* err) {
     std::vector<unsigned char> text(l_text);
     if (l_text && !in.read(text.data(), l_text)) return set_err(err, "truncated BAM header text");
     h.raw.insert(h.raw.end(), text.begin(), text.end());
+    h.text.assign(text.begin(), text.end());
+    while (!h.text.empty() && h.text.back() == '\0') h.text.pop_back();  // (some writers pad the text with NULs)
     if (!in.read(b, 4)) return set_err(err, "truncated BAM header (n_ref)");
     h.raw.insert(h.raw.end(), b, b + 4);
     h.n_ref = le32(b);
@@ -240,8 +284,110 @@ bool read_header(BgzfReader& in, BamHeader& h, std::string* err) {
         if (!in.read(name.data(), name.size())) return set_err(err, "truncated BAM reference entry");
         h.raw.insert(h.raw.end(), name.begin(), name.end());
         if (r == 0) h.first_ref_length = le32(name.data() + l_name);
+        h.references.emplace_back(std::string(reinterpret_cast<const char*>(name.data()), l_name - 1), le32(name.data() + l_name));
     }
     return true;
+}
+
+// ---- SAM text (the reference writes it when the output's extension is not ".bam": bam_api.cpp:564, sam_open(..., "w"))
+// One alignment record as a SAM line (SAM specification 1.4 and 4.2): the eleven mandatory fields, then the optional
+// ones as TAG:TYPE:VALUE.  false if the record's fields run past its end.
+bool record_to_sam(const std::vector<unsigned char>& rec, const BamHeader& h, std::string& line) {
+    const unsigned char* p = rec.data() + 4;
+    const std::size_t size = rec.size() - 4;
+    const std::int32_t ref_id = (std::int32_t)le32(p), pos = (std::int32_t)le32(p + 4);
+    const std::uint32_t l_read_name = p[8], mapq = p[9], n_cigar = le16(p + 12), flag = le16(p + 14), l_seq = le32(p + 16);
+    const std::int32_t next_ref = (std::int32_t)le32(p + 20), next_pos = (std::int32_t)le32(p + 24), tlen = (std::int32_t)le32(p + 28);
+    const std::size_t fixed_end = 32u + (std::size_t)l_read_name + 4u * (std::size_t)n_cigar + ((std::size_t)l_seq + 1) / 2 + (std::size_t)l_seq;
+    if (l_read_name == 0 || fixed_end > size) return false;
+    auto ref_name = [&](std::int32_t id) -> std::string {
+        return id >= 0 && (std::size_t)id < h.references.size() ? h.references[(std::size_t)id].first : std::string("*");
+    };
+    line.clear();
+    line.append(reinterpret_cast<const char*>(p + 32), l_read_name - 1);
+    if (line.empty()) line = "*";
+    line += '\t'; line += std::to_string(flag);
+    line += '\t'; line += ref_name(ref_id);
+    line += '\t'; line += std::to_string((std::int64_t)pos + 1);
+    line += '\t'; line += std::to_string(mapq);
+    line += '\t';
+    const unsigned char* cg = p + 32 + l_read_name;
+    if (n_cigar == 0) line += '*';
+    for (std::uint32_t k = 0; k < n_cigar; ++k) {
+        const std::uint32_t v = le32(cg + 4 * k);
+        line += std::to_string(v >> 4);
+        line += (v & 0xF) < 9 ? "MIDNSHP=X"[v & 0xF] : '?';
+    }
+    line += '\t';
+    line += next_ref < 0 ? std::string("*") : (next_ref == ref_id ? std::string("=") : ref_name(next_ref));
+    line += '\t'; line += std::to_string((std::int64_t)next_pos + 1);
+    line += '\t'; line += std::to_string(tlen);
+    line += '\t';
+    const unsigned char* sq = cg + 4 * (std::size_t)n_cigar;
+    if (l_seq == 0) line += '*';
+    for (std::uint32_t i = 0; i < l_seq; ++i) line += "=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> ((~i & 1u) << 2)) & 0xF];
+    line += '\t';
+    const unsigned char* ql = sq + ((std::size_t)l_seq + 1) / 2;
+    if (l_seq == 0 || ql[0] == 0xFF) line += '*';
+    else for (std::uint32_t i = 0; i < l_seq; ++i) line += (char)(ql[i] + 33);
+    // optional fields
+    const unsigned char* a = p + fixed_end;
+    const unsigned char* const end = p + size;
+    auto number = [&](char type, const unsigned char* v, std::string& out) -> std::size_t {  // appends the value, returns its size (0: unknown type)
+        switch (type) {
+            case 'c': out += std::to_string((int)(std::int8_t)v[0]); return 1;
+            case 'C': out += std::to_string((unsigned)v[0]); return 1;
+            case 's': out += std::to_string((int)(std::int16_t)le16(v)); return 2;
+            case 'S': out += std::to_string((unsigned)le16(v)); return 2;
+            case 'i': out += std::to_string((std::int32_t)le32(v)); return 4;
+            case 'I': out += std::to_string(le32(v)); return 4;
+            case 'f': { float f; const std::uint32_t u = le32(v); std::memcpy(&f, &u, 4); char buf[32]; std::snprintf(buf, sizeof(buf), "%g", (double)f); out += buf; return 4; }
+            default: return 0;
+        }
+    };
+    auto width = [](char type) -> std::size_t { return type == 'c' || type == 'C' ? 1 : type == 's' || type == 'S' ? 2 : type == 'i' || type == 'I' || type == 'f' ? 4 : 0; };
+    while (a + 3 <= end) {
+        line += '\t';
+        line += (char)a[0]; line += (char)a[1]; line += ':';
+        const char type = (char)a[2];
+        a += 3;
+        if (type == 'A') {
+            if (a + 1 > end) return false;
+            line += "A:"; line += (char)a[0]; a += 1;
+        } else if (type == 'Z' || type == 'H') {
+            line += type; line += ':';
+            while (a < end && *a != 0) line += (char)*a++;
+            if (a >= end) return false;
+            ++a;
+        } else if (type == 'B') {
+            if (a + 5 > end) return false;
+            const char sub = (char)a[0];
+            const std::size_t count = le32(a + 1), w = width(sub);
+            a += 5;
+            if (w == 0 || count > (std::size_t)(end - a) / w) return false;
+            line += "B:"; line += sub;
+            for (std::size_t k = 0; k < count; ++k) { line += ','; number(sub, a, line); a += w; }
+        } else {
+            const std::size_t w = width(type);
+            if (w == 0 || a + w > end) return false;
+            line += (type == 'f' ? "f:" : "i:");   // (SAM text has one integer type)
+            number(type, a, line);
+            a += w;
+        }
+    }
+    if (a != end) return false;
+    line += '\n';
+    return true;
+}
+
+// the header as SAM text: the BAM's text, and -- if it names no reference -- @SQ lines from the binary reference list
+// (what HTSlib's sam_hdr_write makes of such a header)
+std::string header_to_sam(const BamHeader& h) {
+    std::string t = h.text;
+    if (!t.empty() && t.back() != '\n') t += '\n';
+    if (t.find("@SQ\t") == std::string::npos)
+        for (const auto& r : h.references) t += "@SQ\tSN:" + r.first + "\tLN:" + std::to_string(r.second) + "\n";
+    return t;
 }
 
 // one alignment record: block_size then the block; false at the end of the file (err stays empty) or on error
@@ -358,25 +504,50 @@ std::uint32_t write_bam(const std::filesystem::path& input, const std::filesyste
     if (!in.open(input)) { set_err(err, "could not open " + input.string()); return UINT32_MAX; }
     BamHeader h;
     if (!read_header(in, h, err)) return UINT32_MAX;
+    // bam_api.cpp:564: `output_filepath.extension() == ".bam" ? "wb" : "w"` -- any other extension is SAM text
+    const bool as_bam = output.extension() == ".bam";
     BgzfWriter out;
-    if (!out.open(output)) { set_err(err, "could not open " + output.string()); return UINT32_MAX; }
-    if (!out.write(h.raw.data(), h.raw.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+    std::FILE* sam = nullptr;
+    std::string sam_buf;
+    if (as_bam) {
+        if (!out.open(output)) { set_err(err, "could not open " + output.string()); return UINT32_MAX; }
+        if (!out.write(h.raw.data(), h.raw.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+    } else {
+        sam = std::fopen(output.c_str(), "wb");
+        if (!sam) { set_err(err, "could not open " + output.string()); return UINT32_MAX; }
+        sam_buf = header_to_sam(h);
+    }
+    auto fail_sam = [&](const std::string& msg) { if (sam) std::fclose(sam); set_err(err, msg); return UINT32_MAX; };
     std::sort(bam_ids.begin(), bam_ids.end());   // bam_api.cpp:603
     auto next = bam_ids.begin();
     std::vector<unsigned char> rec;
-    std::string rec_err;
+    std::string rec_err, line;
     BAMReadId id = 0;
     std::uint32_t written = 0;
     while (next != bam_ids.end() && read_record(in, rec, &rec_err)) {
         if (id == *next) {
-            if (!out.write(rec.data(), rec.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+            if (as_bam) {
+                if (!out.write(rec.data(), rec.size())) { set_err(err, "write failed"); return UINT32_MAX; }
+            } else {
+                if (!record_to_sam(rec, h, line)) return fail_sam("BAM record with fields past its end");
+                sam_buf += line;
+                if (sam_buf.size() >= (std::size_t(1) << 20)) {
+                    if (std::fwrite(sam_buf.data(), 1, sam_buf.size(), sam) != sam_buf.size()) return fail_sam("write failed");
+                    sam_buf.clear();
+                }
+            }
             ++written;
             ++next;
         }
         ++id;
     }
-    if (!rec_err.empty()) { set_err(err, rec_err); return UINT32_MAX; }
-    if (!out.close()) { set_err(err, "closing " + output.string() + " failed"); return UINT32_MAX; }
+    if (!rec_err.empty()) { if (sam) std::fclose(sam); set_err(err, rec_err); return UINT32_MAX; }
+    if (as_bam) {
+        if (!out.close()) { set_err(err, "closing " + output.string() + " failed"); return UINT32_MAX; }
+    } else {
+        const bool ok = std::fwrite(sam_buf.data(), 1, sam_buf.size(), sam) == sam_buf.size();
+        if (std::fclose(sam) != 0 || !ok) { set_err(err, "closing " + output.string() + " failed"); return UINT32_MAX; }
+    }
     return written;
 }
 

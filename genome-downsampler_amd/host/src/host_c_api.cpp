@@ -244,6 +244,27 @@ int qmcp_host_check_bam(const char* path, std::uint64_t* n_reads, char* err, std
     return rc;
 }
 
+// BamApi::write_bam alone (bam_api.cpp:534-656): the header and the records whose running id is in `ids` (n of them;
+// sorted here, as the reference sorts them) copied to `out_path` -- BAM if it ends in ".bam", SAM text otherwise.
+// Returns the number of records written, -1 on failure (message in err, capacity cap).
+std::int64_t qmcp_host_copy_records(const char* in_path, const char* out_path, const std::uint64_t* ids, std::uint64_t n,
+                                    char* err, std::size_t cap) {
+    std::string msg;
+    std::int64_t rc = -1;
+    try {
+        std::vector<bam_api::BAMReadId> v(ids, ids + n);
+        const std::uint32_t written = bam_api::write_bam(in_path, out_path, v, &msg);
+        if (written != UINT32_MAX) rc = (std::int64_t)written;
+    } catch (const std::exception& e) {
+        msg = e.what();
+    }
+    if (err && cap) {
+        std::strncpy(err, msg.c_str(), cap - 1);
+        err[cap - 1] = 0;
+    }
+    return rc;
+}
+
 // The file-to-file flow of App::execute (src/app.cpp:113-151) for one solver: BamApi(path) -> solve ->
 // find_pairs -> write_paired_reads(out) (+ write_bam_api_filtered_out_reads(filtered) if given).
 // Returns the number of records written to `out_path`, negative on an unknown solver.

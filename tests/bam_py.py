@@ -105,3 +105,62 @@ def write_bam(path, references, records, text="@HD\tVN:1.6\tSO:unsorted\n", bloc
         for o in range(0, len(data), block_payload):
             f.write(_bgzf_block(data[o:o + block_payload]))
         f.write(BGZF_EOF)
+
+
+# ---------------------------------------------------------------- an independent SAM rendering (tests only)
+def parse_references(header):
+    """[(name, length)] from the header bytes `parse` returns"""
+    l_text, = struct.unpack_from("<I", header, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<I", header, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<I", header, o)
+        name = header[o + 4:o + 4 + l_name - 1].decode()
+        refs.append((name, struct.unpack_from("<I", header, o + 4 + l_name)[0]))
+        o += 8 + l_name
+    return refs
+
+
+def header_text(header):
+    l_text, = struct.unpack_from("<I", header, 4)
+    return header[8:8 + l_text].rstrip(b"\0").decode()
+
+
+def to_sam(raw, refs):
+    """one record (block_size included) as a SAM line without the newline (SAM specification sections 1.4, 4.2)"""
+    ref_id, pos, l_name, mapq, _bin, n_cigar, flag, l_seq, next_ref, next_pos, tlen = struct.unpack_from("<iiBBHHHIiii", raw, 4)
+    o = 36
+    qname = raw[o:o + l_name - 1].decode() or "*"
+    o += l_name
+    cig = struct.unpack_from(f"<{n_cigar}I", raw, o)
+    o += 4 * n_cigar
+    cigar = "".join(f"{v >> 4}{CIGAR_OPS[v & 0xF]}" for v in cig) or "*"
+    seq = "".join("=ACMGRSVTWYHKDBN"[(raw[o + i // 2] >> (0 if i % 2 else 4)) & 0xF] for i in range(l_seq)) or "*"
+    o += (l_seq + 1) // 2
+    q = raw[o:o + l_seq]
+    qual = "*" if l_seq == 0 or q[0] == 0xFF else "".join(chr(b + 33) for b in q)
+    o += l_seq
+    name_of = lambda i: refs[i][0] if 0 <= i < len(refs) else "*"
+    rnext = "*" if next_ref < 0 else ("=" if next_ref == ref_id else name_of(next_ref))
+    fields = [qname, str(flag), name_of(ref_id), str(pos + 1), str(mapq), cigar, rnext, str(next_pos + 1), str(tlen), seq, qual]
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+    while o < len(raw):
+        tag, typ = raw[o:o + 2].decode(), chr(raw[o + 2])
+        o += 3
+        if typ == "A":
+            fields.append(f"{tag}:A:{chr(raw[o])}"); o += 1
+        elif typ in "ZH":
+            e = raw.index(b"\0", o)
+            fields.append(f"{tag}:{typ}:{raw[o:e].decode()}"); o = e + 1
+        elif typ == "B":
+            sub = chr(raw[o]); count, = struct.unpack_from("<I", raw, o + 1); o += 5
+            w = struct.calcsize(fmt[sub])
+            vals = [struct.unpack_from(fmt[sub], raw, o + k * w)[0] for k in range(count)]
+            o += count * w
+            fields.append(f"{tag}:B:{sub}" + "".join("," + (f"{v:g}" if sub == "f" else str(v)) for v in vals))
+        else:
+            v, = struct.unpack_from(fmt[typ], raw, o); o += struct.calcsize(fmt[typ])
+            fields.append(f"{tag}:f:{v:g}" if typ == "f" else f"{tag}:i:{v}")
+    return "\t".join(fields)

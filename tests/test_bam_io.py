@@ -301,3 +301,94 @@ def test_file_with_soft_clipped_reads_takes_the_near_uniform_route(tmp_path):
         st = sv.last_stats
     assert np.array_equal(got, keep)
     assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_exceptions == int((clip > 0).sum()), st.as_dict()
+
+
+# ---------------------------------------------------------------- SAM text output, deflate on several threads
+def test_sam_text_when_the_extension_is_not_bam(tmp_path):
+    """BamApi::write_bam opens its output with "wb" for ".bam" and with "w" -- SAM text -- for anything else
+    (libs/bam-api/src/bam_api.cpp:564).  The committed two-reference BAM of another writer (unmapped mates, every CIGAR
+    operation, hard clips, aux tags of several types) copied to .sam: header text, then one line per chosen record, equal
+    to an independent rendering (tests/bam_py.py: to_sam) of an independent parse"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    src = os.path.join(GOLDEN, "tiny_other_writer.bam")
+    header, recs, _ = bam_py.parse(src)
+    refs = bam_py.parse_references(header)
+    ids = [0, 1, 3, 5, 7, 11, 12, 13]
+    out = tmp_path / "picked.sam"
+    assert pkg.copy_records(src, out, ids[::-1]) == len(ids)          # (the ids are sorted by the writer, as the reference does)
+    text = open(out).read()
+    want_header = bam_py.header_text(header)
+    assert text.startswith(want_header) and "@SQ\tSN:chrT\tLN:5000" in want_header
+    lines = text[len(want_header):].splitlines()
+    assert lines == [bam_py.to_sam(recs[i]["raw"], refs) for i in ids]
+    assert lines[0].split("\t")[11:] == ["NM:i:2", "RG:Z:grp1"] and lines[4].split("\t")[2:6] == ["*", "0", "0", "*"]
+    # ... and the same records as BAM: byte-identical records, header copied
+    outb = tmp_path / "picked.bam"
+    assert pkg.copy_records(src, outb, ids) == len(ids)
+    oh, orecs, _ = bam_py.parse(outb)
+    assert oh == header and [r["raw"] for r in orecs] == [recs[i]["raw"] for i in ids]
+
+
+def test_sam_lines_with_every_aux_type(tmp_path):
+    pkg = importlib.import_module("genome-downsampler_amd")
+    aux = (b"XAAq" + b"Xcc\xfe" + b"XCC\xfe" + b"Xss" + struct.pack("<h", -300) + b"XSS" + struct.pack("<H", 65000) +
+           b"Xii" + struct.pack("<i", -70000) + b"XII" + struct.pack("<I", 4_000_000_000) + b"Xff" + struct.pack("<f", 1.5) +
+           b"XZZtext with spaces\0" + b"XHH1AE301\0" + b"XBBs" + struct.pack("<I3h", 3, -1, 2, 300) +
+           b"XGBf" + struct.pack("<I2f", 2, 0.25, -8.0) + b"XEBC" + struct.pack("<I", 0))
+    recs = [bam_py.pack_record("r1", 0x63, 10, 60, [(4, "S"), (20, "M"), (2, "I"), (24, "M")], 50, next_ref=0, next_pos=200, tlen=240, aux=aux),
+            bam_py.pack_record("r1", 0x93, 200, 60, [(50, "=")], 50, next_ref=0, next_pos=10, tlen=-240)]
+    path = tmp_path / "aux.bam"
+    bam_py.write_bam(path, [("chrA", 1000)], recs)
+    out = tmp_path / "aux.txt"                                        # any extension but .bam
+    assert pkg.copy_records(path, out, [0, 1]) == 2
+    header, parsed, _ = bam_py.parse(path)
+    lines = open(out).read()[len(bam_py.header_text(header)):].splitlines()
+    assert lines == [bam_py.to_sam(r["raw"], [("chrA", 1000)]) for r in parsed]
+    assert "Xc:i:-2" in lines[0] and "XC:i:254" in lines[0] and "XI:i:4000000000" in lines[0] and "XB:B:s,-1,2,300" in lines[0]
+    assert lines[0].split("\t")[6:9] == ["=", "201", "240"] and lines[0].split("\t")[9] == "A" * 50
+
+
+def test_deflating_on_several_threads_writes_the_same_file(tmp_path, monkeypatch):
+    """BGZF blocks deflate on their own: batches of 64 blocks on up to 8 threads (QMCP_BAM_THREADS), written in order --
+    the reference hands its output file to HTSlib's thread pool (bam_api.cpp:569-586).  A file of several batches written
+    with one thread and with eight: the same bytes, and Python's gzip reads back the chosen records"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    rng = np.random.default_rng(5)
+    n_pairs = 120_000
+    n = 2 * n_pairs
+    names = np.repeat(np.arange(n_pairs), 2)[rng.permutation(n)]
+    flags = np.where(rng.random(n) < 0.5, 0x41, 0x81).astype(np.uint16)
+    src = tmp_path / "src.bam"
+    pkg.write_synthetic_bam(src, 1_000_000, names, flags, rng.integers(0, 900_000, size=n), rng.integers(0, 61, size=n),
+                            np.zeros(n, np.uint32), rng.integers(50, 151, size=n), np.zeros(n, np.uint32), np.zeros(n, np.uint32))
+    ids = np.flatnonzero(rng.random(n) < 0.8)
+    monkeypatch.setenv("QMCP_BAM_THREADS", "1")
+    assert pkg.copy_records(src, tmp_path / "one.bam", ids) == ids.size
+    monkeypatch.setenv("QMCP_BAM_THREADS", "8")
+    assert pkg.copy_records(src, tmp_path / "eight.bam", ids) == ids.size
+    one, eight = open(tmp_path / "one.bam", "rb").read(), open(tmp_path / "eight.bam", "rb").read()
+    assert one == eight
+    _, recs, _ = bam_py.parse(src)
+    _, got, _ = bam_py.parse(tmp_path / "eight.bam")
+    assert [r["raw"] for r in got] == [recs[i]["raw"] for i in ids.tolist()]
+    assert sum(len(r["raw"]) for r in got) > 3 * 64 * 0xFF00      # several batches of 64 blocks
+
+
+@pytest.mark.gpu
+def test_file_to_file_downsampling_to_sam_text(tmp_path):
+    """App::execute's flow on files with `-o out.sam`: the kept pairs' records as SAM lines, in file order"""
+    import oracle_py
+    pkg, path, L = _synthetic(tmp_path, n_pairs=5000, L=4_000, seed=21, triples=False)
+    header, recs, _ = bam_py.parse(path)
+    reads = pkg.read_bam(path)
+    M = 30
+    out = tmp_path / "out.sam"
+    written = pkg.downsample_bam("quasi-mcp-hip", path, out, M)
+    mask = oracle_py.find_pairs(oracle_py.solve(reads["starts"], reads["ends"], L, M), reads["starts"].size)
+    kept_ids = np.sort(reads["bam_ids"][pkg.mask_to_indices(mask, reads["starts"].size).astype(np.int64)])
+    text = open(out).read()
+    want_header = bam_py.header_text(header)
+    assert text.startswith(want_header)
+    refs = bam_py.parse_references(header)
+    assert written == kept_ids.size
+    assert text[len(want_header):].splitlines() == [bam_py.to_sam(recs[i]["raw"], refs) for i in kept_ids.tolist()]
