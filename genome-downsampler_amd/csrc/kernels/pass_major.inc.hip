@@ -605,11 +605,12 @@ __global__ __launch_bounds__(1024) void k_pm_walk(const uint16_t* __restrict__ k
     auto desc_offset = [&](uint32_t c) -> uint32_t {  // byte offset of the wave's descriptor of chunk c (the range's last beyond it: never used)
         return (g0 + min(16u * c + w, n_ws - 1u)) * 4u;
     };
-    auto slot_of = [&](uint32_t dsc_v, uint32_t c) -> Slot {
+    auto slot_of = [&](uint32_t dsc, uint32_t c) -> Slot {
         const bool has = 16u * c + w < n_ws;  // uniform
-        // (every lane holds the same word: through the scalar unit, whose instructions do not take the vector unit's slots)
-        const uint32_t dsc = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsc_v);
-        const PmSlot at = pm_unpack<false>(dsc, has, stride);
+        // (on the vector unit, although every lane holds the same word: through v_readfirstlane and the scalar unit --
+        //  fewer vector instructions -- the walk took 0.285 instead of 0.255 ms at cfg4: the scalar chain's dependent
+        //  multi-cycle instructions sit in front of the requests for the chunk seven steps ahead)
+        const PmSlot at = pm_unpack<true>(dsc, has, stride);
         Slot s;
         s.slot0 = at.slot0;
         s.nv = at.nv;
