@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
 # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction), keyed by workload
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic_{workload}_inflight{depth}.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic_{workload}_inflight{depth}.json")
 
 WORKLOADS = {
     # name: (contigs per GPU, pairs per contig, contig length, read length, M)
@@ -509,8 +509,11 @@ def main():
                 "rccl_ranks": rccl_info,
                 "solves_in_flight_per_gpu": depth,
                 "reads_per_gpu": int(n_reads), "contigs_per_gpu": n_contigs, "max_coverage": M,
-                "path": {1: "uniform-span block sweep", 2: "mixed-span event sweep"}.get(st.path),
+                "path": {1: "uniform-span sweep", 2: "mixed-span event sweep", 3: "near-uniform route"}.get(st.path),
                 "kept_reads_per_gpu": int(st.n_kept),
+                # the selection chain's serial work (event-driven sweep): blocks that changed the kept profile cost
+                # ~170 instructions of one wave each, sixteen blocks tested without a change ~60
+                "sweep_blocks_changed": int(st.sweep_blocks_changed), "sweep_blocks": int(st.sweep_blocks),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2),

@@ -30,6 +30,10 @@ KERNEL_WIDTHS = {
     "k_pm_prepare_sort": ("read_4", "write_4"),   # dword loads of starts and ends; dword stores of two 16-bit records
     "k_pm_offsets": ("read_8", "write_4"),        # 8-byte loads of four u16 keys; dword stores of bucket offsets
     "k_pm_rank_mark": ("read_2", "atomic_or64"),  # two u16 record streams; 64-bit atomic ORs
+    "k_pm_descr": ("read_4", "write_4"),          # dword loads of the two tables; dword stores of descriptors
+    "k_pm_range_table": ("read_4", "write_4"),
+    "k_pm_walk": ("read_2", "atomic_or64"),       # two u16 record streams (+ dword descriptors, quota gathers); 64-bit atomic ORs, 64 per instruction
+    "k_pm_settle": ("read_2", "atomic_or64"),
     "k_sweep_pack": ("read_4", "write_16"),
     "k_sweep_uniform_ev": ("read_16", "write_4"),
     "k_sweep_expand": ("read_4", "write_4"),
