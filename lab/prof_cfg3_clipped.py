@@ -16,6 +16,6 @@ for _ in range(2):
 sv.set_profiling(1)
 st = sv.solve_device(dS.data_ptr(), dE.data_ptr(), S.size, L, 200, dM.data_ptr())
 d = st.as_dict()
-print("ms_total %.3f path %d passes %d stretches %d spec %d/%d" % (d["ms_total"], d["path"], d["sort_passes"], d["sweep_stretches"], d["spec_boundaries"], d["spec_mismatches"]))
+print("ms_total %.3f path %d passes %d stretches %d spec %d/%d giveup %d exceptions %d selected %d rounds %d" % (d["ms_total"], d["path"], d["sort_passes"], d["sweep_stretches"], d["spec_boundaries"], d["spec_mismatches"], d["near_uniform_giveup"], d["near_uniform_exceptions"], d["near_uniform_selected"], d["near_uniform_rounds"]))
 for name, (n, ms) in sorted(sv.kernel_times().items(), key=lambda kv: -kv[1][1]):
     print("   %-45s %3d x %9.4f ms" % (name, n, ms / n))
