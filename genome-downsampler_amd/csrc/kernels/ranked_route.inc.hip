@@ -549,9 +549,7 @@ __global__ __launch_bounds__(1024) void k_rank_mark(const uint16_t* __restrict__
         __syncthreads();  // every q_after is read before the next chunk draws
 #pragma unroll
         for (int u = 0; u < kRankU; ++u) {
-#ifndef QMCP_LAB_NO_MASK_ATOMIC  // (lab: what the walk costs without its mask writes -- wrong masks)
             if (keep[u]) { const uint32_t v = r.val[u]; atomicOr(&mask[v >> 6], 1ull << (v & 63u)); }
-#endif
             kept += (uint32_t)__popcll(__ballot(keep[u]));
         }
     };
