@@ -22,13 +22,19 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     if (!run.may_rank || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
         depth < min_depth || min_span == 0)
         return QMCP_OK;
-    {
-        // The route's sweep is one chain per contig (the event-driven form).  On data deeper than 11 x M that is what
-        // the one-span route runs too; shallower, the one-span and mixed-span routes split contigs into stretches, and a
-        // whole chain per round only pays while contigs are short (cfg4's 10^6 positions at 1.5 x M: 7 ms a sweep).
+    // Which sweep the rounds run.  Deeper than 11 x M: one chain per contig in the event-driven form -- what the one-span
+    // route runs there too -- restarted from its checkpoints.  Shallower (round 4): the block-scan pipeline in STRETCHES,
+    // as the one-span route does -- real cut points (coverage of ALL reads <= M: every read over them is kept in every
+    // round, whatever has been selected) and speculative boundaries checked on the device (uniform_sweep.inc.hip) -- with
+    // the need moved by nadj; every round sweeps everything (hundreds of short chains side by side: a whole chain per
+    // contig was 7 ms a sweep for cfg4's 10^6 positions at 1.5 x M, and long shallow contigs did not take the route).
+    bool stretches = depth < kGenDepth && qmcp::sweep_uniform_mw_supported(ell);
+    if (c->opt.sweep == QMCP_SWEEP_EVENTS) stretches = false;
+    if (c->opt.sweep == QMCP_SWEEP_GENERAL) stretches = qmcp::sweep_uniform_mw_supported(ell);
+    if (!stretches) {
         uint32_t longest = 0;
         for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
-        if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;
+        if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;  // (spans the pipeline does not take: a whole chain per round)
     }
     if (c->nu_failed_n == run.n64 && c->nu_failed_ltot == pr.ltot && c->nu_failed_ell == ell && c->nu_failed_M == M) {
         local.near_uniform_giveup = QMCP_NU_GIVEUP_REMEMBERED;
@@ -76,8 +82,10 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         return QMCP_OK;
     }
     // scratch of the event-driven sweep (launch_uniform_sweep)
-    TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ell, n_contigs + 768)));
-    TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ell, n_contigs + 768)));
+    if (!stretches) {
+        TRY(ensure(c, c->evpk, qmcp::sweep_ev_pack_bytes(ltot, ell, n_contigs + 768)));
+        TRY(ensure(c, c->evlast, qmcp::sweep_ev_last_bytes(ltot, ell, n_contigs + 768)));
+    }
     const uint32_t* boff = (const uint32_t*)c->boff.p;
     const uint64_t* poff = (const uint64_t*)c->poff.p;
     uint32_t* selend = (uint32_t*)c->selend.p;
@@ -87,7 +95,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     unsigned long long* viol_key = (unsigned long long*)((char*)c->nu_state.p + 64);
     uint32_t* viol_idx = (uint32_t*)(viol_key + n_contigs);
     uint32_t* sweep_from[2] = {viol_idx + n_contigs, viol_idx + 2 * (size_t)n_contigs};  // this round's, the next round's
-    TRY(ensure(c, c->nu_ckpt, qmcp::sweep_ev_ckpt_bytes(ltot, ell, n_contigs + 768)));
+    if (!stretches) TRY(ensure(c, c->nu_ckpt, qmcp::sweep_ev_ckpt_bytes(ltot, ell, n_contigs + 768)));
     HIP_TRY(hipMemsetAsync(sweep_from[0], 0, (size_t)n_contigs * sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(c->ev[EV_SCAN], st));
     HIP_TRY(hipEventRecord(c->ev[EV_SORT], st));
@@ -96,6 +104,24 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         qmcp::launch_nu_setup(st, exc, cap, n_exc, d_stats + 6, boff, ltot, ell, M, (uint32_t*)c->nu_ce.p, (uint32_t*)c->spine.p,
                               nadj, state);
     }
+    // stretches: the exact table once (the cut points do not move between rounds), the speculative ones per sweep
+    const uint32_t* seg = nullptr;
+    uint32_t n_seg_max = 0, windows = 0;
+    bool speculate = false;
+    const uint32_t burn_blocks = spec_first_run_in(c, depth);
+    if (stretches) {
+        windows = sweep_cut_windows(c, ltot, ell, n_contigs, true);
+        if (windows != 0) {
+            KernelSpan sp(c, "k_find_cuts", st);
+            seg = qmcp::launch_sweep_segments(st, boff, nullptr, poff, n_contigs, ltot, ell, M, windows, (uint32_t*)c->segs.p,
+                                              (const uint32_t*)c->nu_ce.p);
+            n_seg_max = n_contigs + windows;
+        }
+        speculate = spec_wanted(c, depth) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
+    }
+    // later rounds sweep only the exact stretches a selection of the round before touched (k_nu_select_apply marks them)
+    uint32_t* marks[2] = {(uint32_t*)((char*)c->nu_sus.p + qmcp::nu_suspect_bytes(kNuSuspects)), nullptr};
+    marks[1] = marks[0] + 4096;
     // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
     // all settled is eight launches that return at once (the chain sweeps nothing, the verification skips every
     // exception: ~0.1 ms), about what one more host round trip costs; measured at cfg4 with 1 % clipped reads (7 rounds),
@@ -107,6 +133,26 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         const uint32_t batch = 2u;
         for (uint32_t r = 0; r < batch; ++r) {
             ++rounds;
+            if (stretches) {
+                if (speculate) {
+                    TRY(speculative_sweep(
+                        c, st, n_contigs, ltot, windows, ell, ell, burn_blocks, 4, seg, "k_sweep_uniform_gen",
+                        [&](const uint32_t* table, uint32_t* run_in_out, const uint32_t* redo_in) {
+                            return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, ell, M, ltot, selend, d_iters, table,
+                                                                  n_seg_max, run_in_out, redo_in, nadj);
+                        },
+                        [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
+                            qmcp::launch_spec_verify(st, table, n_seg_max, ell, selend, (const uint32_t*)c->cstart.p, mismatches,
+                                                     redo_in, redo_out);
+                        },
+                        rounds == 1 ? nullptr : marks[0]));
+                } else {
+                    KernelSpan sp(c, "k_sweep_uniform_gen", st);
+                    if (!qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, ell, M, ltot, selend, d_iters, seg, n_seg_max,
+                                                        nullptr, (seg != nullptr && rounds > 1) ? marks[0] : nullptr, nadj))
+                        return fail(QMCP_ERANGE, "near-uniform route: span %u not supported", ell);
+                }
+            } else {
             {
                 KernelSpan sp(c, "k_sweep_pack", st);
                 qmcp::launch_sweep_ev_pack(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (uint32_t*)c->evpk.p, nadj, sweep_from[0]);
@@ -122,11 +168,14 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                 qmcp::launch_sweep_ev_expand(st, boff, poff, n_contigs, ell, M, ltot, nullptr, 0, (const uint32_t*)c->cstart.p,
                                              (const uint32_t*)c->evlast.p, selend, sweep_from[0]);
             }
+            }
             {
                 KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
                 qmcp::launch_nu_round(st, exc, cap, n_exc, d_stats + 6, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
-                                      (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1]);
+                                      (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1],
+                                      ltot, (uint32_t*)c->spine.p, stretches ? seg : nullptr, n_seg_max, marks[1]);
                 std::swap(sweep_from[0], sweep_from[1]);
+                std::swap(marks[0], marks[1]);
             }
         }
         HIP_TRY(hipGetLastError());

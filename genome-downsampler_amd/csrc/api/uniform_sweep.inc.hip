@@ -60,7 +60,9 @@ SpecWords spec_words(qmcp_hip_ctx* c) {
 template <class Sweep, class Check>
 int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint32_t ltot, uint32_t windows,
                       uint32_t unit, uint32_t round_to, uint32_t burn_blocks, uint32_t run_ins_apart,
-                      const uint32_t* seg_exact, const char* sweep_name, Sweep sweep, Check check) {
+                      const uint32_t* seg_exact, const char* sweep_name, Sweep sweep, Check check,
+                      const uint32_t* only_marked = nullptr /* per exact stretch: the parts of the genome to sweep at all
+                                                               (the near-uniform route's later rounds); null: everything */) {
     const SpecWords w = spec_words(c);
     const uint64_t* poff = (const uint64_t*)c->poff.p;
     const uint32_t n_cand = n_contigs + windows;
@@ -84,11 +86,11 @@ int speculative_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n_contigs, uint3
     uint32_t* second_out = (uint32_t*)c->cstart.p;
     {
         KernelSpan sp(c, sweep_name, st);
-        if (!sweep(seg1, second_out, nullptr)) return fail(QMCP_ERANGE, "speculative sweep: span not supported");
+        if (!sweep(seg1, second_out, only_marked)) return fail(QMCP_ERANGE, "speculative sweep: span not supported");
     }
     {
         KernelSpan sp(c, "k_spec_verify + k_spec_merge", st);
-        check(seg1, w.mismatches1, nullptr, redo1);
+        check(seg1, w.mismatches1, only_marked, redo1);
     }
     {
         KernelSpan sp(c, "second tier, where the first disagreed", st);

@@ -120,11 +120,11 @@ size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows) {
 // fills seg_words: [windows' cuts | count, stretches]; returns the table the sweep launchers take
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
                                       const uint64_t* d_poff, uint32_t n_contigs, uint32_t ltot, uint32_t ell,
-                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words) {
+                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words, const uint32_t* other_cov) {
     uint32_t* cut = seg_words;
     uint32_t* seg = seg_words + n_windows;
     const uint32_t win = (ltot + n_windows - 1) / n_windows;
-    hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, eoff, d_poff, n_contigs, ltot, ell, M, win, cut);
+    hipLaunchKernelGGL(k_find_cuts, dim3(n_windows), dim3(256), 0, st, boff, eoff, d_poff, n_contigs, ltot, ell, M, win, cut, other_cov);
     hipLaunchKernelGGL(k_build_segments, dim3(1), dim3(kSegThreads), 0, st, cut, n_windows, d_poff, n_contigs,
                        ltot, win, 0u, 1u, seg, (uint32_t*)nullptr);
     return seg;
@@ -190,16 +190,20 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_run_in, const uint32_t* redo_in) {
+                              uint32_t* selend_run_in, const uint32_t* redo_in, const int32_t* nadj) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
-#define QMCP_SWEEP_GEN(EE)                                                                             \
+#define QMCP_SWEEP_GEN_K(EE, ADJ)                                                                      \
     {                                                                                                   \
         const size_t lds = MgLayout<EE>::kBytes;                                                        \
-        (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE>,                                 \
+        (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE, ADJ>,                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(k_sweep_uniform_gen<EE>, dim3(n_wg), dim3(448), lds, st, boff, d_poff,      \
-                           ell, M, ltot, selend, iter_stats, seg, selend_run_in, redo_in, n_seg_max);        \
+        hipLaunchKernelGGL((k_sweep_uniform_gen<EE, ADJ>), dim3(n_wg), dim3(448), lds, st, boff, d_poff, \
+                           ell, M, ltot, selend, iter_stats, seg, selend_run_in, redo_in, n_seg_max, nadj);  \
+    }
+#define QMCP_SWEEP_GEN(EE)                                                                             \
+    {                                                                                                   \
+        if (nadj != nullptr) QMCP_SWEEP_GEN_K(EE, true) else QMCP_SWEEP_GEN_K(EE, false)               \
     }
     switch (e) {
         case 1: QMCP_SWEEP_GEN(1); break;
@@ -209,6 +213,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
         default: return false;
     }
 #undef QMCP_SWEEP_GEN
+#undef QMCP_SWEEP_GEN_K
     return true;
 }
 

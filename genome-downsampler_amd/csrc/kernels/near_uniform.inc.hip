@@ -167,10 +167,28 @@ __device__ __forceinline__ bool nu_exhausted(const NuView& v, int32_t u, int32_t
     return u < c0 || nu_S(v, (uint32_t)u) == nu_c(v, (uint32_t)u);
 }
 
+// The round's suspects binned by start position (round 4: a replay needs the listed exceptions whose lives overlap its
+// own, and looked through the whole list for them -- 16 ms a round at 20 k suspects on two 10^7-position contigs): cells
+// of 2^shift positions, counted by k_nu_verify, scanned, filled by k_nu_bin; a replay reads the cells over (s - ell, e].
+struct NuBins {
+    uint32_t* count;   // n_cells + 1 words: suspects per cell, then (zeroed again) the fill counters
+    uint32_t* start;   // n_cells + 2: exclusive scan of count
+    uint32_t* sorted;  // suspects_cap: slots of the suspects list, by cell
+    uint32_t shift, n_cells;
+};
+__device__ __forceinline__ uint32_t nu_cell(const NuBins& b, uint32_t pos) { return min(pos >> b.shift, b.n_cells - 1u); }
+__host__ inline uint32_t nu_bin_shift(uint32_t ltot) {
+    uint32_t shift = 8;
+    while (((uint64_t)ltot >> shift) + 1 > (1u << 17)) ++shift;
+    return shift;
+}
+static constexpr uint32_t kNuMaxCells = (1u << 17) + 1;
+
 // suspects: {exception, contig} pairs
 __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                    uint32_t* __restrict__ state,
-                                                   const uint32_t* __restrict__ swept_from /* per contig: the first block this round swept */) {
+                                                   const uint32_t* __restrict__ swept_from /* per contig: the first block this round swept */,
+                                                   NuBins bins) {
     if (state[7] == 0u) return;  // (no contig was swept this round: every one is settled)
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
         const uint32_t i = x.dense[j];
@@ -189,8 +207,12 @@ __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __r
             if (!reach) continue;
         }
         const uint32_t slot = atomicAdd(&state[4], 1u);
-        if (slot < suspects_cap) suspects[slot] = make_uint2(i, contig);
-        else atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
+        if (slot < suspects_cap) {
+            suspects[slot] = make_uint2(i, contig);
+            atomicAdd(&bins.count[nu_cell(bins, (uint32_t)s)], 1u);
+        } else {
+            atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
+        }
         x.key[i] = kNuNoKey;
     }
 }
@@ -198,13 +220,34 @@ __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __r
 // One wave per suspect.  Everything the replay reads -- bucket offsets, the sweep's result and nadj over
 // [s - 2 ell, e + 1] -- is staged in LDS first (a trip to memory per replayed position would make an exception in a
 // contig's last ell positions, where every bucket is empty and the run is as long as the read, cost half a millisecond).
-static constexpr int kNuStage = 3 * 256 + 16;  // ell <= 256 (the event-driven sweep's limit)
-static constexpr int kNuCur = 3 * 256 + 8;  // replayed buckets: from an anchor < 2 ell, from a cut point < 3 ell
+__global__ __launch_bounds__(256) void k_nu_bin(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
+                                                const uint32_t* __restrict__ state, NuBins bins) {
+    const uint32_t n_sus = min(state[4], suspects_cap);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+        const uint32_t cell = nu_cell(bins, x.gs[suspects[q].x]);
+        bins.sorted[bins.start[cell] + atomicAdd(&bins.count[cell], 1u)] = q;
+    }
+}
+
+// How far below a read the replay looks for a state to start from (an anchor or a cut point), in spans.  One span nearly
+// always does; shallow data (1.5 x M: stretches where nearly everything is kept) has runs of used-up buckets longer than
+// that -- the replay is the same from any distance (nothing below an anchor is picked at or after the anchor's time), so a
+// read whose run has nothing within one span is staged again with kNuReach spans (round 4; tests/near_uniform_model.py
+// REACH: at 1.5 x M two of ten cases settled with one span, all ten with six).
+static constexpr int kNuReach = 6;
+// staged positions [s - (reach + 1) ell, e + 1] and replayed buckets: (kNuReach + 2) ell + 16 entries each, dynamic LDS
+__host__ __device__ constexpr uint32_t nu_stage_entries(uint32_t ell) { return (uint32_t)(kNuReach + 2) * ell + 16u; }
 __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                   uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
-                                                  const uint32_t* __restrict__ swept_from) {
-    __shared__ uint32_t s_b[kNuStage], s_e[kNuStage], s_x[kNuStage];
-    __shared__ int32_t s_a[kNuStage], s_cur[kNuCur], s_stack[kNuCur];
+                                                  const uint32_t* __restrict__ swept_from, NuBins bins) {
+    extern __shared__ uint32_t s_nu_dyn[];
+    const int32_t kNuStage = (int32_t)nu_stage_entries(v.ell), kNuCur = kNuStage;
+    uint32_t* const s_b = s_nu_dyn;
+    uint32_t* const s_e = s_b + kNuStage;
+    uint32_t* const s_x = s_e + kNuStage;
+    int32_t* const s_a = reinterpret_cast<int32_t*>(s_x + kNuStage);
+    int32_t* const s_cur = s_a + kNuStage;
+    int32_t* const s_stack = s_cur + kNuStage;
     __shared__ int32_t o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers], o_above[kNuOthers];
     __shared__ uint32_t o_n;
     const int32_t lane = (int32_t)threadIdx.x;
@@ -219,24 +262,33 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         // listed for the others' sake only (it ends before what the round swept: its own questions were settled by an
         // earlier round, on counts that have not changed since)
         if ((uint64_t)(uint32_t)(e - c0) < (uint64_t)swept_from[contig] * v.ell) continue;
-        const int32_t r0 = max(s - 2 * ell, 0);
-        const int32_t count = e + 1 - r0 + 1;  // <= 3 ell + 1
-        __syncthreads();  // (the previous suspect's reads of the stage are done)
-        for (int32_t k = lane; k < count && k < kNuStage; k += 64) {
-            s_b[k] = v.boff[r0 + k];
-            s_e[k] = v.selend[r0 + k];
-            s_a[k] = v.nadj[r0 + k];
-            s_x[k] = v.ce[r0 + k + 1];
-        }
-        for (int32_t k = lane; k < kNuCur; k += 64) s_cur[k] = 0;
+        int32_t r0 = 0;
+        auto stage = [&](int32_t reach) {
+            r0 = max(s - (reach + 1) * ell, 0);
+            const int32_t count = e + 1 - r0 + 1;  // <= (reach + 2) ell + 1
+            __syncthreads();  // (the previous suspect's -- or the first go's -- reads of the stage are done)
+            for (int32_t k = lane; k < count && k < kNuStage; k += 64) {
+                s_b[k] = v.boff[r0 + k];
+                s_e[k] = v.selend[r0 + k];
+                s_a[k] = v.nadj[r0 + k];
+                s_x[k] = v.ce[r0 + k + 1];
+                s_cur[k] = 0;
+            }
+            for (int32_t k = count + lane; k < count + 16 && k < kNuCur; k += 64) s_cur[k] = 0;
+            __syncthreads();
+        };
+        stage(1);
         if (lane == 0) o_n = 0;
         __syncthreads();
         // the other listed exceptions of the contig whose lives overlap this one's: {start, end, selection time or -1,
         // outranks this one}
         const uint32_t my_idx = x.idx[i];
         const int32_t sel = x.pick[i] == kNuUnpicked ? -1 : (int32_t)x.pick[i];
-        for (uint32_t j = (uint32_t)lane; j < n_sus; j += 64u) {
-            const uint2 z = suspects[j];
+        // (an overlapping life starts in (s - ell, e]: spans are at most ell)
+        const uint32_t j0 = bins.start[nu_cell(bins, (uint32_t)max(s - ell + 1, 0))];
+        const uint32_t j1 = bins.start[nu_cell(bins, (uint32_t)e) + 1u];
+        for (uint32_t j = j0 + (uint32_t)lane; j < j1; j += 64u) {
+            const uint2 z = suspects[bins.sorted[j]];
             if (z.y != contig || z.x == i) continue;
             const int32_t zs = (int32_t)x.gs[z.x], ze = (int32_t)x.ge[z.x];
             if (ze < s || zs > e) continue;
@@ -262,19 +314,24 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         };
         // the run of exhausted buckets downwards from b; its anchor u1 - 1 is the first bucket that keeps members for
         // good (or lies before the contig): nothing below it is picked at or after its own time
-        int32_t u1 = b + 1;
-        while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < ell) --u1;
-        // No anchor within ell buckets: a CUT POINT does as well.  At a position p with cov_all(p) <= M every read
-        // covering it is kept, so at time p every bucket in (p - ell, p] is used up -- a known state to start from.
-        int32_t cut = -1;
-        if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
-            for (int32_t p = s - 1; p > s - ell && p >= c0; --p) {
-                const uint32_t cov_reg = s_b[p + 1 - r0] - s_b[max(p + 1 - ell, 0) - r0];
-                if (cov_reg + s_x[p - r0] <= v.M) { cut = p; break; }
+        int32_t u1 = b + 1, cut = -1;
+        for (int32_t reach = 1;; reach = kNuReach) {
+            u1 = b + 1;
+            while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < reach * ell) --u1;
+            // No anchor within reach: a CUT POINT does as well.  At a position p with cov_all(p) <= M every read
+            // covering it is kept, so at time p every bucket in (p - ell, p] is used up -- a known state to start from.
+            cut = -1;
+            if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
+                for (int32_t p = s - 1; p > s - reach * ell && p >= c0; --p) {
+                    const uint32_t cov_reg = s_b[p + 1 - r0] - s_b[max(p + 1 - ell, 0) - r0];
+                    if (cov_reg + s_x[p - r0] <= v.M) { cut = p; break; }
+                }
             }
+            if (!(cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) || reach == kNuReach) break;
+            stage(kNuReach);  // (rare: everything again, from further down)
         }
         if (cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) {
-            // ell exhausted buckets in a row below the read: not modelled.  That only matters if nothing EARLIER in the
+            // kNuReach spans of exhausted buckets in a row below the read: not modelled.  That only matters if nothing EARLIER in the
             // contig is wanted: behind a wanted exception the sweep ran on a need it could not meet, and what it left
             // there (often every bucket used up) is replaced by the next round's sweep anyway.  So the read enters the
             // contig's contest with a key of its own -- its release time, lowest priority -- and the route gives up
@@ -399,7 +456,11 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
                                                           uint32_t* __restrict__ state, const unsigned long long* __restrict__ viol_key,
                                                           int32_t* __restrict__ nadj,
                                                           const uint64_t* __restrict__ poff, uint32_t ell,
-                                                          uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */) {
+                                                          uint32_t* __restrict__ sweep_from /* per contig, preset to "settled" */,
+                                                          const uint32_t* __restrict__ seg_exact /* sweeps in stretches: the exact
+                                                              table [count, {start, end, contig end}...]; or null */,
+                                                          uint32_t* __restrict__ marks_next /* per exact stretch, zeroed: 1 = the
+                                                              next round's sweep must cover it */) {
     const uint32_t n_sus = min(state[4], suspects_cap);
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
         const uint2 su = suspects[q];
@@ -425,6 +486,20 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
         // entering the block two before t's is still the chain's (the chain keeps it at every 64th block)
         const uint32_t kt = (t - (uint32_t)poff[su.y]) / ell;
         atomicMin(&sweep_from[su.y], (kt >= 2u ? kt - 2u : 0u) & ~63u);
+        if (seg_exact != nullptr) {
+            // the need changes on [min(t, old), e] and the kept counts from the bucket above t - ell on, up to the end of
+            // the exact stretch (behind a cut point the sweep starts afresh): every exact stretch that meets
+            // [t - ell + 1, e] is swept again
+            const uint32_t c0 = (uint32_t)poff[su.y];
+            const uint32_t first = min(t, old), lo = first - c0 >= ell ? first - ell + 1u : c0;
+            const uint32_t count = seg_exact[0];
+            uint32_t a = 0, b = count;  // last stretch with start <= lo (the table is in position order)
+            while (b - a > 1) {
+                const uint32_t mid = (a + b) >> 1;
+                if (seg_exact[1 + 3 * mid] <= lo) a = mid; else b = mid;
+            }
+            for (uint32_t r = a; r < count && seg_exact[1 + 3 * r] <= e; ++r) marks_next[r] = 1u;
+        }
         atomicAdd(&state[1], 1u);
     }
 }
@@ -477,21 +552,40 @@ void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_need_adjust, dim3(grid_for((uint64_t)ltot + 1, 256)), dim3(256), 0, st, boff, ce, ltot, ell, M, nadj);
     hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
 }
+size_t nu_suspect_bytes(uint32_t suspects_cap) {  // the list, its slots by cell, the cells' counts and starts
+    return (size_t)suspects_cap * (sizeof(uint2) + sizeof(uint32_t)) + 2 * ((size_t)kNuMaxCells + 3) * sizeof(uint32_t);
+}
 void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
-                     unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next) {
+                     unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next,
+                     uint32_t ltot, uint32_t* spine, const uint32_t* seg_exact, uint32_t n_cand, uint32_t* marks_next) {
     const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
     v.ce = ce;
+    NuBins bins;
+    bins.shift = nu_bin_shift(ltot);
+    bins.n_cells = (uint32_t)(((uint64_t)ltot >> bins.shift) + 1);
+    bins.sorted = reinterpret_cast<uint32_t*>(suspects + suspects_cap);
+    bins.count = bins.sorted + suspects_cap;
+    bins.start = bins.count + kNuMaxCells + 3;
     hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs,
                        first_round ? 1u : 0u);
+    (void)hipMemsetAsync(bins.count, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
+    if (seg_exact != nullptr) (void)hipMemsetAsync(marks_next, 0, (size_t)n_cand * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
-                       swept_from);
-    hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), 0, st, x, v, suspects, suspects_cap, state, viol_key, swept_from);
+                       swept_from, bins);
+    launch_exclusive_scan(st, bins.count, bins.n_cells + 1, bins.start, spine, false);
+    (void)hipMemsetAsync(bins.count, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_nu_bin, dim3(64), dim3(256), 0, st, x, suspects, suspects_cap, state, bins);
+    {
+        const size_t lds = 6 * (size_t)nu_stage_entries(ell) * sizeof(uint32_t);  // (ell <= 256: the sweeps' limit)
+        (void)hipFuncSetAttribute((const void*)k_nu_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), lds, st, x, v, suspects, suspects_cap, state, viol_key, swept_from, bins);
+    }
     hipLaunchKernelGGL(k_nu_select_apply, dim3(64), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
-                       sweep_from_next);
+                       sweep_from_next, seg_exact, marks_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, unsigned long long* kept_total) {

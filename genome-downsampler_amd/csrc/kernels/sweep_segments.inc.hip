@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ eoff,  // null: one span, ell
                                                    const uint64_t* __restrict__ contig_pos_off,
                                                    uint32_t n_contigs, uint32_t ltot, uint32_t ell, uint32_t M,
-                                                   uint32_t win, uint32_t* __restrict__ cut) {
+                                                   uint32_t win, uint32_t* __restrict__ cut,
+                                                   const uint32_t* __restrict__ other_cov /* near-uniform route: reads that are
+                                                       not in boff (the listed exceptions) covering position q - 1 =
+                                                       other_cov[q]; a cut needs the coverage of ALL reads <= M.  Or null */) {
     __shared__ uint32_t s_first;
     __shared__ uint32_t s_cstart[256];  // contig starts (fewer than 256 contigs when this runs)
     const uint32_t w = blockIdx.x;
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint32_t* __restrict__ 
             const uint32_t q = q0 + k * blockDim.x + threadIdx.x;
             if (q < hi) {
                 // coverage of position q - 1: starts up to it minus ends before it
-                const uint32_t cov = boff[q] - (eoff != nullptr ? eoff[q - 1] : boff[q >= ell ? q - ell : 0u]);
+                const uint32_t cov = boff[q] - (eoff != nullptr ? eoff[q - 1] : boff[q >= ell ? q - ell : 0u]) +
+                                     (other_cov != nullptr ? other_cov[q] : 0u);
                 if (cov <= M) {
                     bool contig_start = false;
                     for (uint32_t c = 0; c < n_contigs; ++c) contig_start |= s_cstart[c] == q;

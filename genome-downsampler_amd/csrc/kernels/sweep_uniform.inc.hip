@@ -144,6 +144,26 @@ __device__ __forceinline__ void block_terms(const SweepLoads<E>& cur, uint32_t a
     }
 }
 
+// The near-uniform route's sweep in stretches (round 4): the need at the landing position is moved by nadj and capped at
+// what the regular reads can give -- need' = min(min(cov, M) + nadj, cov), ex' = cov - need' -- exactly what the
+// event-driven form does with it (k_sweep_uniform_ev); adj[r] = nadj at the slot's landing position p + ell.
+__device__ __forceinline__ uint32_t ex_adjusted(uint32_t cov, uint32_t M, int32_t adj) {
+    return (uint32_t)((int32_t)cov - min((int32_t)min(cov, M) + adj, (int32_t)cov));
+}
+template <int E>
+__device__ __forceinline__ void block_terms_adj(const SweepLoads<E>& cur, const int32_t (&adj)[E], uint32_t a, uint32_t ell,
+                                                uint32_t L, uint32_t M, uint32_t lane, BlockTerms<E>& t) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = lane * E + r;
+        const uint32_t p = a + i;
+        const bool valid = i < ell && p < L;
+        const uint32_t cov = cur.x2[r] - cur.x1[r];
+        t.cnt[r] = valid ? cur.x1[r] - cur.x0[r] : 0u;
+        t.exj[r] = (valid && p + ell < L) ? ex_adjusted(cov, M, adj[r]) : kInf;
+    }
+}
+
 // chain-independent part of a block, up to (not including) the wave scan of the lane sums
 template <int E>
 __device__ __forceinline__ uint32_t prep_local(const SweepLoads<E>& ld, uint32_t a, uint32_t ell,
@@ -285,9 +305,17 @@ __device__ __forceinline__ void sweep_block_full(const SweepLoads<E>& cur, uint3
                                                  uint32_t trash, uint32_t ell, uint32_t L, uint32_t Lrun,
                                                  uint32_t M, uint32_t lane, uint32_t last_lane,
                                                  uint32_t last_r, uint32_t (&h)[E],
-                                                 uint32_t& d_last, uint32_t* __restrict__ csel) {
+                                                 uint32_t& d_last, uint32_t* __restrict__ csel,
+                                                 const int32_t* __restrict__ nb = nullptr /* nadj + base, or null */) {
     BlockTerms<E> t;
-    block_terms<E>(cur, a, ell, L, M, lane, t);
+    if (nb != nullptr) {
+        int32_t adj[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) adj[r] = nb[min(a + lane * E + r + ell, L)];
+        block_terms_adj<E>(cur, adj, a, ell, L, M, lane, t);
+    } else {
+        block_terms<E>(cur, a, ell, L, M, lane, t);
+    }
     uint32_t sufA[E], dn[E], hn[E];
     {
         uint32_t srun = kInf;
@@ -334,15 +362,16 @@ __device__ __forceinline__ void sweep_full_run(const uint32_t* __restrict__ cb, 
                                                uint32_t L, uint32_t Lrun, uint32_t M, uint32_t lane,
                                                uint32_t last_lane, uint32_t last_r,
                                                uint32_t (&h)[E], uint32_t& d_last,
-                                               uint32_t* __restrict__ csel) {
+                                               uint32_t* __restrict__ csel,
+                                               const int32_t* __restrict__ nb = nullptr /* nadj + base, or null */) {
     SweepLoads<E> T0, T1;
     sweep_load<E>(cb, b_begin * ell, ell, L, lane, T0);
     for (uint32_t b = b_begin; b < b_end; b += 2) {
         sweep_load<E>(cb, (b + 1) * ell, ell, L, lane, T1);
-        sweep_block_full<E>(T0, b * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
+        sweep_block_full<E>(T0, b * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel, nb);
         sweep_load<E>(cb, (b + 2) * ell, ell, L, lane, T0);
         if (b + 1 < b_end)
-            sweep_block_full<E>(T1, (b + 1) * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
+            sweep_block_full<E>(T1, (b + 1) * ell, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel, nb);
     }
 }
 
@@ -376,13 +405,16 @@ __device__ __forceinline__ bool sweep_segment(const uint64_t* __restrict__ conti
 // global prefix counts need no clamp at contig borders.
 template <int E>
 __device__ __forceinline__ void sweep_initial_h(const uint32_t* __restrict__ boff, const SweepSeg& sg,
-                                                uint32_t ell, uint32_t M, uint32_t lane, uint32_t (&h)[E]) {
+                                                uint32_t ell, uint32_t M, uint32_t lane, uint32_t (&h)[E],
+                                                const int32_t* __restrict__ nadj = nullptr /* near-uniform route, or null */) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint32_t i = lane * E + r;
         const uint32_t hi = sg.base + min(i + 1, sg.L);  // prefix index p + 1
         const uint32_t cov = boff[hi] - boff[hi >= ell ? hi - ell : 0u];
-        h[r] = (i < ell && i < sg.L) ? (cov > M ? cov - M : 0u) : kInf;
+        uint32_t ex = cov > M ? cov - M : 0u;
+        if (nadj != nullptr) ex = ex_adjusted(cov, M, nadj[sg.base + min(i, sg.L)]);
+        h[r] = (i < ell && i < sg.L) ? ex : kInf;
     }
 }
 

@@ -534,7 +534,9 @@ __device__ __forceinline__ bool mg_no_source(int s, uint32_t lane) {
     return lane < 32;                            // rows 0 and 1
 }
 
-template <int E>
+// kAdj (round 4): the near-uniform route's sweep -- the need at every position is moved by nadj[] and capped at what the
+// swept (regular) reads can give (block_terms_adj); PREP loads one more row per block, the nadj of its landing positions.
+template <int E, bool kAdj>
 __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __restrict__ boff,
                                                            const uint64_t* __restrict__ contig_pos_off,
                                                            uint32_t ell, uint32_t M, uint32_t ltot,
@@ -544,7 +546,8 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                            uint32_t* __restrict__ selend_run_in /* speculative tables: where a stretch's
                                                                run-in (the positions before the one it owns from) goes; or null */,
                                                            const uint32_t* __restrict__ redo_in /* or null: every stretch */,
-                                                           uint32_t n_cand /* entries per column of seg (redo_in != null) */) {
+                                                           uint32_t n_cand /* entries per column of seg (redo_in != null) */,
+                                                           const int32_t* __restrict__ nadj /* kAdj: ltot + 1 entries */) {
     using Ly = MgLayout<E>;
     // (a later tier of a speculative sweep: only the parts of the genome a disagreement marked)
     if (redo_in != nullptr && (blockIdx.x >= seg[0] || spec_stretch_idle(seg, n_cand, blockIdx.x, redo_in))) return;
@@ -577,8 +580,9 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
     __builtin_amdgcn_s_setprio(3);
 
     uint32_t h[E];
-    sweep_initial_h<E>(boff, sg, ell, M, lane, h);
+    sweep_initial_h<E>(boff, sg, ell, M, lane, h, kAdj ? nadj : nullptr);
     uint32_t d_last = 0;
+    const uint32_t* __restrict__ nb = reinterpret_cast<const uint32_t*>(nadj) + base;  // (kAdj only)
 
 #define MG_SLOT0(idx) (s_mw + (size_t)(idx) * kG * Ly::kWords * 64)
 #define MG_SLOT(idx) (MG_SLOT0(idx) + lane)
@@ -591,20 +595,30 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
         constexpr uint32_t kD = 3;
         constexpr int kRows = kPB + 2;  // rows its blocks need
         RowRaw<E> R0[kRows], R1[kRows], R2[kRows];
-        auto issue_rows = [&](RowRaw<E> (&buf)[kRows], uint32_t g) {
+        RowRaw<E> N0[kPB], N1[kPB], N2[kPB];  // kAdj: nadj at the blocks' landing positions (the row one block on)
+        auto issue_rows = [&](RowRaw<E> (&buf)[kRows], RowRaw<E> (&nbuf)[kPB], uint32_t g) {
 #pragma unroll
             for (int k = 0; k < kRows; ++k) row_issue<E>(cb, (g * kG + pblk + k) * ell, L, lane, buf[k]);
+            if constexpr (kAdj) {
+#pragma unroll
+                for (int k = 0; k < kPB; ++k) row_issue<E>(nb, (g * kG + pblk + k + 1) * ell, L, lane, nbuf[k]);
+            }
         };
-        issue_rows(R0, 0);
-        issue_rows(R1, 1);
-        issue_rows(R2, 2);
-        auto pstage = [&](RowRaw<E> (&buf)[kRows], uint32_t t) {
+        issue_rows(R0, N0, 0);
+        issue_rows(R1, N1, 1);
+        issue_rows(R2, N2, 2);
+        auto pstage = [&](RowRaw<E> (&buf)[kRows], RowRaw<E> (&nbuf)[kPB], uint32_t t) {
             if (t < n_groups) {
                 uint32_t Wr[kRows][E];
+                uint32_t Nr[kPB][E];
 #pragma unroll
                 for (int k = 0; k < kRows; ++k) row_finish<E>(buf[k], Wr[k]);
+                if constexpr (kAdj) {
+#pragma unroll
+                    for (int k = 0; k < kPB; ++k) row_finish<E>(nbuf[k], Nr[k]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                issue_rows(buf, t + kD);
+                issue_rows(buf, nbuf, t + kD);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < kPB; ++kk) {
@@ -612,7 +626,14 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                     SweepLoads<E> ld;
                     rows_to_loads<E>(Wr[kk], Wr[kk + 1], Wr[kk + 2], lane, last_lane, last_r, ld);
                     BlockTerms<E> bt;
-                    block_terms<E>(ld, (t * kG + pblk + kk) * ell, ell, L, M, lane, bt);
+                    if constexpr (kAdj) {
+                        int32_t adj[E];
+#pragma unroll
+                        for (int r = 0; r < E; ++r) adj[r] = (int32_t)Nr[kk][r];
+                        block_terms_adj<E>(ld, adj, (t * kG + pblk + kk) * ell, ell, L, M, lane, bt);
+                    } else {
+                        block_terms<E>(ld, (t * kG + pblk + kk) * ell, ell, L, M, lane, bt);
+                    }
                     // the lane's own (a, b): composition of its E single-position maps
                     uint32_t a = bt.cnt[0], b = bt.cnt[0] + bt.exj[0];
 #pragma unroll
@@ -656,11 +677,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
         };
         for (uint32_t t = 0;; t += kD) {
             if (t >= n_groups + 2) break;
-            pstage(R0, t);
+            pstage(R0, N0, t);
             if (t + 1 >= n_groups + 2) break;
-            pstage(R1, t + 1);
+            pstage(R1, N1, t + 1);
             if (t + 2 >= n_groups + 2) break;
-            pstage(R2, t + 2);
+            pstage(R2, N2, t + 2);
         }
     } else {
         for (uint32_t t = 0; t < n_groups + 2; ++t) {
@@ -814,10 +835,11 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
             // (the blocks behind the last whole group; those of them that are run-in go to the other output)
             const uint32_t t0 = n_groups * kG;
             const uint32_t mid = min(max(own_blk, t0), n_blocks);
+            const int32_t* const nbt = kAdj ? nadj + base : nullptr;
             if (t0 < mid)
-                sweep_full_run<E>(cb, t0, mid, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel_run_in);
+                sweep_full_run<E>(cb, t0, mid, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel_run_in, nbt);
             if (mid < n_blocks)
-                sweep_full_run<E>(cb, mid, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel);
+                sweep_full_run<E>(cb, mid, n_blocks, trash, ell, L, Lrun, M, lane, last_lane, last_r, h, d_last, csel, nbt);
         }
         if (iter_stats && lane == 0) {
             atomicAdd(&iter_stats[0], n_blocks);  // every block is in the general form here

@@ -52,7 +52,9 @@ size_t sweep_segment_words(uint32_t n_contigs, uint32_t n_windows);
 // eoff: prefix counts of read ends for mixed spans (coverage = starts - ends); null for one span ell
 const uint32_t* launch_sweep_segments(hipStream_t st, const uint32_t* boff, const uint32_t* eoff,
                                       const uint64_t* d_poff, uint32_t n_contigs, uint32_t ltot, uint32_t ell,
-                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words);
+                                      uint32_t M, uint32_t n_windows, uint32_t* seg_words,
+                                      const uint32_t* other_cov = nullptr /* reads outside boff covering position q - 1:
+                                          other_cov[q] (the near-uniform route's exceptions) */);
 // seven-wave pipelined forms (spans <= 256); false if the span needs the single-wave kernel
 bool sweep_uniform_mw_supported(uint32_t ell);
 // the same pipeline with every block in the general form (sparse data: the fast form rarely holds)
@@ -62,7 +64,9 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
                               uint32_t n_seg_max, uint32_t* selend_run_in = nullptr,
-                              const uint32_t* redo_in = nullptr);
+                              const uint32_t* redo_in = nullptr,
+                              const int32_t* nadj = nullptr /* near-uniform route: need(p) += nadj[p], capped at the
+                                                               swept reads' coverage (ltot + 1 entries) */);
 // Speculative boundaries (kernels/sweep_segments.inc.hip): further tables of the same windows (tier 1, 2
 // behind the exact one in seg_words), with a boundary `burn` positions of run-in wide wherever a window has no
 // cut (call launch_sweep_segments first; *n_speculative receives how many; burn == 0: the exact table again),
@@ -231,7 +235,11 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx,
                      const uint32_t* swept_from /* per contig: first block the round's sweep covered (0xFFFFFFFF: none) */,
-                     uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */);
+                     uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */,
+                     uint32_t ltot, uint32_t* spine /* scan_spine_entries(2^17 + 2) words */,
+                     const uint32_t* seg_exact /* sweeps in stretches: launch_sweep_segments' table; or null */, uint32_t n_cand,
+                     uint32_t* marks_next /* n_cand words, out: the exact stretches the next round's sweep must cover */);
+size_t nu_suspect_bytes(uint32_t suspects_cap);  // `suspects`: the list and, behind it, its bins by start position
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, unsigned long long* kept_total);
 

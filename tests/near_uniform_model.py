@@ -58,6 +58,13 @@ def coverage(starts, ends, L):
     return np.cumsum(d)[:L]
 
 
+# How far below a read (in spans) the replay looks for a state to start from -- an anchor (a bucket that keeps members
+# for good) or a cut point.  Round 3 looked one span down; shallow data (1.5 x M: nearly everything is kept over long
+# stretches) has runs of used-up buckets longer than that, and the replay works from any distance: nothing below an
+# anchor is picked at or after the anchor's time, however far the anchor is (k_nu_replay: kNuReach).
+REACH = 6
+
+
 def verify(c, S, need, ell, exc_s, exc_e, exc_idx, unpicked):
     """earliest (time, priority) at which an unselected exception would be taken, from FINAL counts only.
     Returns None, or (t, x) with x an index into the exception arrays; or "unresolved"."""
@@ -74,7 +81,7 @@ def verify(c, S, need, ell, exc_s, exc_e, exc_idx, unpicked):
             continue
         # the run of exhausted buckets downwards from v
         u1 = v + 1
-        while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < ell:
+        while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < REACH * ell:
             u1 -= 1
         if u1 - 1 >= 0 and exhausted(u1 - 1):
             # ell used-up buckets in a row below the read: not modelled.  It only matters if nothing earlier is wanted
@@ -183,14 +190,14 @@ def _walk(c, S, need, ell, s, e, others, sel_time, L, cov_all=None, M=None):
     def exhausted(u):
         return u < 0 or S[u] == c[u]
     u1 = v + 1
-    while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < ell:
+    while u1 - 1 >= 0 and exhausted(u1 - 1) and s - (u1 - 1) < REACH * ell:
         u1 -= 1
     cut = None
     if u1 - 1 >= 0 and exhausted(u1 - 1):
         # no anchor within ell buckets.  A CUT POINT does as well: at a position p* with cov_all(p*) <= M every read
         # covering it is kept, so at time p* every bucket in (p* - ell, p*] is used up -- a known state to start from
         if cov_all is not None:
-            for p in range(s - 1, max(s - ell, -1), -1):
+            for p in range(s - 1, max(s - REACH * ell, -1), -1):
                 if cov_all[p] <= M:
                     cut = p
                     break

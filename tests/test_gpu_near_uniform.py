@@ -245,3 +245,22 @@ def test_two_contexts_in_flight(pkg, oracle):
         for k in range(2):
             sv[k].solve_end()
             assert np.array_equal(masks[k].cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("L,depth,M,fraction", [(400_000, 1.5, 100, 0.01), (800_000, 2.4, 40, 0.02), (3_000_000, 4.0, 20, 0.01),
+                                                (1_500_000, 8.0, 12, 0.01)])
+def test_shallow_contigs_are_swept_in_stretches(pkg, oracle, solver, L, depth, M, fraction):
+    """below 11 x M the route's sweeps run in stretches (cut points where the coverage of ALL reads is <= M, speculative
+    boundaries checked on the device) with the need moved by the selected exceptions: two contigs long enough for
+    speculative boundaries at their depth -- the oracle's mask, on the near-uniform route, whole contigs never swept as
+    one chain (stats.sweep_stretches counts them)"""
+    rng = np.random.default_rng(int(L * depth) % 7919)
+    lengths = np.array([L, L // 2 + 12_345], np.uint32)
+    counts = [int(depth * M * int(x) / 150) for x in lengths]
+    s, e, offs = _contigs(rng, lengths, counts, 150, fraction, 50)
+    got = solver.solve(s, e, lengths, M, contig_read_offsets=offs)
+    st = solver.last_stats
+    want = oracle.solve(s, e, lengths, M, offs)
+    assert np.array_equal(got, want), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_giveup == 0, st.as_dict()
+    assert st.sweep_stretches > 2 * st.near_uniform_rounds, st.as_dict()

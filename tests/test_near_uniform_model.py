@@ -95,3 +95,24 @@ def test_batched_rounds_on_identical_exceptions(oracle):
         r = nu.solve_near_uniform_batched(s.astype(np.uint32), e.astype(np.uint32), L, M, ell)
         if r is not None:
             assert np.array_equal(r[0], _bits(oracle.solve(s.astype(np.uint32), e.astype(np.uint32), [L], M), n)), seed
+
+
+@pytest.mark.parametrize("depth", [1.5, 2.0, 2.5])
+def test_shallow_data_long_runs_of_used_up_buckets(oracle, depth, monkeypatch):
+    """1.5 - 2.5 x M: stretches where nearly everything is kept give runs of used-up buckets longer than a span below a
+    read; the replay starts from an anchor or a cut point up to REACH spans down (round 3: one span, and such a read
+    ended the attempt) -- more cases resolve, every one the oracle's"""
+    def run(reach):
+        monkeypatch.setattr(nu, "REACH", reach)
+        resolved = 0
+        for seed in range(10):
+            L, ell, M = 2400, 24, 16
+            s, e = _instance(seed * 3 + 11, L, ell, M, depth, 0.03, 10)
+            r = nu.solve_near_uniform_batched(s, e, L, M, ell)
+            if r is None:
+                continue
+            assert np.array_equal(r[0], _bits(oracle.solve(s, e, [L], M), s.size)), (depth, seed, reach)
+            resolved += 1
+        return resolved
+    near, far = run(1), run(6)
+    assert far >= near and far >= 5, (near, far)
