@@ -79,7 +79,7 @@ struct qmcp_hip_ctx {
     // one goes straight to the mixed-span route instead of burning the budget again
     uint64_t nu_failed_n = 0, nu_failed_ltot = 0;
     uint32_t nu_failed_ell = 0, nu_failed_M = 0;
-    DevBuf nu_exc, nu_nadj, nu_ce, nu_state, nu_sus, nu_ckpt;
+    DevBuf nu_exc, nu_nadj, nu_ce, nu_state, nu_sus, nu_ckpt, nu_prev;
     uint32_t* h_nu = nullptr;       // pinned landing zone of the route's state words (8)
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))
     size_t h_tables_cap = 0;

@@ -158,7 +158,7 @@ void qmcp_hip_destroy(qmcp_hip_ctx* c) {
     DevBuf* bufs[] = {&c->roff, &c->poff, &c->stats, &c->cstart, &c->boff, &c->ecnt, &c->eoff,
                       &c->selend, &c->spine, &c->hist, &c->spine2, &c->hist2, &c->keys[0], &c->keys[1], &c->vals[0],
                       &c->vals[1], &c->in_starts, &c->in_ends, &c->in_aux0, &c->in_aux1, &c->mask,
-                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_desc, &c->pm_work, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt};
+                      &c->cov, &c->amp, &c->scalars, &c->next_head, &c->ranges, &c->rankamb, &c->pm_desc, &c->pm_work, &c->segs, &c->specsnap, &c->specflags, &c->rings, &c->evpk, &c->evlast, &c->kidx, &c->f_starts, &c->f_ends, &c->f_map, &c->f_words, &c->f_mask, &c->nu_exc, &c->nu_nadj, &c->nu_ce, &c->nu_state, &c->nu_sus, &c->nu_ckpt, &c->nu_prev};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i)

@@ -4,6 +4,7 @@
 // mixed-span route (nothing has touched the mask).  The head's producer may already have filtered on c->nu_ell
 // (run.nu_filter); otherwise the reads are counted first and, if the longest span is the dominant one, the head's
 // stages are queued again with the filter on.
+constexpr uint32_t kNuRunInsApart = 2;
 int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uint32_t max_load, uint32_t* d_iters, bool& done) {
     done = false;
     SolveRun& run = c->run;
@@ -118,10 +119,15 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             n_seg_max = n_contigs + windows;
         }
         speculate = spec_wanted(c, depth) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
+        // (stretches two run-ins long instead of the one-span route's four: the route sweeps several times, and a sweep is
+        //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> ?? ms a sweep)
     }
     // later rounds sweep only the exact stretches a selection of the round before touched (k_nu_select_apply marks them)
     uint32_t* marks[2] = {(uint32_t*)((char*)c->nu_sus.p + qmcp::nu_suspect_bytes(kNuSuspects)), nullptr};
     marks[1] = marks[0] + 4096;
+    uint32_t* dirty[2] = {marks[1] + 4096, nullptr};  // (cells a replay reads from that changed: kernels/near_uniform.inc.hip NuBins)
+    dirty[1] = dirty[0] + qmcp::nu_cells_bytes() / sizeof(uint32_t);
+    if (stretches) HIP_TRY(hipMemsetAsync(dirty[0], 0, 2 * qmcp::nu_cells_bytes(), st));
     // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
     // all settled is eight launches that return at once (the chain sweeps nothing, the verification skips every
     // exception: ~0.1 ms), about what one more host round trip costs; measured at cfg4 with 1 % clipped reads (7 rounds),
@@ -136,7 +142,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             if (stretches) {
                 if (speculate) {
                     TRY(speculative_sweep(
-                        c, st, n_contigs, ltot, windows, ell, ell, burn_blocks, 4, seg, "k_sweep_uniform_gen",
+                        c, st, n_contigs, ltot, windows, ell, ell, burn_blocks, kNuRunInsApart, seg, "k_sweep_uniform_gen",
                         [&](const uint32_t* table, uint32_t* run_in_out, const uint32_t* redo_in) {
                             return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, ell, M, ltot, selend, d_iters, table,
                                                                   n_seg_max, run_in_out, redo_in, nadj);
@@ -173,9 +179,11 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                 KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
                 qmcp::launch_nu_round(st, exc, cap, n_exc, d_stats + 6, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
                                       (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1],
-                                      ltot, (uint32_t*)c->spine.p, stretches ? seg : nullptr, n_seg_max, marks[1]);
+                                      ltot, (uint32_t*)c->spine.p, stretches ? seg : nullptr, n_seg_max, marks[1],
+                                      stretches ? (uint32_t*)c->nu_prev.p : nullptr, dirty[0], dirty[1]);
                 std::swap(sweep_from[0], sweep_from[1]);
                 std::swap(marks[0], marks[1]);
+                std::swap(dirty[0], dirty[1]);
             }
         }
         HIP_TRY(hipGetLastError());

@@ -32,7 +32,8 @@ int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_c
     TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
     TRY(ensure(c, c->nu_ce, ((size_t)ltot + 4) * sizeof(uint32_t)));
     TRY(ensure(c, c->nu_state, 64 + (size_t)n_contigs * 20 + 16));
-    TRY(ensure(c, c->nu_sus, qmcp::nu_suspect_bytes(kNuSuspects) + 2 * 4096 * sizeof(uint32_t)));  // + marks per exact stretch, two rounds'
+    TRY(ensure(c, c->nu_sus, qmcp::nu_suspect_bytes(kNuSuspects) + 2 * 4096 * sizeof(uint32_t) + 2 * qmcp::nu_cells_bytes()));  // + marks per exact stretch and dirty cells, two rounds' each
+    TRY(ensure(c, c->nu_prev, ((size_t)ltot + 8) * sizeof(uint32_t)));  // sweeps in stretches: the round before's kept counts
     if (c->nu_ell != 0) {
         // (the route's sweep scratch depends on the span: known from the last call that took the route, so a second call
         //  of the shape grows nothing after its first launch)

@@ -175,6 +175,12 @@ struct NuBins {
     uint32_t* start;   // n_cells + 2: exclusive scan of count
     uint32_t* sorted;  // suspects_cap: slots of the suspects list, by cell
     uint32_t shift, n_cells;
+    // Sweeps in stretches (long contigs: a contig-wide "swept from" says little): cells where something a replay reads has
+    // changed since the round before -- the sweep's counts (k_nu_diff) or the need (k_nu_select_apply).  A listed
+    // exception is replayed again only if a cell of [s - (kNuReach + 1) ell, e + 1] is dirty (or its run had no anchor
+    // last time); the others keep their answer and are listed for their neighbours' sake.  null: replay every one.
+    const uint32_t* dirty;   // this round's
+    uint32_t* dirty_next;    // the next round's (zeroed): written by k_nu_select_apply, then by the next k_nu_diff
 };
 __device__ __forceinline__ uint32_t nu_cell(const NuBins& b, uint32_t pos) { return min(pos >> b.shift, b.n_cells - 1u); }
 __host__ inline uint32_t nu_bin_shift(uint32_t ltot) {
@@ -184,42 +190,99 @@ __host__ inline uint32_t nu_bin_shift(uint32_t ltot) {
 }
 static constexpr uint32_t kNuMaxCells = (1u << 17) + 1;
 
-// suspects: {exception, contig} pairs
+// How far below a read the replay looks for a state to start from (an anchor or a cut point), in spans.  One span nearly
+// always does; shallow data (1.5 x M: stretches where nearly everything is kept) has runs of used-up buckets longer than
+// that -- the replay is the same from any distance (nothing below an anchor is picked at or after the anchor's time), so a
+// read whose run has nothing within one span is staged again with kNuReach spans (round 4; tests/near_uniform_model.py
+// REACH: at 1.5 x M two of ten cases settled with one span, all ten with six).
+static constexpr int kNuReach = 6;
+// suspects: {exception, contig} pairs; replay_list: the slots of those that are replayed this round (the others are listed
+// for their neighbours' sake).  Slots are handed out a workgroup at a time: one atomic per counter and workgroup (one per
+// suspect was 25 k atomics on one word per round on long shallow contigs, most of the round's time).
 __global__ __launch_bounds__(256) void k_nu_verify(NuExc x, NuView v, uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                    uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ swept_from /* per contig: the first block this round swept */,
-                                                   NuBins bins) {
+                                                   NuBins bins, uint32_t* __restrict__ replay_list) {
+    __shared__ uint32_t s_w[4][2], s_base[2];
     if (state[7] == 0u) return;  // (no contig was swept this round: every one is settled)
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < x.n_dense; j += gridDim.x * blockDim.x) {
-        const uint32_t i = x.dense[j];
-        const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
-        const int32_t b = e - (int32_t)v.ell + 1;
-        const uint32_t contig = nu_contig_of(v, (uint32_t)s);
-        const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
-        // what an earlier round settled stays settled: nothing at or below e has changed if the round swept only from
-        // a later block on (a contig that is settled sweeps nothing).  One span of slack: an exception listed for its
-        // own sake needs the ones whose lives overlap its own beside it, and those may end a span earlier.
-        const uint32_t from = swept_from[contig];
-        if (from == 0xFFFFFFFFu || (uint64_t)(uint32_t)(e - c0) + v.ell < (uint64_t)from * v.ell) continue;
-        if (x.pick[i] == kNuUnpicked) {  // (a selected exception is always listed: its selection is checked)
-            bool reach = true;
-            for (int32_t u = s; u > b && reach; --u) reach = nu_exhausted(v, u, c0);
-            if (!reach) continue;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < x.n_dense; j0 += gridDim.x * blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        bool listed = false, replay = false;
+        uint32_t i = 0, contig = 0;
+        int32_t s = 0;
+        if (j < x.n_dense) {
+            i = x.dense[j];
+            s = (int32_t)x.gs[i];
+            const int32_t e = (int32_t)x.ge[i];
+            const int32_t b = e - (int32_t)v.ell + 1;
+            contig = nu_contig_of(v, (uint32_t)s);
+            const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
+            // what an earlier round settled stays settled: nothing at or below e has changed if the round swept only from
+            // a later block on (a contig that is settled sweeps nothing).  One span of slack: an exception listed for its
+            // own sake needs the ones whose lives overlap its own beside it, and those may end a span earlier.
+            const uint32_t from = swept_from[contig];
+            listed = !(from == 0xFFFFFFFFu || (uint64_t)(uint32_t)(e - c0) + v.ell < (uint64_t)from * v.ell);
+            if (listed && x.pick[i] == kNuUnpicked) {  // (a selected exception is always listed: its selection is checked)
+                bool reach = true;
+                for (int32_t u = s; u > b && reach; --u) reach = nu_exhausted(v, u, c0);
+                listed = reach;
+            }
+            if (listed) {
+                // replayed: unless it ends before what the round swept, or nothing it reads has changed since it was last
+                // replayed (its answer -- no question -- stands); a read whose run had no anchor keeps that key until a
+                // replay says otherwise, and is replayed whatever changed
+                replay = (uint64_t)(uint32_t)(e - c0) >= (uint64_t)from * v.ell;
+                const unsigned long long k0 = x.key[i];
+                const bool was_unresolved = bins.dirty != nullptr && k0 != kNuNoKey && (k0 & kNuUnresolvedLow) == kNuUnresolvedLow;
+                if (replay && bins.dirty != nullptr && !was_unresolved) {
+                    const uint32_t c_lo = nu_cell(bins, (uint32_t)max(s - (kNuReach + 1) * (int32_t)v.ell, 0));
+                    const uint32_t c_hi = nu_cell(bins, (uint32_t)e + 1u);
+                    bool d = false;
+                    for (uint32_t cc = c_lo; cc <= c_hi; ++cc) d |= bins.dirty[cc] != 0u;
+                    replay = d;
+                }
+                if (!was_unresolved || replay) x.key[i] = kNuNoKey;
+            }
         }
-        const uint32_t slot = atomicAdd(&state[4], 1u);
-        if (slot < suspects_cap) {
-            suspects[slot] = make_uint2(i, contig);
-            atomicAdd(&bins.count[nu_cell(bins, (uint32_t)s)], 1u);
-        } else {
-            atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
+        const uint64_t ml = __builtin_amdgcn_ballot_w64(listed), mr = __builtin_amdgcn_ballot_w64(replay);
+        if (lane == 0) { s_w[w][0] = (uint32_t)__builtin_popcountll(ml); s_w[w][1] = (uint32_t)__builtin_popcountll(mr); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t0 = s_w[0][0] + s_w[1][0] + s_w[2][0] + s_w[3][0], t1 = s_w[0][1] + s_w[1][1] + s_w[2][1] + s_w[3][1];
+            s_base[0] = t0 ? atomicAdd(&state[4], t0) : 0u;
+            s_base[1] = t1 ? atomicAdd(&state[14], t1) : 0u;
         }
-        x.key[i] = kNuNoKey;
+        __syncthreads();
+        if (listed) {
+            uint32_t slot = s_base[0] + (uint32_t)__builtin_popcountll(ml & ((1ull << lane) - 1ull));
+            uint32_t rslot = s_base[1] + (uint32_t)__builtin_popcountll(mr & ((1ull << lane) - 1ull));
+            for (uint32_t ww = 0; ww < w; ++ww) { slot += s_w[ww][0]; rslot += s_w[ww][1]; }
+            if (slot < suspects_cap) {
+                suspects[slot] = make_uint2(i, contig);
+                atomicAdd(&bins.count[nu_cell(bins, (uint32_t)s)], 1u);
+                if (replay && rslot < suspects_cap) replay_list[rslot] = slot;
+            } else {
+                atomicOr(&state[2], 2u);  // more suspects than the list holds: the route gives up
+            }
+        }
+        __syncthreads();  // (s_w and s_base are written again by the next strip)
     }
 }
 
 // One wave per suspect.  Everything the replay reads -- bucket offsets, the sweep's result and nadj over
 // [s - 2 ell, e + 1] -- is staged in LDS first (a trip to memory per replayed position would make an exception in a
 // contig's last ell positions, where every bucket is empty and the run is as long as the read, cost half a millisecond).
+// after a sweep in stretches: which cells' kept counts differ from the round before (and the copy for the next round)
+__global__ __launch_bounds__(256) void k_nu_diff(const uint32_t* __restrict__ selend, uint32_t* __restrict__ prev, uint32_t ltot,
+                                                 uint32_t shift, uint32_t n_cells, uint32_t* __restrict__ dirty, uint32_t first_round) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < ltot; p += gridDim.x * blockDim.x) {
+        const uint32_t a = selend[p];
+        if (!first_round && a != prev[p]) dirty[min(p >> shift, n_cells - 1u)] = 1u;
+        prev[p] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_nu_bin(NuExc x, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                 const uint32_t* __restrict__ state, NuBins bins) {
     const uint32_t n_sus = min(state[4], suspects_cap);
@@ -229,39 +292,41 @@ __global__ __launch_bounds__(256) void k_nu_bin(NuExc x, const uint2* __restrict
     }
 }
 
-// How far below a read the replay looks for a state to start from (an anchor or a cut point), in spans.  One span nearly
-// always does; shallow data (1.5 x M: stretches where nearly everything is kept) has runs of used-up buckets longer than
-// that -- the replay is the same from any distance (nothing below an anchor is picked at or after the anchor's time), so a
-// read whose run has nothing within one span is staged again with kNuReach spans (round 4; tests/near_uniform_model.py
-// REACH: at 1.5 x M two of ten cases settled with one span, all ten with six).
-static constexpr int kNuReach = 6;
-// staged positions [s - (reach + 1) ell, e + 1] and replayed buckets: (kNuReach + 2) ell + 16 entries each, dynamic LDS
-__host__ __device__ constexpr uint32_t nu_stage_entries(uint32_t ell) { return (uint32_t)(kNuReach + 2) * ell + 16u; }
+// staged positions [s - (reach + 1) ell, e + 1] and replayed buckets: (reach + 2) ell + 16 entries each, dynamic LDS.
+// Two launches: every listed exception with one span of reach (11 KB of LDS at ell = 150: six workgroups per CU; with
+// kNuReach spans for all of them it was two, and the replays of a round are one wave each -- 1.7 ms for 25 k of them),
+// then the few whose run had nothing within a span (the far list) with kNuReach.
+__host__ __device__ constexpr uint32_t nu_stage_entries(uint32_t ell, bool far) { return (uint32_t)((far ? kNuReach : 1) + 2) * ell + 16u; }
+template <bool kFar>
 __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2* __restrict__ suspects, uint32_t suspects_cap,
                                                   uint32_t* __restrict__ state, unsigned long long* __restrict__ viol_key,
-                                                  const uint32_t* __restrict__ swept_from, NuBins bins) {
+                                                  const uint32_t* __restrict__ swept_from, NuBins bins,
+                                                  const uint32_t* __restrict__ replay_list /* kFar: the far list */,
+                                                  uint32_t* __restrict__ far_list /* !kFar: out */) {
     extern __shared__ uint32_t s_nu_dyn[];
-    const int32_t kNuStage = (int32_t)nu_stage_entries(v.ell), kNuCur = kNuStage;
+    const int32_t kNuStage = (int32_t)nu_stage_entries(v.ell, kFar), kNuCur = kNuStage;
     uint32_t* const s_b = s_nu_dyn;
     uint32_t* const s_e = s_b + kNuStage;
     uint32_t* const s_x = s_e + kNuStage;
     int32_t* const s_a = reinterpret_cast<int32_t*>(s_x + kNuStage);
     int32_t* const s_cur = s_a + kNuStage;
     int32_t* const s_stack = s_cur + kNuStage;
-    __shared__ int32_t o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers], o_above[kNuOthers];
+    // (the others' starts, ends and selection times relative to s - ell: lives that overlap [s, e] lie within 3 spans of it)
+    __shared__ short o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers];
+    __shared__ unsigned char o_above[kNuOthers];
     __shared__ uint32_t o_n;
     const int32_t lane = (int32_t)threadIdx.x;
-    const uint32_t n_sus = min(state[4], suspects_cap);
+    const uint32_t n_replay = min(state[kFar ? 15 : 14], suspects_cap);
     const int32_t ell = (int32_t)v.ell;
-    for (uint32_t q = blockIdx.x; q < n_sus; q += gridDim.x) {
-        const uint2 su = suspects[q];
+    for (uint32_t rq = blockIdx.x; rq < n_replay; rq += gridDim.x) {
+        const uint32_t sus_slot = replay_list[rq];
+        const uint2 su = suspects[sus_slot];
         const uint32_t i = su.x, contig = su.y;
         const int32_t s = (int32_t)x.gs[i], e = (int32_t)x.ge[i];
         const int32_t b = e - ell + 1;
         const int32_t c0 = (int32_t)(uint32_t)v.poff[contig];
-        // listed for the others' sake only (it ends before what the round swept: its own questions were settled by an
-        // earlier round, on counts that have not changed since)
-        if ((uint64_t)(uint32_t)(e - c0) < (uint64_t)swept_from[contig] * v.ell) continue;
+        // (the exceptions listed for the others' sake only -- they end before what the round swept, or nothing they read has
+        //  changed -- are not in the replay list: k_nu_verify)
         int32_t r0 = 0;
         auto stage = [&](int32_t reach) {
             r0 = max(s - (reach + 1) * ell, 0);
@@ -277,7 +342,7 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             for (int32_t k = count + lane; k < count + 16 && k < kNuCur; k += 64) s_cur[k] = 0;
             __syncthreads();
         };
-        stage(1);
+        stage(kFar ? kNuReach : 1);
         if (lane == 0) o_n = 0;
         __syncthreads();
         // the other listed exceptions of the contig whose lives overlap this one's: {start, end, selection time or -1,
@@ -294,8 +359,9 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             if (ze < s || zs > e) continue;
             const uint32_t slot = atomicAdd(&o_n, 1u);
             if (slot < (uint32_t)kNuOthers) {
-                o_s[slot] = zs; o_e[slot] = ze;
-                o_t[slot] = x.pick[z.x] == kNuUnpicked ? -1 : (int32_t)x.pick[z.x];
+                const int32_t rel0 = s - ell;
+                o_s[slot] = (short)(zs - rel0); o_e[slot] = (short)(ze - rel0);
+                o_t[slot] = x.pick[z.x] == kNuUnpicked ? (short)-1 : (short)((int32_t)x.pick[z.x] - rel0);
                 o_above[slot] = (ze > e || (ze == e && (zs > s || (zs == s && x.idx[z.x] < my_idx)))) ? 1 : 0;
             }
         }
@@ -314,21 +380,24 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
         };
         // the run of exhausted buckets downwards from b; its anchor u1 - 1 is the first bucket that keeps members for
         // good (or lies before the contig): nothing below it is picked at or after its own time
+        constexpr int32_t reach = kFar ? kNuReach : 1;
         int32_t u1 = b + 1, cut = -1;
-        for (int32_t reach = 1;; reach = kNuReach) {
-            u1 = b + 1;
-            while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < reach * ell) --u1;
-            // No anchor within reach: a CUT POINT does as well.  At a position p with cov_all(p) <= M every read
-            // covering it is kept, so at time p every bucket in (p - ell, p] is used up -- a known state to start from.
-            cut = -1;
-            if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
-                for (int32_t p = s - 1; p > s - reach * ell && p >= c0; --p) {
-                    const uint32_t cov_reg = s_b[p + 1 - r0] - s_b[max(p + 1 - ell, 0) - r0];
-                    if (cov_reg + s_x[p - r0] <= v.M) { cut = p; break; }
-                }
+        while (u1 - 1 >= c0 && exhausted(u1 - 1) && s - (u1 - 1) < reach * ell) --u1;
+        // No anchor within reach: a CUT POINT does as well.  At a position p with cov_all(p) <= M every read
+        // covering it is kept, so at time p every bucket in (p - ell, p] is used up -- a known state to start from.
+        if (u1 - 1 >= c0 && exhausted(u1 - 1)) {
+            for (int32_t p = s - 1; p > s - reach * ell && p >= c0; --p) {
+                const uint32_t cov_reg = s_b[p + 1 - r0] - s_b[max(p + 1 - ell, 0) - r0];
+                if (cov_reg + s_x[p - r0] <= v.M) { cut = p; break; }
             }
-            if (!(cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) || reach == kNuReach) break;
-            stage(kNuReach);  // (rare: everything again, from further down)
+        }
+        if (!kFar && cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) {
+            // nothing within a span (rare): the far launch stages kNuReach spans for it
+            if (lane == 0) {
+                const uint32_t f = atomicAdd(&state[15], 1u);
+                if (f < suspects_cap) far_list[f] = sus_slot;
+            }
+            continue;
         }
         if (cut < 0 && u1 - 1 >= c0 && exhausted(u1 - 1)) {
             // kNuReach spans of exhausted buckets in a row below the read: not modelled.  That only matters if nothing EARLIER in the
@@ -395,9 +464,11 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
                 int32_t k = sel == t ? 1 : 0, r = 0;
                 if (n_others > 0) {  // (uniform)
                     int32_t kk = 0, rr = 0;
+                    const int32_t tr = t - (s - ell);  // (>= ell: t >= s)
                     for (int32_t j = lane; j < n_others; j += 64) {
-                        kk += o_t[j] == t ? 1 : 0;
-                        rr += (o_above[j] != 0 && o_s[j] <= t && t <= o_e[j] && (o_t[j] < 0 || o_t[j] >= t)) ? 1 : 0;
+                        const int32_t zt = o_t[j];
+                        kk += zt == tr ? 1 : 0;
+                        rr += (o_above[j] != 0 && o_s[j] <= tr && tr <= o_e[j] && (zt < 0 || zt >= tr)) ? 1 : 0;
                     }
                     k += (int32_t)wave_sum_u32((uint32_t)kk);
                     r = (int32_t)wave_sum_u32((uint32_t)rr);
@@ -443,6 +514,8 @@ __global__ __launch_bounds__(256) void k_nu_round_reset(uint32_t* __restrict__ s
         state[6] += state[1] != 0u ? 1u : 0u;  // rounds that selected something
         state[1] = 0;
         state[4] = 0;
+        state[14] = 0;  // exceptions to replay this round
+        state[15] = 0;  // ... of them, those whose run has nothing within one span
     }
     if (i < n_contigs) { viol_key[i] = kNuNoKey; viol_idx[i] = 0xFFFFFFFFu; sweep_from_next[i] = 0xFFFFFFFFu; }
 }
@@ -460,32 +533,47 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
                                                           const uint32_t* __restrict__ seg_exact /* sweeps in stretches: the exact
                                                               table [count, {start, end, contig end}...]; or null */,
                                                           uint32_t* __restrict__ marks_next /* per exact stretch, zeroed: 1 = the
-                                                              next round's sweep must cover it */) {
+                                                              next round's sweep must cover it */,
+                                                          NuBins bins) {
+    // one wave per listed exception (the lanes share the walks over [t, e]: a round on shallow data settles thousands of
+    // questions, a span of atomics each -- 0.35 ms with a thread apiece); what happens once per question is lane 0's
     const uint32_t n_sus = min(state[4], suspects_cap);
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_sus; q += gridDim.x * blockDim.x) {
+    const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t applied = 0;   // (lane 0's: questions settled, and the change in the number of selected exceptions -- one
+    int32_t selected = 0;   //  atomic per wave at the end; one per question was thousands on one word)
+    for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < n_sus; q += n_waves) {
         const uint2 su = suspects[q];
         const unsigned long long k = x.key[su.x];
         if (k == kNuNoKey) continue;
         if ((k & kNuUnresolvedLow) == kNuUnresolvedLow) {
-            if (k == viol_key[su.y]) atomicOr(&state[2], 1u);  // the contig's earliest open question has no answer
+            if (lane == 0 && k == viol_key[su.y]) atomicOr(&state[2], 1u);  // the contig's earliest open question has no answer
             continue;
         }
         const uint32_t t = (uint32_t)(k >> kNuKeyShift), e = x.ge[su.x];
         const uint32_t old = x.pick[su.x];
+        __builtin_amdgcn_wave_barrier();  // (every lane has read pick before lane 0 writes it)
         if ((k & 1ull) == 0ull) {  // wanted at t: select it there (it may have been selected later)
             const uint32_t hi = old != kNuUnpicked ? old - 1u : e;
-            for (uint32_t p = t; p <= hi; ++p) atomicSub(&nadj[p], 1);
-            x.pick[su.x] = t;
-            if (old == kNuUnpicked) atomicAdd(&state[3], 1u);
+            for (uint32_t p = t + lane; p <= hi; p += 64u) atomicSub(&nadj[p], 1);
+            if (lane == 0) {
+                x.pick[su.x] = t;
+                if (old == kNuUnpicked) ++selected;
+            }
         } else {                   // selected at `old`, not wanted there
-            for (uint32_t p = old; p <= e; ++p) atomicAdd(&nadj[p], 1);
-            x.pick[su.x] = kNuUnpicked;
-            atomicSub(&state[3], 1u);
+            for (uint32_t p = old + lane; p <= e; p += 64u) atomicAdd(&nadj[p], 1);
+            if (lane == 0) {
+                x.pick[su.x] = kNuUnpicked;
+                --selected;
+            }
         }
+        if (lane != 0) continue;
         // the next sweep of this contig: what happens from t on changes buckets above t - ell only, so the state
         // entering the block two before t's is still the chain's (the chain keeps it at every 64th block)
         const uint32_t kt = (t - (uint32_t)poff[su.y]) / ell;
         atomicMin(&sweep_from[su.y], (kt >= 2u ? kt - 2u : 0u) & ~63u);
+        if (bins.dirty_next != nullptr) {  // the need changes on [min(t, old), e]
+            for (uint32_t cc = nu_cell(bins, min(t, old)); cc <= nu_cell(bins, e); ++cc) bins.dirty_next[cc] = 1u;
+        }
         if (seg_exact != nullptr) {
             // the need changes on [min(t, old), e] and the kept counts from the bucket above t - ell on, up to the end of
             // the exact stretch (behind a cut point the sweep starts afresh): every exact stretch that meets
@@ -500,7 +588,11 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
             }
             for (uint32_t r = a; r < count && seg_exact[1 + 3 * r] <= e; ++r) marks_next[r] = 1u;
         }
-        atomicAdd(&state[1], 1u);
+        ++applied;
+    }
+    if (lane == 0 && applied != 0) {
+        atomicAdd(&state[1], applied);
+        if (selected != 0) atomicAdd(&state[3], (uint32_t)selected);
     }
 }
 
@@ -553,13 +645,15 @@ void launch_nu_setup(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     hipLaunchKernelGGL(k_nu_prepick, dim3(grid_for(cap ? cap : 1, 256)), dim3(256), 0, st, x, boff, ce, ell, M, nadj, state);
 }
 size_t nu_suspect_bytes(uint32_t suspects_cap) {  // the list, its slots by cell, the cells' counts and starts
-    return (size_t)suspects_cap * (sizeof(uint2) + sizeof(uint32_t)) + 2 * ((size_t)kNuMaxCells + 3) * sizeof(uint32_t);
+    return (size_t)suspects_cap * (sizeof(uint2) + 3 * sizeof(uint32_t)) + 2 * ((size_t)kNuMaxCells + 3) * sizeof(uint32_t);
 }
+size_t nu_cells_bytes() { return ((size_t)kNuMaxCells + 3) * sizeof(uint32_t); }  // one word per cell (the dirty flags)
 void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over, bool first_round,
                      const uint32_t* boff, const uint32_t* selend, int32_t* nadj, const uint32_t* ce, const uint64_t* d_poff, uint32_t n_contigs,
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next,
-                     uint32_t ltot, uint32_t* spine, const uint32_t* seg_exact, uint32_t n_cand, uint32_t* marks_next) {
+                     uint32_t ltot, uint32_t* spine, const uint32_t* seg_exact, uint32_t n_cand, uint32_t* marks_next,
+                     uint32_t* selend_prev, uint32_t* dirty, uint32_t* dirty_next) {
     const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
@@ -568,24 +662,40 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
     bins.shift = nu_bin_shift(ltot);
     bins.n_cells = (uint32_t)(((uint64_t)ltot >> bins.shift) + 1);
     bins.sorted = reinterpret_cast<uint32_t*>(suspects + suspects_cap);
-    bins.count = bins.sorted + suspects_cap;
+    uint32_t* const replay_list = bins.sorted + suspects_cap;
+    uint32_t* const far_list = replay_list + suspects_cap;
+    bins.count = far_list + suspects_cap;
     bins.start = bins.count + kNuMaxCells + 3;
+    bins.dirty = first_round ? nullptr : dirty;
+    bins.dirty_next = dirty_next;
+    if (selend_prev != nullptr) {
+        hipLaunchKernelGGL(k_nu_diff, dim3(grid_for(ltot ? ltot : 1, 256)), dim3(256), 0, st, selend, selend_prev, ltot, bins.shift,
+                           bins.n_cells, dirty, first_round ? 1u : 0u);
+        (void)hipMemsetAsync(dirty_next, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
+    } else {
+        bins.dirty = nullptr;
+        bins.dirty_next = nullptr;
+    }
     hipLaunchKernelGGL(k_nu_round_reset, dim3((n_contigs + 255) / 256), dim3(256), 0, st, state, viol_key, viol_idx, sweep_from_next, n_contigs,
                        first_round ? 1u : 0u);
     (void)hipMemsetAsync(bins.count, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
     if (seg_exact != nullptr) (void)hipMemsetAsync(marks_next, 0, (size_t)n_cand * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
-                       swept_from, bins);
+                       swept_from, bins, replay_list);
     launch_exclusive_scan(st, bins.count, bins.n_cells + 1, bins.start, spine, false);
     (void)hipMemsetAsync(bins.count, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_nu_bin, dim3(64), dim3(256), 0, st, x, suspects, suspects_cap, state, bins);
     {
-        const size_t lds = 6 * (size_t)nu_stage_entries(ell) * sizeof(uint32_t);  // (ell <= 256: the sweeps' limit)
-        (void)hipFuncSetAttribute((const void*)k_nu_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_nu_replay, dim3(512), dim3(64), lds, st, x, v, suspects, suspects_cap, state, viol_key, swept_from, bins);
+        const size_t lds = 6 * (size_t)nu_stage_entries(ell, false) * sizeof(uint32_t);  // (ell <= 256: the sweeps' limit)
+        const size_t lds_far = 6 * (size_t)nu_stage_entries(ell, true) * sizeof(uint32_t);
+        (void)hipFuncSetAttribute((const void*)k_nu_replay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_far);
+        hipLaunchKernelGGL(k_nu_replay<false>, dim3(2048), dim3(64), lds, st, x, v, suspects, suspects_cap, state, viol_key, swept_from,
+                           bins, replay_list, far_list);
+        hipLaunchKernelGGL(k_nu_replay<true>, dim3(256), dim3(64), lds_far, st, x, v, suspects, suspects_cap, state, viol_key, swept_from,
+                           bins, far_list, (uint32_t*)nullptr);
     }
-    hipLaunchKernelGGL(k_nu_select_apply, dim3(64), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
-                       sweep_from_next, seg_exact, marks_next);
+    hipLaunchKernelGGL(k_nu_select_apply, dim3(128), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
+                       sweep_from_next, seg_exact, marks_next, bins);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, unsigned long long* kept_total) {

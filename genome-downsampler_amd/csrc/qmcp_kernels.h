@@ -238,7 +238,13 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                      uint32_t* sweep_from_next /* per contig, out: where the next round's sweep starts (0xFFFFFFFF: settled) */,
                      uint32_t ltot, uint32_t* spine /* scan_spine_entries(2^17 + 2) words */,
                      const uint32_t* seg_exact /* sweeps in stretches: launch_sweep_segments' table; or null */, uint32_t n_cand,
-                     uint32_t* marks_next /* n_cand words, out: the exact stretches the next round's sweep must cover */);
+                     uint32_t* marks_next /* n_cand words, out: the exact stretches the next round's sweep must cover */,
+                     uint32_t* selend_prev /* sweeps in stretches: ltot words, the round before's selend (kept here); or null:
+                                              every listed exception is replayed */,
+                     uint32_t* dirty /* nu_cells_bytes(): cells that changed since the round before (the last round's
+                                        dirty_next) */,
+                     uint32_t* dirty_next);
+size_t nu_cells_bytes();
 size_t nu_suspect_bytes(uint32_t suspects_cap);  // `suspects`: the list and, behind it, its bins by start position
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, unsigned long long* kept_total);

@@ -1,5 +1,7 @@
 """lab: random instances through the near-uniform route against the oracle.
-   python lab/stress_near_uniform.py <cases> [seed0]"""
+   python lab/stress_near_uniform.py <cases> [seed0] [shallow]
+shallow: depths 1.4 - 8 x M on contigs long enough for the sweeps' speculative boundaries (small spans and M keep the
+oracle quick) -- the route's sweeps in stretches (round 4)"""
 import os, sys, importlib, collections
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +10,8 @@ pkg = importlib.import_module("genome-downsampler_amd")
 import oracle_py
 
 cases = int(sys.argv[1]); seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+shallow = len(sys.argv) > 3 and sys.argv[3] == "shallow"
+stretches = 0
 paths = collections.Counter(); rounds = collections.Counter(); wrong = 0; selected = 0
 with pkg.Solver(0) as sv:
     for case in range(cases):
@@ -17,6 +21,12 @@ with pkg.Solver(0) as sv:
         M = int(rng.choice([20, 50, 100, 200]))
         depth = float(rng.choice([6.5, 9, 12.5, 19, 30]))
         lengths = rng.integers(4 * ell, 60_000, size=n_contigs)
+        if shallow:
+            n_contigs = int(rng.integers(1, 4))
+            ell = int(rng.choice([40, 64, 100]))
+            M = int(rng.choice([6, 10, 16]))
+            depth = float(rng.choice([1.4, 1.7, 2.2, 3.0, 4.5, 8.0]))
+            lengths = rng.integers(4 * ell, int(rng.choice([60_000, 400_000, 900_000])), size=n_contigs)
         counts = np.maximum((depth * M * lengths / ell).astype(np.int64), 1)
         scale = max(1.0, 140_000 / counts.sum())          # the ranked route wants >= 128 Ki reads
         if counts.sum() > 1_500_000: scale = 1_500_000 / counts.sum()
@@ -49,6 +59,7 @@ with pkg.Solver(0) as sv:
         paths[int(st.path)] += 1
         if st.path == pkg.PATH_NEAR_UNIFORM:
             rounds[int(st.near_uniform_rounds)] += 1; selected += int(st.near_uniform_selected)
+            stretches += int(st.sweep_stretches)
             bits = np.unpackbits(want.view(np.uint8), bitorder="little")[:s.size].astype(bool)
             exc_kept = int((bits & ((e - s + 1) != ell)).sum())
             if exc_kept != int(st.near_uniform_selected):
@@ -58,4 +69,4 @@ with pkg.Solver(0) as sv:
             print("MISMATCH case", seed0 + case, dict(n_contigs=n_contigs, ell=ell, M=M, depth=depth, frac=frac, style=str(style)), st.as_dict(), flush=True)
         if case % 25 == 24:
             print(f"{case + 1} cases, {wrong} wrong, paths {dict(paths)}, rounds {dict(sorted(rounds.items()))}, selected exceptions {selected}", flush=True)
-print(f"done: {cases} cases, {wrong} wrong, paths {dict(paths)}, rounds {dict(sorted(rounds.items()))}, selected exceptions {selected}")
+print(f"done: {cases} cases, {wrong} wrong, paths {dict(paths)}, rounds {dict(sorted(rounds.items()))}, selected exceptions {selected}, stretches swept {stretches}")

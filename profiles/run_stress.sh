@@ -7,4 +7,5 @@ run pm python lab/stress_pm.py 0 $((600 * S))
 run more python lab/stress_more.py 0 $((300 * S))
 run ev python lab/stress_ev.py 0 $((500 * S))
 run near_uniform python lab/stress_near_uniform.py $((1000 * S)) 0
+run near_uniform_shallow python lab/stress_near_uniform.py $((250 * S)) 100000 shallow
 run spec python lab/stress_spec.py $((300 * S))
