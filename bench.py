@@ -20,6 +20,7 @@ For N > 1 either launch through torch.distributed.run (one rank per GPU over RCC
 child process (before torch or the GPU is touched) and exits with its code; rank 0 prints ONE JSON line.  The CPU baseline (oracle/, rank 0, N = 1 only) is a reported number, not the target.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -182,6 +183,39 @@ def clipped_configs(pkg, torch, dev, solver, stream, d_starts, d_ends, n_reads, 
     res["ratio"] = round(res["clipped_tail_15pct"]["device_ms"] / res["one_length"]["device_ms"], 2)
     res["note"] = "30 M amplicon reads on 29 903 bases, M = 200 (no FILTER): mixed-span route over one-length route"
     out["cfg3_clipped_tail"] = res
+    del d_s, d_e, d_m
+    # long SHALLOW contigs with a tail of clipped reads (a low-pass genome's shape): two contigs of 10^7 positions at
+    # 1.5 x M, 1 % clipped -- the near-uniform route with its sweeps in stretches, the same reads
+    # of one length, and the mixed-span walk
+    L, pairs = 10_000_000, 5_000_000
+    parts = [pkg.reads_gen(0, pairs, L, seed=4242 + c) for c in range(2)]
+    a = np.concatenate([p[0] for p in parts]); b = np.concatenate([p[1] for p in parts])
+    a2, b2 = synthetic.clipped_mix(a, b, 0.01)
+    offs2 = np.arange(3, dtype=np.uint64) * np.uint64(2 * pairs)
+    len2 = np.full(2, L, np.uint32)
+    d_m = torch.zeros(pkg.mask_words(a.size), dtype=torch.int64, device=dev)
+    res = {}
+    for name, (x, y, near, reps) in (("one_length", (a, b, 0, 3)), ("clipped_1pct", (a2, b2, 0, 3)), ("clipped_1pct_mixed_route", (a2, b2, -1, 1))):
+        d_s = torch.from_numpy(x.view(np.int32)).to(dev)
+        d_e = torch.from_numpy(y.view(np.int32)).to(dev)
+        ms = []
+        with solver.options(near_uniform=near):
+            for _ in range(reps):
+                st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), x.size, len2, M, d_m.data_ptr(),
+                                         contig_read_offsets=offs2, stream=stream)
+                ms.append(float(st.ms_total))
+        res[name] = {"device_ms": round(min(ms), 3), "path": int(st.path), "kept": int(st.n_kept),
+                     "stretches": int(st.sweep_stretches)}
+        if name == "clipped_1pct":
+            res[name].update(exceptions=int(st.near_uniform_exceptions), exceptions_kept=int(st.near_uniform_selected),
+                             sweeps=int(st.near_uniform_rounds), giveup=int(st.near_uniform_giveup))
+            res[name]["mask_sha1"] = hashlib.sha1(d_m.cpu().numpy().tobytes()).hexdigest()[:16]
+        if name == "clipped_1pct_mixed_route":
+            res["same_mask"] = res["clipped_1pct"]["mask_sha1"] == hashlib.sha1(d_m.cpu().numpy().tobytes()).hexdigest()[:16]
+        del d_s, d_e
+    res["ratio"] = round(res["clipped_1pct"]["device_ms"] / res["one_length"]["device_ms"], 2)
+    res["note"] = "two contigs of 10^7 positions, 2 x 10^7 reads of 150 at 1.5 x M (M = 100), 1 % clipped by 1...50 bases"
+    out["long_shallow_1pct_clipped"] = res
     return out
 
 

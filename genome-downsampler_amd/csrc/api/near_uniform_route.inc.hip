@@ -5,6 +5,7 @@
 // (run.nu_filter); otherwise the reads are counted first and, if the longest span is the dominant one, the head's
 // stages are queued again with the filter on.
 constexpr uint32_t kNuRunInsApart = 2;
+constexpr double kNuStretchDepth = 3.1;
 int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uint32_t max_load, uint32_t* d_iters, bool& done) {
     done = false;
     SolveRun& run = c->run;
@@ -20,21 +21,26 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                      (int)run.may_rank, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
     double min_depth = kNuMinDepth;
     if (c->opt.near_uniform_min_depth > 0.f) min_depth = c->opt.near_uniform_min_depth;  // (lab)
-    if (!run.may_rank || ell < ev_min_span() || !qmcp::sweep_uniform_ev_supported(ell, M) ||
-        depth < min_depth || min_span == 0)
-        return QMCP_OK;
+    if (!run.may_rank || depth < min_depth || min_span == 0) return QMCP_OK;
     // Which sweep the rounds run.  Deeper than 11 x M: one chain per contig in the event-driven form -- what the one-span
     // route runs there too -- restarted from its checkpoints.  Shallower (round 4): the block-scan pipeline in STRETCHES,
     // as the one-span route does -- real cut points (coverage of ALL reads <= M: every read over them is kept in every
     // round, whatever has been selected) and speculative boundaries checked on the device (uniform_sweep.inc.hip) -- with
     // the need moved by nadj; every round sweeps everything (hundreds of short chains side by side: a whole chain per
     // contig was 7 ms a sweep for cfg4's 10^6 positions at 1.5 x M, and long shallow contigs did not take the route).
-    bool stretches = depth < kGenDepth && qmcp::sweep_uniform_mw_supported(ell);
+    // Between 3.1 and 11 x M contigs of up to 2 M positions keep the chain: the speculative run-ins there are 1 536 - 2 304
+    // blocks, as long as such a contig, and the chain changes fewer blocks the deeper the data (lab/near_uniform_depths.py,
+    // cfg4's reads with 1 % clipped, chain / stretches ms: 6.3 x M 6.0 / 13.1; 4.7 x M 5.5 / 13.2; 3.75 x M 6.4 / 11.5;
+    // with 40 % of the reads: 5 x M 12.4 / 15.3; 3 x M 15.7 / 11.2; 2.1 x M gives up / 14.2; 1.5 x M 41.9 / 8.6).
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
+    // (the event-driven form's own limits: scratch for short spans, M in a packed field)
+    const bool ev_ok = ell >= ev_min_span() && qmcp::sweep_uniform_ev_supported(ell, M);
+    bool stretches = depth < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth < kNuStretchDepth || longest > 2000000u || !ev_ok);
     if (c->opt.sweep == QMCP_SWEEP_EVENTS) stretches = false;
     if (c->opt.sweep == QMCP_SWEEP_GENERAL) stretches = qmcp::sweep_uniform_mw_supported(ell);
     if (!stretches) {
-        uint32_t longest = 0;
-        for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
+        if (!ev_ok) return QMCP_OK;
         if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;  // (spans the pipeline does not take: a whole chain per round)
     }
     if (c->nu_failed_n == run.n64 && c->nu_failed_ltot == pr.ltot && c->nu_failed_ell == ell && c->nu_failed_M == M) {
@@ -120,7 +126,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         }
         speculate = spec_wanted(c, depth) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
         // (stretches two run-ins long instead of the one-span route's four: the route sweeps several times, and a sweep is
-        //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> ?? ms a sweep)
+        //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> 0.24 ms a sweep; one run-in long: 0.37)
     }
     // later rounds sweep only the exact stretches a selection of the round before touched (k_nu_select_apply marks them)
     uint32_t* marks[2] = {(uint32_t*)((char*)c->nu_sus.p + qmcp::nu_suspect_bytes(kNuSuspects)), nullptr};
