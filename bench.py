@@ -59,6 +59,7 @@ def cfg5_share(pkg, torch, dev, solver, stream):
     n = int(s.size)
     d_s = torch.from_numpy(s.view(np.int32)).to(dev)
     d_e = torch.from_numpy(e.view(np.int32)).to(dev)
+    s2, e2 = synthetic.clipped_mix(s, e, 0.01)
     del s, e
     d_m = torch.zeros(pkg.mask_words(n), dtype=torch.int64, device=dev)
     best = None
@@ -70,6 +71,22 @@ def cfg5_share(pkg, torch, dev, solver, stream):
                     "kept": int(st.n_kept), "stretches": int(st.sweep_stretches),
                     "speculative_boundaries": int(st.spec_boundaries),
                     "boundaries_that_disagreed": int(st.spec_mismatches)}
+    # the same share with 1 % of its reads clipped by 1...50 bases: the near-uniform route
+    # with its sweeps in stretches; parity: tests/test_gpu_full_size.py::test_cfg5_real_share_with_clipped_reads
+    d_s.copy_(torch.from_numpy(s2.view(np.int32)))
+    d_e.copy_(torch.from_numpy(e2.view(np.int32)))
+    del s2, e2
+    clipped = None
+    for _ in range(3):
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n, lengths, 50, d_m.data_ptr(),
+                                 contig_read_offsets=offs, stream=stream)
+        if clipped is None or st.ms_total < clipped["device_ms"]:
+            clipped = {"device_ms": round(float(st.ms_total), 3), "path": int(st.path), "kept": int(st.n_kept),
+                       "exceptions": int(st.near_uniform_exceptions), "exceptions_kept": int(st.near_uniform_selected),
+                       "sweeps": int(st.near_uniform_rounds), "giveup": int(st.near_uniform_giveup),
+                       "stretches": int(st.sweep_stretches)}
+    clipped["ratio_to_one_length"] = round(clipped["device_ms"] / best["device_ms"], 2)
+    best["clipped_1pct"] = clipped
     b_alg = algorithmic_bytes(n, int(lengths.sum()), lengths.size)
     best.update({"reads": n, "positions": int(lengths.sum()), "contigs": int(lengths.size), "max_coverage": 50,
                  "Mreads_per_s": round(n / best["device_ms"] / 1e3, 1),
@@ -89,6 +106,7 @@ def cfg5_real_share(pkg, torch, dev, solver, stream):
     n = int(s.size)
     d_s = torch.from_numpy(s.view(np.int32)).to(dev)
     d_e = torch.from_numpy(e.view(np.int32)).to(dev)
+    s2, e2 = synthetic.clipped_mix(s, e, 0.01)
     del s, e
     d_m = torch.zeros(pkg.mask_words(n), dtype=torch.int64, device=dev)
     best = None
@@ -100,6 +118,22 @@ def cfg5_real_share(pkg, torch, dev, solver, stream):
                     "kept": int(st.n_kept), "stretches": int(st.sweep_stretches),
                     "speculative_boundaries": int(st.spec_boundaries),
                     "boundaries_that_disagreed": int(st.spec_mismatches)}
+    # the same share with 1 % of its reads clipped by 1...50 bases: the near-uniform route
+    # with its sweeps in stretches; parity: tests/test_gpu_full_size.py::test_cfg5_real_share_with_clipped_reads
+    d_s.copy_(torch.from_numpy(s2.view(np.int32)))
+    d_e.copy_(torch.from_numpy(e2.view(np.int32)))
+    del s2, e2
+    clipped = None
+    for _ in range(3):
+        st = solver.solve_device(d_s.data_ptr(), d_e.data_ptr(), n, lengths, 50, d_m.data_ptr(),
+                                 contig_read_offsets=offs, stream=stream)
+        if clipped is None or st.ms_total < clipped["device_ms"]:
+            clipped = {"device_ms": round(float(st.ms_total), 3), "path": int(st.path), "kept": int(st.n_kept),
+                       "exceptions": int(st.near_uniform_exceptions), "exceptions_kept": int(st.near_uniform_selected),
+                       "sweeps": int(st.near_uniform_rounds), "giveup": int(st.near_uniform_giveup),
+                       "stretches": int(st.sweep_stretches)}
+    clipped["ratio_to_one_length"] = round(clipped["device_ms"] / best["device_ms"], 2)
+    best["clipped_1pct"] = clipped
     b_alg = algorithmic_bytes(n, int(lengths.sum()), lengths.size)
     best.update({"contigs_of_the_whole_genome": [int(c) for c in share], "reads": n,
                  "positions": int(lengths.sum()), "longest_contig": int(lengths.max()), "max_coverage": 50,

@@ -129,11 +129,19 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> 0.24 ms a sweep; one run-in long: 0.37)
     }
     // later rounds sweep only the exact stretches a selection of the round before touched (k_nu_select_apply marks them)
-    uint32_t* marks[2] = {(uint32_t*)((char*)c->nu_sus.p + qmcp::nu_suspect_bytes(kNuSuspects)), nullptr};
-    marks[1] = marks[0] + 4096;
-    uint32_t* dirty[2] = {marks[1] + 4096, nullptr};  // (cells a replay reads from that changed: kernels/near_uniform.inc.hip NuBins)
+    uint32_t* marks[2] = {(uint32_t*)((char*)c->nu_sus.p + qmcp::nu_suspect_bytes(nu_suspects_for(n))), nullptr};
+    const uint32_t mw = nu_marks_words(n_contigs);
+    marks[1] = marks[0] + mw;
+    // ... and, where the sweeps speculate, only the first tier's stretches that read or write something a selection changed
+    // (k_nu_select_apply; a boundary is compared when the stretch on either side of it was swept)
+    uint32_t* fine[2] = {marks[1] + mw, marks[1] + 2 * (size_t)mw};
+    uint32_t* dirty[2] = {fine[1] + mw, nullptr};  // (cells a replay reads from that changed: kernels/near_uniform.inc.hip NuBins)
     dirty[1] = dirty[0] + qmcp::nu_cells_bytes() / sizeof(uint32_t);
     if (stretches) HIP_TRY(hipMemsetAsync(dirty[0], 0, 2 * qmcp::nu_cells_bytes(), st));
+    // (the first tier's table: launch_sweep_segments_speculative(..., tier 1) builds it at this place on every sweep, from
+    //  the same cut points -- the same table every round)
+    const uint32_t* seg_fine = speculate ? (const uint32_t*)c->segs.p + windows + (1 + 5 * ((size_t)n_contigs + windows)) : nullptr;
+    if (c->opt.near_uniform_debug == 2) seg_fine = nullptr;  // (lab: every round sweeps every stretch its exact marks cover)
     // Rounds are queued two at a time and the host looks at the state words after each pair: a round whose contigs are
     // all settled is eight launches that return at once (the chain sweeps nothing, the verification skips every
     // exception: ~0.1 ms), about what one more host round trip costs; measured at cfg4 with 1 % clipped reads (7 rounds),
@@ -151,11 +159,12 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                         c, st, n_contigs, ltot, windows, ell, ell, burn_blocks, kNuRunInsApart, seg, "k_sweep_uniform_gen",
                         [&](const uint32_t* table, uint32_t* run_in_out, const uint32_t* redo_in) {
                             return qmcp::launch_sweep_uniform_gen(st, boff, poff, n_contigs, ell, M, ltot, selend, d_iters, table,
-                                                                  n_seg_max, run_in_out, redo_in, nadj);
+                                                                  n_seg_max, run_in_out, redo_in, nadj,
+                                                                  (table == seg_fine && rounds > 1) ? fine[0] : nullptr);
                         },
                         [&](const uint32_t* table, uint32_t* mismatches, const uint32_t* redo_in, uint32_t* redo_out) {
                             qmcp::launch_spec_verify(st, table, n_seg_max, ell, selend, (const uint32_t*)c->cstart.p, mismatches,
-                                                     redo_in, redo_out);
+                                                     redo_in, redo_out, (table == seg_fine && rounds > 1) ? fine[0] : nullptr);
                         },
                         rounds == 1 ? nullptr : marks[0]));
                 } else {
@@ -184,11 +193,12 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             {
                 KernelSpan sp(c, "near-uniform round (verify, replay, select, apply)");
                 qmcp::launch_nu_round(st, exc, cap, n_exc, d_stats + 6, rounds == 1, boff, selend, nadj, (const uint32_t*)c->nu_ce.p, poff, n_contigs, ell, M,
-                                      (uint2*)c->nu_sus.p, kNuSuspects, state, viol_key, viol_idx, sweep_from[0], sweep_from[1],
+                                      (uint2*)c->nu_sus.p, nu_suspects_for(n), state, viol_key, viol_idx, sweep_from[0], sweep_from[1],
                                       ltot, (uint32_t*)c->spine.p, stretches ? seg : nullptr, n_seg_max, marks[1],
-                                      stretches ? (uint32_t*)c->nu_prev.p : nullptr, dirty[0], dirty[1]);
+                                      stretches ? (uint32_t*)c->nu_prev.p : nullptr, dirty[0], dirty[1], seg_fine, fine[1]);
                 std::swap(sweep_from[0], sweep_from[1]);
                 std::swap(marks[0], marks[1]);
+                std::swap(fine[0], fine[1]);
                 std::swap(dirty[0], dirty[1]);
             }
         }

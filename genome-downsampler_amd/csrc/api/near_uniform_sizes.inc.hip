@@ -2,7 +2,11 @@
 // The near-uniform route (kernels/near_uniform.inc.hip): sizes, round budget, buffers (a solve's head sizes them).
 // Near-uniform route: sizes.  Exceptions beyond a tenth of the reads are not worth the route (every one the sweep
 // wants costs a sweep of its own); the list holds an eighth of every wave's reads.
-constexpr uint32_t kNuSuspects = 1u << 16;
+// The suspects of a round (exceptions whose own bucket is used up in the sweep's final counts): 64 Ki entries, or a
+// sixty-fourth of the reads on large calls -- one GPU's real share of configs[4] (129.7 M reads at 2 x M, where half of
+// all reads are kept) lists 125 k of its 1.3 M clipped reads in a round, and the fixed 64 Ki sent it to the mixed-span
+// walk: 14.5 s for a 117.7 M-position contig.
+uint32_t nu_suspects_for(uint32_t n) { return n / 64u > (1u << 16) ? n / 64u : (1u << 16); }
 // Rounds the route may take before it gives way to the mixed-span walk: that walk is one serial chain per contig at
 // ~0.07 us per position (79.8 ms for cfg4's 10^6-position contigs), a round is ~0.1 ms + what it sweeps again (at most
 // a contig: 0.5 ms per 10^6 positions); the route may spend up to about half of what the walk would take.
@@ -23,6 +27,9 @@ uint32_t nu_round_budget(const qmcp_hip_ctx* c, const uint32_t* lengths, uint32_
 // neither an anchor nor a cut point --; 1.5 x M 41.9 / 600, from cut points).  Below 1.3 x M nearly every window of the
 // mixed-span sweep has a real cut point and that sweep is quick.
 constexpr double kNuMinDepth = 1.3;
+// marks per stretch of a table: contig starts + at most kSweepWindowsOneSpan windows (a fixed 4 096 until round 4: a call of
+// more than 3 328 contigs would have cleared past its array)
+uint32_t nu_marks_words(uint32_t n_contigs) { return n_contigs + qmcp::kSweepWindowsOneSpan + 256u; }
 uint32_t nu_cap_for(uint32_t n) {  // 128 slots per wave and pass (or tile): an eighth of the reads, on either producer
     const uint32_t a = qmcp::pm_exc_slots(n), b = qmcp::prepare_exc_slots(n);
     return a > b ? a : b;
@@ -32,7 +39,7 @@ int ensure_near_uniform(qmcp_hip_ctx* c, uint32_t n, uint32_t ltot, uint32_t n_c
     TRY(ensure(c, c->nu_nadj, ((size_t)ltot + 2) * sizeof(int32_t)));
     TRY(ensure(c, c->nu_ce, ((size_t)ltot + 4) * sizeof(uint32_t)));
     TRY(ensure(c, c->nu_state, 64 + (size_t)n_contigs * 20 + 16));
-    TRY(ensure(c, c->nu_sus, qmcp::nu_suspect_bytes(kNuSuspects) + 2 * 4096 * sizeof(uint32_t) + 2 * qmcp::nu_cells_bytes()));  // + marks per exact stretch and dirty cells, two rounds' each
+    TRY(ensure(c, c->nu_sus, qmcp::nu_suspect_bytes(nu_suspects_for(n)) + 4 * (size_t)nu_marks_words(n_contigs) * sizeof(uint32_t) + 2 * qmcp::nu_cells_bytes()));  // + marks per exact stretch, per speculative stretch, and dirty cells: two rounds' each
     TRY(ensure(c, c->nu_prev, ((size_t)ltot + 8) * sizeof(uint32_t)));  // sweeps in stretches: the round before's kept counts
     if (c->nu_ell != 0) {
         // (the route's sweep scratch depends on the span: known from the last call that took the route, so a second call

@@ -368,8 +368,9 @@ int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
         uint32_t raw[16];
         HIP_TRY(hipMemcpy(raw, c->scalars.p, sizeof(raw), hipMemcpyDeviceToHost));
         const uint32_t* it = raw + 4;
-        fprintf(stderr, "[ev stamp] changed %u of %u blocks, stretches %u | x16 cycles: total %u general %u wait-for-ring %u slow-pieces %u (%u pieces)\n",
-                it[0], it[1], it[2], it[4], it[5], it[6], it[7], it[8]);
+        fprintf(stderr, "[ev stamp] changed %u of %u blocks, stretches %u | x16 cycles: total %u general %u wait-for-ring %u slow-pieces %u (%u pieces) "
+                        "failing rounds %u (%u rounds), blocks through the two scans %u\n",
+                it[0], it[1], it[2], it[4], it[5], it[6], it[7], it[8], it[9], it[10], it[11]);
     }
 #endif
     qmcp_hip_stats local = c->pend_stats;

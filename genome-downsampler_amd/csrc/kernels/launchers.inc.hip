@@ -156,9 +156,9 @@ void launch_spec_verify_merge_mixed(hipStream_t st, const uint32_t* seg, uint32_
 }
 void launch_spec_verify(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                         const uint32_t* owned, const uint32_t* run_in, uint32_t* mismatches,
-                        const uint32_t* redo_in, uint32_t* redo_out) {
+                        const uint32_t* redo_in, uint32_t* redo_out, const uint32_t* own_marks) {
     hipLaunchKernelGGL(k_spec_verify, dim3(n_cand), dim3(256), 0, st, seg, n_cand, ell, owned, run_in, mismatches,
-                       redo_in, redo_out);
+                       redo_in, redo_out, own_marks);
 }
 
 bool sweep_uniform_mw_supported(uint32_t ell) { return ell >= 1 && (ell + 63) / 64 <= 4; }
@@ -190,7 +190,8 @@ bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_
 bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                               uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                               uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg, uint32_t n_seg_max,
-                              uint32_t* selend_run_in, const uint32_t* redo_in, const int32_t* nadj) {
+                              uint32_t* selend_run_in, const uint32_t* redo_in, const int32_t* nadj,
+                              const uint32_t* own_marks) {
     const uint32_t n_wg = seg ? n_seg_max : n_contigs;
     const uint32_t e = (ell + 63) / 64;
 #define QMCP_SWEEP_GEN_K(EE, ADJ)                                                                      \
@@ -199,7 +200,7 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
         (void)hipFuncSetAttribute((const void*)k_sweep_uniform_gen<EE, ADJ>,                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL((k_sweep_uniform_gen<EE, ADJ>), dim3(n_wg), dim3(448), lds, st, boff, d_poff, \
-                           ell, M, ltot, selend, iter_stats, seg, selend_run_in, redo_in, n_seg_max, nadj);  \
+                           ell, M, ltot, selend, iter_stats, seg, selend_run_in, redo_in, n_seg_max, nadj, own_marks);  \
     }
 #define QMCP_SWEEP_GEN(EE)                                                                             \
     {                                                                                                   \

@@ -42,7 +42,7 @@ static constexpr unsigned long long kNuNoKey = ~0ull;
 // anchor (no event key has them: time - start < 256).
 static constexpr unsigned long long kNuUnresolvedLow = 0x7FFFFull;
 static constexpr int kNuKeyShift = 19;
-static constexpr int kNuOthers = 2048;  // exceptions of one contig whose lives overlap a suspect's (more: the route gives up)
+static constexpr int kNuOthers = 1024;  // listed exceptions of one contig whose lives overlap a suspect's and that outrank it or are selected (more: the route gives up)
 
 struct NuExc {  // the exception list: three arrays of cap slots + the route's own two; slots come in groups of 128
     const uint32_t* gs; const uint32_t* ge; const uint32_t* idx; uint32_t* pick; unsigned long long* key;
@@ -312,8 +312,10 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
     int32_t* const s_cur = s_a + kNuStage;
     int32_t* const s_stack = s_cur + kNuStage;
     // (the others' starts, ends and selection times relative to s - ell: lives that overlap [s, e] lie within 3 spans of it)
-    __shared__ short o_s[kNuOthers], o_e[kNuOthers], o_t[kNuOthers];
-    __shared__ unsigned char o_above[kNuOthers];
+    // (one word and a half per neighbour: start | end << 16 | outranks << 31, and the selection time -- with four arrays
+    //  of 2 048 the workgroup held 25 KB and six fitted a compute unit; a replay is one wave, mostly waiting)
+    __shared__ uint32_t o_se[kNuOthers];
+    __shared__ short o_t[kNuOthers];
     __shared__ uint32_t o_n;
     const int32_t lane = (int32_t)threadIdx.x;
     const uint32_t n_replay = min(state[kFar ? 15 : 14], suspects_cap);
@@ -357,12 +359,15 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
             if (z.y != contig || z.x == i) continue;
             const int32_t zs = (int32_t)x.gs[z.x], ze = (int32_t)x.ge[z.x];
             if (ze < s || zs > e) continue;
+            // (only a neighbour that outranks this one, or that is selected, enters the test below)
+            const bool above = ze > e || (ze == e && (zs > s || (zs == s && x.idx[z.x] < my_idx)));
+            const uint32_t zp = x.pick[z.x];
+            if (!above && zp == kNuUnpicked) continue;
             const uint32_t slot = atomicAdd(&o_n, 1u);
             if (slot < (uint32_t)kNuOthers) {
-                const int32_t rel0 = s - ell;
-                o_s[slot] = (short)(zs - rel0); o_e[slot] = (short)(ze - rel0);
-                o_t[slot] = x.pick[z.x] == kNuUnpicked ? (short)-1 : (short)((int32_t)x.pick[z.x] - rel0);
-                o_above[slot] = (ze > e || (ze == e && (zs > s || (zs == s && x.idx[z.x] < my_idx)))) ? 1 : 0;
+                const int32_t rel0 = s - ell;  // (lives that overlap [s, e] lie within three spans of it: 15 bits do)
+                o_se[slot] = (uint32_t)(zs - rel0) | ((uint32_t)(ze - rel0) << 16) | (above ? 0x80000000u : 0u);
+                o_t[slot] = zp == kNuUnpicked ? (short)-1 : (short)((int32_t)zp - rel0);
             }
         }
         __syncthreads();
@@ -467,8 +472,10 @@ __global__ __launch_bounds__(64) void k_nu_replay(NuExc x, NuView v, const uint2
                     const int32_t tr = t - (s - ell);  // (>= ell: t >= s)
                     for (int32_t j = lane; j < n_others; j += 64) {
                         const int32_t zt = o_t[j];
+                        const uint32_t se = o_se[j];
                         kk += zt == tr ? 1 : 0;
-                        rr += (o_above[j] != 0 && o_s[j] <= tr && tr <= o_e[j] && (zt < 0 || zt >= tr)) ? 1 : 0;
+                        rr += ((se >> 31) != 0 && (int32_t)(se & 0xFFFFu) <= tr && tr <= (int32_t)((se >> 16) & 0x7FFFu) &&
+                               (zt < 0 || zt >= tr)) ? 1 : 0;
                     }
                     k += (int32_t)wave_sum_u32((uint32_t)kk);
                     r = (int32_t)wave_sum_u32((uint32_t)rr);
@@ -534,7 +541,10 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
                                                               table [count, {start, end, contig end}...]; or null */,
                                                           uint32_t* __restrict__ marks_next /* per exact stretch, zeroed: 1 = the
                                                               next round's sweep must cover it */,
-                                                          NuBins bins) {
+                                                          NuBins bins,
+                                                          const uint32_t* __restrict__ seg_fine /* the first speculative tier's
+                                                              table, or null */, uint32_t n_cand,
+                                                          uint32_t* __restrict__ fine_next /* per stretch of it, zeroed */) {
     // one wave per listed exception (the lanes share the walks over [t, e]: a round on shallow data settles thousands of
     // questions, a span of atomics each -- 0.35 ms with a thread apiece); what happens once per question is lane 0's
     const uint32_t n_sus = min(state[4], suspects_cap);
@@ -587,6 +597,23 @@ __global__ __launch_bounds__(256) void k_nu_select_apply(NuExc x, const uint2* _
                 if (seg_exact[1 + 3 * mid] <= lo) a = mid; else b = mid;
             }
             for (uint32_t r = a; r < count && seg_exact[1 + 3 * r] <= e; ++r) marks_next[r] = 1u;
+            if (seg_fine != nullptr) {
+                // ... and of the speculative stretches only those whose sweep READS a position whose need changes or
+                // WRITES a bucket that may keep another count: a stretch looks at [start, end + ell] (run-in included)
+                // and a selection at t moves buckets from t - ell + 1 on; two spans of margin either side.  What changes
+                // further on changes through the state at a boundary, and that is compared wherever the stretch on either
+                // side was swept (k_spec_verify) -- a sweep forgets a change within a run-in, so later rounds, which settle
+                // a few questions each, sweep a few stretches instead of the genome (one GPU's share of configs[4] with
+                // 1 % clipped reads: rounds 4 to 6 were 2 ms of sweep each for 37, 6 and 0 selections).
+                const uint32_t fc = seg_fine[0];
+                const uint32_t from = lo - c0 >= 2u * ell ? lo - 2u * ell : c0, upto = e + 2u * ell;
+                uint32_t fa = 0, fb = fc;  // first stretch whose end + 2 ell >= from (ends are in position order)
+                while (fa < fb) {
+                    const uint32_t mid = (fa + fb) >> 1;
+                    if (seg_fine[1 + 3 * mid + 1] + 2u * ell < from) fa = mid + 1; else fb = mid;
+                }
+                for (uint32_t r = fa; r < fc && seg_fine[1 + 3 * r] <= upto; ++r) fine_next[r] = 1u;
+            }
         }
         ++applied;
     }
@@ -653,7 +680,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                      uint32_t ell, uint32_t M, uint2* suspects, uint32_t suspects_cap, uint32_t* state,
                      unsigned long long* viol_key, uint32_t* viol_idx, const uint32_t* swept_from, uint32_t* sweep_from_next,
                      uint32_t ltot, uint32_t* spine, const uint32_t* seg_exact, uint32_t n_cand, uint32_t* marks_next,
-                     uint32_t* selend_prev, uint32_t* dirty, uint32_t* dirty_next) {
+                     uint32_t* selend_prev, uint32_t* dirty, uint32_t* dirty_next, const uint32_t* seg_fine, uint32_t* fine_next) {
     const NuExc x = nu_exc_view(exc, cap, n_exc, n_over);
     NuView v;
     v.boff = boff; v.selend = selend; v.nadj = nadj; v.poff = d_poff; v.n_contigs = n_contigs; v.ell = ell; v.M = M;
@@ -680,6 +707,7 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                        first_round ? 1u : 0u);
     (void)hipMemsetAsync(bins.count, 0, ((size_t)bins.n_cells + 1) * sizeof(uint32_t), st);
     if (seg_exact != nullptr) (void)hipMemsetAsync(marks_next, 0, (size_t)n_cand * sizeof(uint32_t), st);
+    if (seg_exact != nullptr && seg_fine != nullptr) (void)hipMemsetAsync(fine_next, 0, (size_t)n_cand * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_nu_verify, dim3(grid_for(n_exc ? n_exc : 1, 256)), dim3(256), 0, st, x, v, suspects, suspects_cap, state,
                        swept_from, bins, replay_list);
     launch_exclusive_scan(st, bins.count, bins.n_cells + 1, bins.start, spine, false);
@@ -689,13 +717,13 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
         const size_t lds = 6 * (size_t)nu_stage_entries(ell, false) * sizeof(uint32_t);  // (ell <= 256: the sweeps' limit)
         const size_t lds_far = 6 * (size_t)nu_stage_entries(ell, true) * sizeof(uint32_t);
         (void)hipFuncSetAttribute((const void*)k_nu_replay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_far);
-        hipLaunchKernelGGL(k_nu_replay<false>, dim3(2048), dim3(64), lds, st, x, v, suspects, suspects_cap, state, viol_key, swept_from,
+        hipLaunchKernelGGL(k_nu_replay<false>, dim3(2304), dim3(64), lds, st, x, v, suspects, suspects_cap, state, viol_key, swept_from,
                            bins, replay_list, far_list);
         hipLaunchKernelGGL(k_nu_replay<true>, dim3(256), dim3(64), lds_far, st, x, v, suspects, suspects_cap, state, viol_key, swept_from,
                            bins, far_list, (uint32_t*)nullptr);
     }
     hipLaunchKernelGGL(k_nu_select_apply, dim3(128), dim3(256), 0, st, x, suspects, suspects_cap, state, viol_key, nadj, d_poff, ell,
-                       sweep_from_next, seg_exact, marks_next, bins);
+                       sweep_from_next, seg_exact, marks_next, bins, seg_exact != nullptr ? seg_fine : nullptr, n_cand, fine_next);
 }
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,
                              unsigned long long* mask, unsigned long long* kept_total) {

@@ -247,9 +247,15 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ run_in,
                                                      uint32_t* __restrict__ mismatches,
                                                      const uint32_t* __restrict__ redo_in /* or null: every stretch */,
-                                                     uint32_t* __restrict__ redo_out) {
+                                                     uint32_t* __restrict__ redo_out,
+                                                     const uint32_t* __restrict__ own_marks /* or null; else per stretch of
+                                                         this table: 1 = swept this time.  A boundary is looked at when the
+                                                         stretch on EITHER side of it was: the other side's output is the
+                                                         sweep before's, and equal counts there say that what lies behind
+                                                         the boundary has not changed either */) {
     const uint32_t r = blockIdx.x;
     if (r >= seg[0] || spec_stretch_idle(seg, n_cand, r, redo_in)) return;
+    if (own_marks != nullptr && own_marks[r] == 0 && (r == 0 || own_marks[r - 1] == 0)) return;
     const uint32_t start = seg[1 + 3 * r], own = seg[1 + 3 * n_cand + r];
     if (own == start) return;  // an exact boundary
     bool differs = false;

@@ -289,8 +289,8 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
     }
 
 #ifdef QMCP_EV_STAMP
-    unsigned long long st_gen = 0, st_slow = 0, st_wait = 0;
-    uint32_t st_slow_pieces = 0, st_full = 0;
+    unsigned long long st_gen = 0, st_slow = 0, st_wait = 0, st_fail = 0;
+    uint32_t st_slow_pieces = 0, st_full = 0, st_fail_rounds = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
     // pieces [0, landed) are in the ring; the chain looks at the ring's progress word only when it has
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
         while (landed < want) {
-            landed = s_ctl[0];
+            landed = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[0]);
             if (landed < want) __builtin_amdgcn_s_sleep(1);
         }
 #ifdef QMCP_EV_STAMP
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
     // a lane has all E slots or none): no partial lanes, no per-slot stores.  The lane's byte offset inside a block is a
     // constant; lanes without slots store to the spare words behind the table.
     const bool lane_has_slots = lane * E + E <= ell;
+    const uint32_t n_lean = ell % E == 0 ? Lrun / ell : 0u;  // blocks [0, n_lean) may take it
     auto commit_plain = [&](uint32_t k, const uint32_t (&S)[E], uint32_t cword) {
         gp = 0;
 #pragma unroll
@@ -382,7 +383,10 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
     auto general_block = [&](uint32_t k, uint32_t word) {
         uint32_t c[E];
         uint32_t S[E];
-        if (word & P::kPlain) {
+        // (the flag is the same in every lane: read on the scalar unit, so that the branches on it are scalar branches
+        //  and not exec-masked regions)
+        const bool plain = ((uint32_t)__builtin_amdgcn_readfirstlane((int)word) & P::kPlain) != 0;
+        if (plain) {
             // Deep block: the demand is the profile itself.  Nearly always whatever a position cannot
             // serve is taken by the position just before it: one shifted read instead of two scans.
             //   ex = what the slot cannot serve = max(g - c, 0) (one saturating subtract), S = min(g, c) + ex of the
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
                 viol = max(viol, (int32_t)S[r] - (int32_t)c[r]);
             }
             if (__builtin_amdgcn_ballot_w64(viol > 0) == 0) {
-                if (ell % E == 0 && (uint64_t)(k + 1) * ell <= Lrun) commit_plain(k, S, word);  // (uniform)
+                if (k < n_lean) commit_plain(k, S, word);  // (uniform)
                 else commit(k, S, word);
                 return;
             }
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
 #endif
         int32_t dn[E];
         bool kill[E];
-        if (!(word & P::kPlain)) {
+        if (!plain) {
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const uint32_t i = lane * E + r;
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
             if (total < rem) break;  // cannot happen for a feasible demand; do not spin
         }
         uint32_t cword = word;
-        if (!(word & P::kPlain)) {
+        if (!plain) {
             cword = P::kGuard;
 #pragma unroll
             for (int r = 0; r < E; ++r) cword |= min(c[r], P::kSat) << (r * P::kW);
@@ -526,44 +530,81 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
 #endif
     };
 
-    // four pieces (sixteen blocks) per round; the next four are read from the ring meanwhile
+    // Four pieces (sixteen blocks) per round.  An UNCHANGED round is the common case late in a contig and must be cheap:
+    // up to four of them run back to back on two register sets that swap roles (the next round's pieces are read from
+    // the ring while this one is tested; as first written the loop moved sixteen registers, tested (q & 15) three times
+    // and compared `landed` on the vector unit every round -- 76 instructions against 26 of test proper).  A round with
+    // a block that changes the profile leaves that run and is taken piece by piece in ONE copy of the slow path, which
+    // reads its pieces from the ring again (they stay until the chain says it is 64 blocks further).
     auto piece_and = [&](const uint4& w) { return ((w.x - gp) & (w.y - gp)) & ((w.z - gp) & (w.w - gp)); };
-    for (uint32_t q = q0; q < n_pieces; q += 4) {
-        if (landed < q + 8) wait_for(q + 8);  // pieces q + 4 .. q + 7 are in the ring
-        uint4 nxt[4];
+    // the bookkeeping at the end of the round that starts at piece q: every 64 blocks (and at the stretch's end) the
+    // last-changed index of each of them, and the state entering the next 64
+    auto round_done = [&](uint32_t q) {
+        if ((q & 15) != 12 && q + 4 < n_pieces) return;  // (uniform)
+        const uint32_t kb = (q >> 4) * 64 + lane;
+        if (kb < n_blocks) my_last[kb] = lastv;
+        lastv = last_ns;
+        if (my_ckpt != nullptr && (q & 15) == 12) {
+            uint32_t* ck = my_ckpt + (size_t)((q >> 4) + 1u) * 512u + lane * 8u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nxt[i] = s_evring[((q + 4 + i) % kEvSlots) * 64 + lane];
-        if ((q & 15) == 0 && lane == 0) s_ctl[1] = q;  // every piece before q has been read into registers
-        const uint32_t all = (piece_and(cur[0]) & piece_and(cur[1])) & (piece_and(cur[2]) & piece_and(cur[3]));
-        if (__builtin_amdgcn_ballot_w64((all & P::kAll) != P::kAll) != 0) {
-            // some block changes the profile: piece by piece, each tested against the profile as it is then
+            for (int r = 0; r < E; ++r) ck[r] = g[r];
+            ck[4] = cprevw;
+            ck[5] = last_ns;
+        }
+        if (lane == 0) s_ctl[1] = q + 4 < n_pieces ? q + 4 : q;  // every piece before the next group has been read
+    };
+    uint32_t q = q0;
+    bool failed = false;
+    // one unchanged round on the register set `now`, the next round's pieces into `nxt`
+#define QMCP_EV_ROUND(now, nxt)                                                                                      \
+    if (!failed && q < n_pieces) {                                                                                   \
+        if (landed < min(q + 8, n_pieces)) wait_for(q + 8);                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) nxt[i] = s_evring[(((q + 4) % kEvSlots) + i) * 64 + lane];     \
+        const uint32_t all = (piece_and(now[0]) & piece_and(now[1])) & (piece_and(now[2]) & piece_and(now[3]));      \
+        if (__builtin_amdgcn_ballot_w64((all & P::kAll) != P::kAll) != 0) {                                          \
+            failed = true;                                                                                           \
+        } else {                                                                                                     \
+            cprevw = now[3].w;                                                                                       \
+            round_done(q);                                                                                           \
+            q += 4;                                                                                                  \
+        }                                                                                                            \
+    }
+    uint4 alt[4];
+    while (q < n_pieces) {
+        QMCP_EV_ROUND(cur, alt)
+        QMCP_EV_ROUND(alt, cur)
+        QMCP_EV_ROUND(cur, alt)
+        QMCP_EV_ROUND(alt, cur)
+        if (failed) {
+            // some block of round q changes the profile: piece by piece, each tested against the profile as it is then
+            failed = false;
+#ifdef QMCP_EV_STAMP
+            const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+            ++st_fail_rounds;
+#endif
+            uint4 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = s_evring[((q % kEvSlots) + i) * 64 + lane];  // (q is a multiple of 4)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (q + i < n_pieces) {
-                    if (__builtin_amdgcn_ballot_w64((piece_and(cur[i]) & P::kAll) != P::kAll) != 0) slow_piece(q + i, cur[i]);
-                    else cprevw = cur[i].w;
+                    if (__builtin_amdgcn_ballot_w64((piece_and(w[i]) & P::kAll) != P::kAll) != 0) slow_piece(q + i, w[i]);
+                    else cprevw = w[i].w;
                 }
             }
-        } else {
-            cprevw = cur[3].w;
-        }
-        if ((q & 15) == 12 || q + 4 >= n_pieces) {
-            // 64 blocks done: for each of them the last changed block at or before it
-            const uint32_t kb = (q >> 4) * 64 + lane;
-            if (kb < n_blocks) my_last[kb] = lastv;
-            lastv = last_ns;
-            if (my_ckpt != nullptr && (q & 15) == 12) {
-                // the state entering block 64 (q / 16 + 1)
-                uint32_t* ck = my_ckpt + (size_t)((q >> 4) + 1u) * 512u + lane * 8u;
+            round_done(q);
+            q += 4;
+            if (q < n_pieces) {
+                if (landed < min(q + 4, n_pieces)) wait_for(q + 4);
 #pragma unroll
-                for (int r = 0; r < E; ++r) ck[r] = g[r];
-                ck[4] = cprevw;
-                ck[5] = last_ns;
+                for (int i = 0; i < 4; ++i) cur[i] = s_evring[((q % kEvSlots) + i) * 64 + lane];
             }
+#ifdef QMCP_EV_STAMP
+            st_fail += __builtin_amdgcn_s_memtime() - f0;
+#endif
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
     }
+#undef QMCP_EV_ROUND
     if (iter_stats && lane == 0) {
         atomicAdd(&iter_stats[0], n_changed);
         atomicAdd(&iter_stats[1], n_blocks);
@@ -574,6 +615,9 @@ __global__ __launch_bounds__(128) void k_sweep_uniform_ev(const uint32_t* __rest
         atomicAdd(&iter_stats[6], (uint32_t)(st_wait >> 4));
         atomicAdd(&iter_stats[7], (uint32_t)(st_slow >> 4));
         atomicAdd(&iter_stats[8], st_slow_pieces);
+        atomicAdd(&iter_stats[9], (uint32_t)(st_fail >> 4));
+        atomicAdd(&iter_stats[10], st_fail_rounds);
+        atomicAdd(&iter_stats[11], st_full);
 #endif
     }
 }

@@ -547,10 +547,14 @@ __global__ __launch_bounds__(448) void k_sweep_uniform_gen(const uint32_t* __res
                                                                run-in (the positions before the one it owns from) goes; or null */,
                                                            const uint32_t* __restrict__ redo_in /* or null: every stretch */,
                                                            uint32_t n_cand /* entries per column of seg (redo_in != null) */,
-                                                           const int32_t* __restrict__ nadj /* kAdj: ltot + 1 entries */) {
+                                                           const int32_t* __restrict__ nadj /* kAdj: ltot + 1 entries */,
+                                                           const uint32_t* __restrict__ own_marks /* or null; else per
+                                                               stretch of THIS table: 0 = leave its output as it is (the
+                                                               near-uniform route's later rounds: sweep_segments.inc.hip) */) {
     using Ly = MgLayout<E>;
     // (a later tier of a speculative sweep: only the parts of the genome a disagreement marked)
     if (redo_in != nullptr && (blockIdx.x >= seg[0] || spec_stretch_idle(seg, n_cand, blockIdx.x, redo_in))) return;
+    if (own_marks != nullptr && own_marks[blockIdx.x] == 0) return;
     constexpr int kG = Ly::kG;
     extern __shared__ uint32_t s_mw[];
     const uint32_t lane = threadIdx.x & 63;

@@ -66,7 +66,8 @@ bool launch_sweep_uniform_gen(hipStream_t st, const uint32_t* boff, const uint64
                               uint32_t n_seg_max, uint32_t* selend_run_in = nullptr,
                               const uint32_t* redo_in = nullptr,
                               const int32_t* nadj = nullptr /* near-uniform route: need(p) += nadj[p], capped at the
-                                                               swept reads' coverage (ltot + 1 entries) */);
+                                                               swept reads' coverage (ltot + 1 entries) */,
+                              const uint32_t* own_marks = nullptr /* per stretch of `seg`: 0 = leave its output alone */);
 // Speculative boundaries (kernels/sweep_segments.inc.hip): further tables of the same windows (tier 1, 2
 // behind the exact one in seg_words), with a boundary `burn` positions of run-in wide wherever a window has no
 // cut (call launch_sweep_segments first; *n_speculative receives how many; burn == 0: the exact table again),
@@ -78,7 +79,8 @@ const uint32_t* launch_sweep_segments_speculative(hipStream_t st, const uint64_t
                                                   uint32_t run_ins_apart, uint32_t tier);
 void launch_spec_verify(hipStream_t st, const uint32_t* seg, uint32_t n_cand, uint32_t ell,
                         const uint32_t* owned, const uint32_t* run_in, uint32_t* mismatches,
-                        const uint32_t* redo_in, uint32_t* redo_out);
+                        const uint32_t* redo_in, uint32_t* redo_out,
+                        const uint32_t* own_marks = nullptr /* per stretch of `seg`: which were swept this time */);
 bool launch_sweep_uniform_mw(hipStream_t st, const uint32_t* boff, const uint64_t* d_poff,
                              uint32_t n_contigs, uint32_t ell, uint32_t M, uint32_t ltot,
                              uint32_t* selend, uint32_t* iter_stats, const uint32_t* seg,
@@ -243,7 +245,10 @@ void launch_nu_round(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc
                                               every listed exception is replayed */,
                      uint32_t* dirty /* nu_cells_bytes(): cells that changed since the round before (the last round's
                                         dirty_next) */,
-                     uint32_t* dirty_next);
+                     uint32_t* dirty_next,
+                     const uint32_t* seg_fine = nullptr /* sweeps in speculative stretches: the first tier's table */,
+                     uint32_t* fine_next = nullptr /* n_cand words, out: the stretches of that table the next round's sweep
+                                                      must cover */);
 size_t nu_cells_bytes();
 size_t nu_suspect_bytes(uint32_t suspects_cap);  // `suspects`: the list and, behind it, its bins by start position
 void launch_nu_mark_selected(hipStream_t st, uint32_t* exc, uint32_t cap, uint32_t n_exc, const uint32_t* n_over,

@@ -85,6 +85,26 @@ def test_cfg5_real_share_of_the_heaviest_rank_at_full_length(pkg, oracle, solver
         assert np.array_equal(bits[a:b], wbits), f"contig {share[c]}"
 
 
+def test_cfg5_real_share_with_clipped_reads(pkg, oracle, solver):
+    """the same share (117.7 M, 52.0 M and 24.8 M positions, 129.7 M reads, M = 50) with 1 % of its reads clipped by
+    1 ... 50 bases: long shallow contigs with a tail of shorter spans take the near-uniform route with its sweeps in
+    stretches (a round lists ~140 k suspects there -- with the fixed list of 64 Ki the call
+    went to the mixed-span walk, one chain per contig: 14.5 s); kept set == oracle contig by contig."""
+    share, _ = workloads.cfg5_heaviest_share(8)
+    s, e, offs, lengths = workloads.wgs_contigs(int(1.5e9), int(0.5e9), only=share)
+    s, e = workloads.clipped_mix(s, e, 0.01)
+    got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_giveup == 0, st.as_dict()
+    assert st.near_uniform_exceptions > 1_000_000 and st.near_uniform_selected > 10_000 and st.sweep_stretches > 500
+    bits = np.unpackbits(got.view(np.uint8), bitorder="little")
+    for c in range(lengths.size):
+        a, b = int(offs[c]), int(offs[c + 1])
+        want = oracle.solve(s[a:b], e[a:b], int(lengths[c]), 50)
+        wbits = np.unpackbits(want.view(np.uint8), bitorder="little")[:b - a]
+        assert np.array_equal(bits[a:b], wbits), f"contig {share[c]}"
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_emulated_on_one_gpu(pkg, oracle, solver, world):
     """the N > 1 composition with the HIP solver: assign_contigs -> local_problem -> HIP solve per
