@@ -16,7 +16,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     if (c->opt.near_uniform < 0) return QMCP_OK;
     const uint32_t ell = max_span;
     const double depth = (double)n * (double)ell / ((double)ltot * (double)(M ? M : 1));
-    const bool dbg = c->opt.near_uniform_debug != 0;
+    const bool dbg = c->opt.near_uniform_debug == 1;
     if (dbg) fprintf(stderr, "[near] pm %d may_rank %d ell %u ev %d depth %.2f min_span %u filter %u\n", (int)run.pm,
                      (int)run.may_rank, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
     double min_depth = kNuMinDepth;

@@ -266,3 +266,40 @@ def test_shallow_contigs_are_swept_in_stretches(pkg, oracle, solver, L, depth, M
     assert np.array_equal(got, want), st.as_dict()
     assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_giveup == 0, st.as_dict()
     assert st.sweep_stretches > 2 * st.near_uniform_rounds, st.as_dict()
+
+
+def test_thousands_of_contigs_in_stretches(pkg, oracle, solver):
+    """5 000 small contigs at a shallow depth with clipped reads: the per-stretch marks of the rounds are sized by the
+    contig count (a fixed 4 096 words until round 4: a call of more than 3 328 contigs cleared past its array)"""
+    rng = np.random.default_rng(5000)
+    n_contigs = 5000
+    lengths = rng.integers(1_500, 3_000, size=n_contigs).astype(np.uint32)
+    counts = [int(2.0 * 30 * int(x) / 150) for x in lengths]
+    s, e, offs = _contigs(rng, lengths, counts, 150, 0.01, 50)
+    got = solver.solve(s, e, lengths, 30, contig_read_offsets=offs)
+    st = solver.last_stats
+    want = oracle.solve(s, e, lengths, 30, offs)
+    assert np.array_equal(got, want), st.as_dict()
+    assert st.n_contigs == n_contigs
+
+
+def test_later_rounds_sweep_only_the_stretches_a_selection_reaches(pkg, oracle, solver):
+    """two contigs of 6 M positions at 2 x M with 1 % clipped reads: the rounds after the first sweep only the
+    speculative stretches whose sweep reads or writes something a selection changed (a boundary is compared where the
+    stretch on either side of it was swept) -- fewer stretches in all than rounds x stretches of a whole sweep, and the
+    oracle's mask"""
+    rng = np.random.default_rng(606)
+    lengths = np.array([6_000_000, 6_000_000], np.uint32)
+    counts = [int(2.0 * 20 * int(x) / 150) for x in lengths]
+    s, e, offs = _contigs(rng, lengths, counts, 150, 0.01, 50)
+    got = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_giveup == 0, st.as_dict()
+    with solver.options(near_uniform_debug=2):   # (lab switch: every round sweeps all its exact marks cover)
+        again = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
+        st_all = solver.last_stats
+    assert np.array_equal(got, again)
+    assert st.near_uniform_rounds == st_all.near_uniform_rounds and st.near_uniform_rounds >= 3, st.as_dict()
+    assert st.sweep_stretches < st_all.sweep_stretches, (st.as_dict(), st_all.as_dict())
+    want = oracle.solve(s, e, lengths, 20, offs)
+    assert np.array_equal(got, want), st.as_dict()
