@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 # (QMCP_HIP_LIB: another build of the same library -- lab/variants/<name>/libqmcp_hip.so -- instead of the product's;
 #  lab use only: the host mirror library still links the product's)
 HIP_LIB_PATH = os.environ.get("QMCP_HIP_LIB") or os.path.join(LIB_DIR, "libqmcp_hip.so")
-HOST_LIB_PATH = os.path.join(LIB_DIR, "libqmcp_host.so")
+HOST_LIB_PATH = os.environ.get("QMCP_HOST_LIB") or os.path.join(LIB_DIR, "libqmcp_host.so")  # (e.g. a sanitizer build of the host mirror)
 
 # every symbol include/qmcp_hip.h declares
 ABI_SYMBOLS = (

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqmcp_oracle.so")
+LIB_PATH = os.environ.get("QMCP_ORACLE_LIB") or os.path.join(_HERE, "libqmcp_oracle.so")  # (e.g. a sanitizer build: tools/sanitize_cpu.sh)
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} missing: run `make oracle`")
 _lib = C.CDLL(LIB_PATH)
