@@ -72,6 +72,17 @@ CIGAR_OPS = "MIDNSHP=X"
 BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
+def members(path):
+    """the BGZF members of a file: (offset, total size, uncompressed size) of each, from the BC subfield (BSIZE)"""
+    data = open(path, "rb").read()
+    o = 0
+    while o < len(data):
+        assert data[o:o + 4] == b"\x1f\x8b\x08\x04" and data[o + 12:o + 14] == b"BC"
+        bsize = struct.unpack_from("<H", data, o + 16)[0] + 1
+        yield o, bsize, struct.unpack_from("<I", data, o + bsize - 4)[0]
+        o += bsize
+
+
 def _bgzf_block(payload, level=6):
     co = zlib.compressobj(level, zlib.DEFLATED, -15)
     body = co.compress(payload) + co.flush()
@@ -93,18 +104,24 @@ def pack_record(qname, flag, pos, mapq, cigar, l_seq, ref_id=0, next_ref=-1, nex
     return struct.pack("<I", len(body)) + body
 
 
-def write_bam(path, references, records, text="@HD\tVN:1.6\tSO:unsorted\n", block_payload=40_000):
+def write_bam(path, references, records, text="@HD\tVN:1.6\tSO:unsorted\n", block_payload=40_000, eof=True,
+              empty_member_after=None):
     """references = [(name, length), ...]; records = packed records (pack_record).  Records straddle BGZF
-    block borders (blocks are cut every `block_payload` bytes), as in files written by other tools."""
+    block borders (blocks are cut every `block_payload` bytes), as in files written by other tools.  eof=False leaves
+    the 28-byte end-of-file member out (a truncated-but-whole file: HTSlib warns and reads it); empty_member_after=k
+    puts an empty member (legal anywhere in a BGZF stream) behind the k-th block."""
     text = text + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in references)
     data = b"BAM\x01" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(references))
     for n, l in references:
         data += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", l)
     data += b"".join(records)
     with open(path, "wb") as f:
-        for o in range(0, len(data), block_payload):
+        for k, o in enumerate(range(0, len(data), block_payload)):
             f.write(_bgzf_block(data[o:o + block_payload]))
-        f.write(BGZF_EOF)
+            if empty_member_after is not None and k == empty_member_after:
+                f.write(BGZF_EOF)   # (the end-of-file marker IS an empty member)
+        if eof:
+            f.write(BGZF_EOF)
 
 
 # ---------------------------------------------------------------- an independent SAM rendering (tests only)

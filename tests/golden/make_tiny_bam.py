@@ -52,6 +52,22 @@ def main():
     with open(os.path.join(HERE, "tiny_other_writer.expected.json"), "w") as f:
         json.dump(expected, f, indent=1)
     print(path, os.path.getsize(path), "bytes;", len(recs), "records ->", len(reads), "reads imported")
+    # A second file of the same records the way other tools leave them: a header text of ~1.2 KB (@PG / @CO lines) cut
+    # into BGZF members of 200 bytes -- the header and the reference list span seven members, an empty member sits in
+    # the middle of the stream -- and NO end-of-file member at the end.
+    path2 = os.path.join(HERE, "tiny_multi_member_header.bam")
+    text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(
+        f"@PG\tID:step{k}\tPN:tool{k}\tVN:0.{k}\tCL:tool{k} --in a.bam --out b.bam --threads {k + 1}\n" for k in range(12)
+    ) + "@CO\t" + "a comment line that is there to be long " * 6 + "\n"
+    bam_py.write_bam(path2, [("chrT", 5000), ("chrU", 800)], records(), text=text, block_payload=200, eof=False,
+                     empty_member_after=9)
+    header2, recs2, ref_lengths2 = bam_py.parse(path2)
+    reads2, filtered2 = bam_py.pair_like_the_reference(recs2)
+    assert [r["bam_id"] for r in reads2] == expected["bam_ids"] and ref_lengths2 == ref_lengths
+    with open(os.path.join(HERE, "tiny_multi_member_header.expected.json"), "w") as f:
+        json.dump({"same_import_as": "tiny_other_writer.expected.json", "header_text_bytes": len(bam_py.header_text(header2)),
+                   "members": sum(1 for _ in bam_py.members(path2)), "ends_with_eof_member": False}, f, indent=1)
+    print(path2, os.path.getsize(path2), "bytes; header text", len(text), "bytes")
 
 
 if __name__ == "__main__":

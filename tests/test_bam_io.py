@@ -150,6 +150,30 @@ def test_reader_on_a_file_written_by_another_writer():
     assert [r["bam_id"] for r in reads] == want["bam_ids"] and filtered == want["filtered_out"]
 
 
+def test_reader_on_a_header_over_several_members_without_an_eof_member():
+    """tests/golden/tiny_multi_member_header.bam (make_tiny_bam.py): the same records behind a 1.2 KB header text cut
+    into 200-byte BGZF members -- text and reference list span seven of them --, an empty member in the middle of the
+    stream, and NO end-of-file member (a truncated-but-whole file; HTSlib warns and reads it): the same import"""
+    pkg = importlib.import_module("genome-downsampler_amd")
+    path = os.path.join(GOLDEN, "tiny_multi_member_header.bam")
+    meta = json.load(open(os.path.join(GOLDEN, "tiny_multi_member_header.expected.json")))
+    want = json.load(open(os.path.join(GOLDEN, meta["same_import_as"])))
+    mem = list(bam_py.members(path))
+    assert len(mem) == meta["members"] and mem[-1][2] != 0 and any(u == 0 for _, _, u in mem[:-1])
+    assert open(path, "rb").read()[-28:] != bam_py.BGZF_EOF
+    header, recs, ref_lengths = bam_py.parse(path)
+    assert len(bam_py.header_text(header)) == meta["header_text_bytes"] > 5 * 200
+    ok, n, msg = pkg.check_bam(path)
+    assert ok and n == len(want["bam_ids"]), msg
+    got = pkg.read_bam(path)
+    assert got["ref_genome_length"] == want["ref_lengths"][0]
+    assert got["bam_ids"].tolist() == want["bam_ids"]
+    assert got["starts"].tolist() == [v % (1 << 32) for v in want["starts"]]
+    assert got["ends"].tolist() == [v % (1 << 32) for v in want["ends"]]
+    assert got["qualities"].tolist() == want["qualities"] and got["is_first"].tolist() == want["is_first"]
+    assert got["filtered_out"].tolist() == want["filtered_out"]
+
+
 def test_python_written_file_with_many_records_equals_the_pairing_rules(tmp_path):
     """2 000 pairs in random order with soft clips, deletions, skips and unmapped mates, blocks cut every 5 000
     bytes: C++ reader == independent parse + restated pairing, with and without the -l / -q filters"""

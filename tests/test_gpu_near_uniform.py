@@ -303,3 +303,22 @@ def test_later_rounds_sweep_only_the_stretches_a_selection_reaches(pkg, oracle, 
     assert st.sweep_stretches < st_all.sweep_stretches, (st.as_dict(), st_all.as_dict())
     want = oracle.solve(s, e, lengths, 20, offs)
     assert np.array_equal(got, want), st.as_dict()
+
+
+@pytest.mark.parametrize("run_in", [2, 4, 16])
+def test_partial_rounds_with_boundaries_that_disagree(pkg, oracle, solver, run_in):
+    """the rounds' partial sweeps with a run-in far too short: boundaries disagree in every round, also where a stretch
+    that was swept again meets one that was left alone -- the later tiers take over (k_spec_verify marks the exact
+    stretch), and the mask is still the oracle's"""
+    rng = np.random.default_rng(1000 + run_in)
+    lengths = np.array([3_000_000, 2_000_000], np.uint32)
+    counts = [int(1.8 * 20 * int(x) / 150) for x in lengths]
+    s, e, offs = _contigs(rng, lengths, counts, 150, 0.01, 50)
+    with solver.options(speculation=1, speculation_run_in=run_in):
+        got = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
+        st = solver.last_stats
+    want = oracle.solve(s, e, lengths, 20, offs)
+    assert np.array_equal(got, want), st.as_dict()
+    assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_rounds >= 2, st.as_dict()
+    # (stats.spec_mismatches is the LAST sweep's count -- a partial one: lab/stress_near_uniform.py with QMCP_HIP_SPEC_BURN
+    #  = 2, 8, 32 is where the disagreeing rounds are counted: profiles/r04_stress_near_uniform_shallow_burn*.log)
