@@ -79,6 +79,13 @@ struct qmcp_hip_ctx {
     // one goes straight to the mixed-span route instead of burning the budget again
     uint64_t nu_failed_n = 0, nu_failed_ltot = 0;
     uint32_t nu_failed_ell = 0, nu_failed_M = 0;
+    // ... and a call of this shape settled within this many queued rounds: the next one queues them -- and the ranking
+    // behind them -- without waiting for the device in between (qmcp_hip_solve_device_begin returns at once; the state
+    // words are looked at when the solve is collected, and a call that turns out to need more is solved again the
+    // blocking way)
+    uint64_t nu_need_n = 0, nu_need_ltot = 0;
+    uint32_t nu_need_ell = 0, nu_need_M = 0, nu_need_rounds = 0;
+    bool nu_deferred = false;       // the pending solve's rounds were queued unseen
     DevBuf nu_exc, nu_nadj, nu_ce, nu_state, nu_sus, nu_ckpt, nu_prev;
     uint32_t* h_nu = nullptr;       // pinned landing zone of the route's state words (8)
     uint64_t* h_tables = nullptr;  // pinned staging for the contig tables (2 x (n_contigs + 1))

@@ -149,6 +149,11 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     uint32_t rounds = 0;
     bool settled = false;
     const uint32_t budget = nu_round_budget(c, run.lengths, n_contigs);
+    // A shape that settled within a few rounds last time: queue that many (a round whose contigs are all settled sweeps
+    // and verifies nothing) and the ranking behind them WITHOUT waiting in between; collect_one looks at the state words.
+    const bool defer = !dbg && c->opt.near_uniform_rounds == 0 && c->nu_need_rounds != 0 && c->nu_need_rounds <= 8 &&
+                       c->nu_need_n == run.n64 && c->nu_need_ltot == pr.ltot && c->nu_need_ell == ell && c->nu_need_M == M &&
+                       run.nu_filter == ell;
     while (rounds < budget && !settled) {
         const uint32_t batch = 2u;
         for (uint32_t r = 0; r < batch; ++r) {
@@ -203,7 +208,9 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
             }
         }
         HIP_TRY(hipGetLastError());
+        if (defer && rounds < c->nu_need_rounds) continue;
         HIP_TRY(hipMemcpyAsync(c->h_nu, state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (defer) break;  // (looked at when the solve is collected)
         HIP_TRY(hipStreamSynchronize(st));
         if (dbg) {
             uint32_t more[8];
@@ -219,10 +226,18 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
         if (c->h_nu[2] != 0) break;          // a run the replay does not model, or too many suspects
         settled = c->h_nu[1] == 0;           // the last round wanted no exception: the sweep's counts are the greedy's
     }
-    if (settled) rounds = c->h_nu[6] + 1;    // (the rounds that did something, and the one that found nothing left)
+    c->nu_deferred = defer;
+    if (defer) {
+        settled = true;  // (provisionally: collect_one checks, and solves the call again if it is not)
+    } else if (settled) {
+        c->nu_need_n = run.n64; c->nu_need_ltot = pr.ltot; c->nu_need_ell = ell; c->nu_need_M = M;
+        c->nu_need_rounds = rounds;              // (queued: an even number)
+        rounds = c->h_nu[6] + 1;                 // (the rounds that did something, and the one that found nothing left)
+    }
     local.near_uniform_rounds = rounds;
-    local.near_uniform_selected = c->h_nu[3];
+    local.near_uniform_selected = defer ? 0u : c->h_nu[3];
     if (!settled) {
+        c->nu_need_rounds = 0;
         // (the head must not filter on this span again, and the next call of this shape must not burn the budget again)
         local.near_uniform_giveup = c->h_nu[2] != 0 ? QMCP_NU_GIVEUP_UNMODELLED : QMCP_NU_GIVEUP_BUDGET;
         c->nu_ell = 0;

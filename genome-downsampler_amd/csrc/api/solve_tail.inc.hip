@@ -358,10 +358,29 @@ int enqueue_tail(qmcp_hip_ctx* c) {
     return QMCP_OK;
 }
 
+int solve_enqueue(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_ends, const uint64_t* roff,
+                  const uint32_t* lengths, uint32_t n_contigs, uint64_t n64, uint32_t M, uint64_t* d_mask);
 int collect_one(qmcp_hip_ctx* c, qmcp_hip_stats* st) {
     if (!c->pending) return fail(QMCP_EINVAL, "no solve is pending on this context");
     c->pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->nu_deferred) {
+        // the near-uniform route queued its rounds and the ranking unseen (near_uniform_tail): did they settle?
+        c->nu_deferred = false;
+        if (c->h_nu[2] != 0 || c->h_nu[1] != 0) {
+            // no: the call again, the blocking way (the head clears the mask; the contig tables are the context's copies)
+            c->nu_need_rounds = 0;
+            const SolveRun r = c->run;
+            const size_t count = (size_t)r.n_contigs + 1;
+            std::vector<uint64_t> roff(c->h_tables, c->h_tables + count);
+            std::vector<uint32_t> lengths(r.n_contigs);
+            for (uint32_t k = 0; k < r.n_contigs; ++k) lengths[k] = (uint32_t)(c->h_tables[count + k + 1] - c->h_tables[count + k]);
+            TRY(solve_enqueue(c, r.d_starts, r.d_ends, roff.data(), lengths.data(), r.n_contigs, r.n64, r.M, r.d_mask));
+            return collect_one(c, st);
+        }
+        c->pend_stats.near_uniform_rounds = c->h_nu[6] + 1;
+        c->pend_stats.near_uniform_selected = c->h_nu[3];
+    }
     collect_spans(c);
 #ifdef QMCP_EV_STAMP
     if (c->scalars.p) {

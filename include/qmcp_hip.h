@@ -243,11 +243,15 @@ int qmcp_hip_solve_device(qmcp_hip_ctx* ctx,
  * after `hip_stream`, enqueues all of it and returns without waiting for the device (it does wait
  * for one 16-byte read-back that picks the kernels; the device keeps working on other contexts
  * meanwhile).  That holds for calls whose reads have ONE length (QMCP_PATH_UNIFORM).  A call with other
- * lengths is decided by what the device finds: on QMCP_PATH_NEAR_UNIFORM _begin waits for the device two to
- * three times and once more per pair of rounds (each round's outcome decides whether another is queued), on
- * QMCP_PATH_GENERAL once more where it samples the lengths -- _begin then returns when most of the solve has
- * RUN, and a pipelined caller gets little overlap out of it (bench.py reports both rates for cfg4 with 1 % of
- * the reads shortened: other_configs.cfg4_1pct_clipped.pipelined_ms against device_ms).  A context's first call
+ * lengths is decided by what the device finds: on QMCP_PATH_NEAR_UNIFORM the FIRST call of a shape (reads, positions,
+ * dominant length, M) waits for the device two to three times and once more per pair of rounds (each round's outcome
+ * decides whether another is queued) -- _begin then returns when most of the solve has RUN.  The context remembers in
+ * how many rounds the shape settled (up to eight), and the next call of it queues that many rounds and the ranking
+ * behind them without looking: _begin returns at once again, _end looks at the route's state words and, should
+ * the call have needed more rounds than were queued, solves it again the blocking way before it returns (bench.py
+ * reports both rates for cfg4 with 1 % of the reads shortened: other_configs.cfg4_1pct_clipped.pipelined_ms 1.75
+ * against device_ms 2.27; before round 4's second half 2.24).  On QMCP_PATH_GENERAL _begin waits once more where it
+ * samples the lengths.  A context's first call
  * of a shape may also grow its arena after work is queued (stats.arena_grown_mid_solve), which waits for every
  * stream of the context; the second call of the shape does not.  _end waits for the solve and fills `stats`.  One pending solve per context: a second
  * _begin, or any other entry point of the same context, before _end fails with QMCP_EINVAL.

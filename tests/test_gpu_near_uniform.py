@@ -322,3 +322,26 @@ def test_partial_rounds_with_boundaries_that_disagree(pkg, oracle, solver, run_i
     assert st.path == pkg.PATH_NEAR_UNIFORM and st.near_uniform_rounds >= 2, st.as_dict()
     # (stats.spec_mismatches is the LAST sweep's count -- a partial one: lab/stress_near_uniform.py with QMCP_HIP_SPEC_BURN
     #  = 2, 8, 32 is where the disagreeing rounds are counted: profiles/r04_stress_near_uniform_shallow_burn*.log)
+
+
+def test_rounds_queued_unseen_and_a_call_that_needs_more(pkg, oracle):
+    """a shape that settled within a few rounds is remembered: the next call of it queues those rounds and the ranking
+    without waiting for the device in between (qmcp_hip_solve_device_begin returns at once), and the state words are
+    looked at when the solve is collected.  Same shape, other reads that need MORE rounds: the collection notices and
+    solves the call again the blocking way -- every mask the oracle's"""
+    rng = np.random.default_rng(2024)
+    lengths = np.array([400_000], np.uint32)
+    n, M = 1_200_000, 40          # 11.25 x M: the event-driven chain
+    sa, ea, offs = _contigs(rng, lengths, [n], 150, 0.001, 10)
+    sb, eb, _ = _contigs(rng, lengths, [n], 150, 0.05, 60)
+    wa = oracle.solve(sa, ea, lengths, M, offs)
+    wb = oracle.solve(sb, eb, lengths, M, offs)
+    with pkg.Solver(0) as sv:
+        rounds = []
+        for s, e, w in ((sa, ea, wa), (sa, ea, wa), (sa, ea, wa), (sb, eb, wb), (sb, eb, wb), (sb, eb, wb), (sa, ea, wa)):
+            got = sv.solve(s, e, lengths, M, contig_read_offsets=offs)
+            st = sv.last_stats
+            assert np.array_equal(got, w), (rounds, st.as_dict())
+            assert st.path == pkg.PATH_NEAR_UNIFORM, st.as_dict()
+            rounds.append(int(st.near_uniform_rounds))
+        assert rounds[0] == rounds[1] == rounds[2] == rounds[6] and rounds[3] == rounds[4] == rounds[5], rounds
