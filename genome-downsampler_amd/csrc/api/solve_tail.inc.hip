@@ -261,7 +261,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
             // windows of max_span positions
             // (the first tier starts lower than for one span: a walk is slow per position, so short stretches
             //  matter more, and the second tier is there)
-            const uint32_t burn_blocks = c->opt.speculation_run_in ? spec_first_run_in(c, depth) : spec_first_run_in(c, depth) * 3u / 5u;
+            uint32_t burn_blocks = c->opt.speculation_run_in ? spec_first_run_in(c, depth) : spec_first_run_in(c, depth) * 3u / 5u;
             bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M;
             if (!hopeless && spec_wanted(c, depth) && in_regs && seg != nullptr && n >= (1u << 20)) {
                 // One dominant read length (what is left for this route once the shorter reads have their own: a few
@@ -274,7 +274,24 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                 uint32_t share[2] = {0, 0};
                 HIP_TRY(hipMemcpyAsync(share, d_share, sizeof(share), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
-                hopeless = share[0] != 0 && (uint64_t)share[1] * 10u >= (uint64_t)share[0] * 9u;
+                if (share[0] != 0 && (uint64_t)share[1] * 10u >= (uint64_t)share[0] * 9u) {
+                    // Second half of round 4: that finding was about how DEEP the data is in standard deviations, not about
+                    // the one length.  The run-in table (spec_burn_blocks) was measured at M = 50; what makes a sweep forget
+                    // is how often the coverage comes near M, i.e. z = (mean coverage - M) / sqrt(mean coverage) =
+                    // sqrt(M) (d - 1) / sqrt(d) for Poisson starts -- the lab's reads at 2.1 x M with M = 350 are as deep as
+                    // M = 50 at 6 x M, and their boundaries disagreed at the run-in of 2.1 x M.  So: the depth at which
+                    // M = 50 has the same z; below 3.1 of it the walk speculates with that depth's whole run-in (not three
+                    // fifths: a boundary that disagrees costs its exact stretch again, and on such data exact stretches are
+                    // long), deeper it does not.  One GPU's real share of configs[4] (117.7 M positions in its longest
+                    // contig, 2 x M, M = 50) with 1 % clipped reads, this route: 14.5 s as one chain per contig, 52 ms in
+                    // 1 925 stretches, no boundary disagreeing (lab/cfg5_share_mixed_spec.py) -- which is what a whole-genome
+                    // BAM with reads LONGER than the dominant length (deletions) gets, since those leave the near-uniform route.
+                    const double y = std::sqrt((double)M / 50.0) * (depth - 1.0) / std::sqrt(depth > 0.01 ? depth : 0.01);
+                    const double x = 0.5 * (y + std::sqrt(y * y + 4.0));
+                    const double depth_eff = depth > 1.0 ? x * x : depth;
+                    hopeless = !(depth_eff < 3.1);
+                    if (!hopeless) burn_blocks = spec_first_run_in(c, depth_eff > depth ? depth_eff : depth);
+                }
             }
             if (c->opt.speculation != 0 || c->opt.speculation_run_in != 0) hopeless = false;
             const bool speculate = !hopeless && spec_wanted(c, depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&

@@ -91,3 +91,16 @@ def clipped_mix(starts, ends, fraction, max_clip=50, seed=7):
     s[pick[front]] += clip[front]
     e[pick[~front]] -= clip[~front]
     return s, e
+
+
+def lengthened_mix(starts, ends, contig_read_offsets, contig_lengths, fraction, max_extra=20, seed=9):
+    """a fraction of the reads LENGTHENED by 1 ... max_extra bases (a deletion against the reference lengthens a read's
+    span: BamApi takes it from the CIGAR's reference length, libs/bam-api/src/read.cpp:11-13), never past the read's
+    contig: returns the new ends"""
+    rng = np.random.default_rng(seed)
+    e = np.array(ends, dtype=np.uint32, copy=True)
+    offs = np.asarray(contig_read_offsets, dtype=np.int64)
+    last = np.repeat(np.asarray(contig_lengths, dtype=np.int64) - 1, np.diff(offs))
+    j = rng.choice(e.size, size=int(e.size * fraction), replace=False)
+    e[j] = np.minimum(e[j].astype(np.int64) + rng.integers(1, max_extra + 1, size=j.size), last[j]).astype(np.uint32)
+    return e

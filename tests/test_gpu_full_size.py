@@ -105,6 +105,27 @@ def test_cfg5_real_share_with_clipped_reads(pkg, oracle, solver):
         assert np.array_equal(bits[a:b], wbits), f"contig {share[c]}"
 
 
+def test_cfg5_real_share_with_longer_reads(pkg, oracle, solver):
+    """the same share with 1 % clipped AND 0.5 % of the reads lengthened by 1 ... 20 bases (deletions): reads longer than
+    the dominant length leave the near-uniform route; the mixed-span walk then must not be one chain per contig (14.5 s for
+    the 117.7 M-position contig): it speculates -- the rule is how deep the data is in standard deviations, not that one
+    length dominates -- and its boundaries hold; kept set == oracle contig by contig"""
+    share, _ = workloads.cfg5_heaviest_share(8)
+    s, e, offs, lengths = workloads.wgs_contigs(int(1.5e9), int(0.5e9), only=share)
+    s, e = workloads.clipped_mix(s, e, 0.01)
+    e = workloads.lengthened_mix(s, e, offs, lengths, 0.005)
+    got = solver.solve(s, e, lengths, 50, contig_read_offsets=offs)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_GENERAL and st.near_uniform_giveup == 2, st.as_dict()
+    assert st.spec_boundaries > 300 and st.sweep_stretches > 300 and st.ms_total < 1000.0, st.as_dict()
+    bits = np.unpackbits(got.view(np.uint8), bitorder="little")
+    for c in range(lengths.size):
+        a, b = int(offs[c]), int(offs[c + 1])
+        want = oracle.solve(s[a:b], e[a:b], int(lengths[c]), 50)
+        wbits = np.unpackbits(want.view(np.uint8), bitorder="little")[:b - a]
+        assert np.array_equal(bits[a:b], wbits), f"contig {share[c]}"
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_emulated_on_one_gpu(pkg, oracle, solver, world):
     """the N > 1 composition with the HIP solver: assign_contigs -> local_problem -> HIP solve per

@@ -238,3 +238,25 @@ def test_one_dominant_read_length_does_not_speculate_a_broad_mix_does(pkg, oracl
     st = solver.last_stats
     assert st.path == pkg.PATH_GENERAL and np.array_equal(got, oracle.solve(s2, e2, lengths, M)), st.as_dict()
     assert st.spec_boundaries >= 2 and st.spec_mismatches == 0, st.as_dict()
+
+
+def test_a_shallow_genome_with_longer_reads_speculates_on_the_mixed_span_route(pkg, oracle, solver):
+    """one dominant read length plus reads LONGER than it (deletions) leaves the near-uniform route; on a long shallow
+    contig (2 x M, M = 50: cfg5's depth -- five standard deviations above M, a handful of real cut points) the mixed-span walk must not be
+    one chain per contig: its speculative boundaries are used (the rule is how deep the data is in standard deviations,
+    not that one length dominates) and hold; the oracle's mask"""
+    rng = np.random.default_rng(77)
+    L, M, span = 12_000_000, 50, 150
+    n = int(2.0 * M * L / span)
+    lengths = np.array([L], np.uint32)
+    s = rng.integers(0, L - span - 24, size=n, dtype=np.uint32)
+    e = (s + np.uint32(span - 1)).astype(np.uint32)
+    j = rng.choice(n, size=n // 200, replace=False)
+    e[j] += rng.integers(1, 21, size=j.size).astype(np.uint32)          # deletions: longer spans
+    k = rng.choice(n, size=n // 100, replace=False)
+    s[k] += rng.integers(1, 40, size=k.size).astype(np.uint32)          # and soft clips: shorter ones
+    got = solver.solve(s, e, lengths, M)
+    st = solver.last_stats
+    assert st.path == pkg.PATH_GENERAL and st.near_uniform_giveup == 2, st.as_dict()   # (longer reads)
+    assert np.array_equal(got, oracle.solve(s, e, lengths, M)), st.as_dict()
+    assert st.spec_boundaries >= 10 and st.spec_mismatches == 0 and st.sweep_stretches >= 12, st.as_dict()

@@ -10,3 +10,4 @@ wgs_contigs = _syn.wgs_contigs
 wgs_shape = _syn.wgs_shape
 cfg5_heaviest_share = _syn.cfg5_heaviest_share
 clipped_mix = _syn.clipped_mix
+lengthened_mix = _syn.lengthened_mix
