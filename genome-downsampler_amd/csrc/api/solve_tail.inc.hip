@@ -289,8 +289,16 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                     const double y = std::sqrt((double)M / 50.0) * (depth - 1.0) / std::sqrt(depth > 0.01 ? depth : 0.01);
                     const double x = 0.5 * (y + std::sqrt(y * y + 4.0));
                     const double depth_eff = depth > 1.0 ? x * x : depth;
+                    const double d_run = depth_eff > depth ? depth_eff : depth;
                     hopeless = !(depth_eff < 3.1);
-                    if (!hopeless) burn_blocks = spec_first_run_in(c, depth_eff > depth ? depth_eff : depth);
+                    if (hopeless && depth_eff < kSpecDepth) {
+                        // deeper than that (run-ins of 1 536 blocks and more) only where the longest contig holds a dozen
+                        // run-ins: a 10^6-position contig would become two stretches, a chromosome becomes hundreds
+                        uint32_t longest = 0;
+                        for (uint32_t k = 0; k < n_contigs; ++k) longest = lengths[k] > longest ? lengths[k] : longest;
+                        hopeless = (uint64_t)longest < 12ull * spec_first_run_in(c, d_run) * max_span;
+                    }
+                    if (!hopeless) burn_blocks = spec_first_run_in(c, d_run);
                 }
             }
             if (c->opt.speculation != 0 || c->opt.speculation_run_in != 0) hopeless = false;
