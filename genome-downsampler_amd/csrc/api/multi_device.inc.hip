@@ -19,7 +19,7 @@ bool share_sweeps_as_stretches(double reads, double positions, size_t n_contigs,
     if (span == 0 || M == 0 || positions <= 0 || n_contigs >= 256) return false;
     const double depth = reads * (double)span / (positions * (double)M);
     if (depth <= kSpecMinDepth) return positions >= 128.0 * (double)span;  // nearly every window has a real cut
-    return depth < kSpecDepth && positions >= 8.0 * (double)spec_burn_blocks(depth) * (double)span;
+    return depth < kSpecDepth && positions >= 8.0 * (double)spec_burn_blocks(spec_depth_in_sigma(depth, M)) * (double)span;
 }
 double share_cost(double reads, double positions, double longest, size_t n_contigs, uint32_t span, uint32_t M) {
     if (share_sweeps_as_stretches(reads, positions, n_contigs, span, M))

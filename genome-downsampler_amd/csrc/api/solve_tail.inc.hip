@@ -286,10 +286,8 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                     // contig, 2 x M, M = 50) with 1 % clipped reads, this route: 14.5 s as one chain per contig, 52 ms in
                     // 1 925 stretches, no boundary disagreeing (lab/cfg5_share_mixed_spec.py) -- which is what a whole-genome
                     // BAM with reads LONGER than the dominant length (deletions) gets, since those leave the near-uniform route.
-                    const double y = std::sqrt((double)M / 50.0) * (depth - 1.0) / std::sqrt(depth > 0.01 ? depth : 0.01);
-                    const double x = 0.5 * (y + std::sqrt(y * y + 4.0));
-                    const double depth_eff = depth > 1.0 ? x * x : depth;
-                    const double d_run = depth_eff > depth ? depth_eff : depth;
+                    const double depth_eff = spec_depth_in_sigma(depth, M);   // (uniform_sweep.inc.hip; >= depth)
+                    const double d_run = depth_eff;
                     hopeless = !(depth_eff < 3.1);
                     if (hopeless && depth_eff < kSpecDepth) {
                         // deeper than that (run-ins of 1 536 blocks and more) only where the longest contig holds a dozen

@@ -39,6 +39,21 @@ bool spec_wanted(const qmcp_hip_ctx* c, double depth) {
 uint32_t spec_first_run_in(const qmcp_hip_ctx* c, double depth) {
     return c->opt.speculation_run_in ? c->opt.speculation_run_in : spec_burn_blocks(depth);
 }
+// The table above was measured at M = 50.  What makes a sweep forget its start is how often the coverage comes near M --
+// how many standard deviations above M it sits: z = (mean coverage - M) / sqrt(mean coverage) = sqrt(M) (d - 1) / sqrt(d)
+// for Poisson starts at depth d x M.  This is the depth at which M = 50 has the same z; the run-in is looked up at the
+// larger of the two (a smaller M keeps the table's value: measured over-provisioned, not under).  Second half of round 4,
+// lab/spec_run_in_vs_M.py, one contig of 60 M positions, one read length, boundaries that disagreed / sweep ms at the
+// table's run-in and at the corrected one: M = 100 at 2 x M: 12 of 255 / 1.98 -> (1 152 blocks) none; M = 100 at 3 x M:
+// 16 of 85 / 5.75 -> 4 of 63 / 7.5; **M = 200 at 2 x M: 161 of 255, the second tier failing too: the exact sweep, 94 ms ->
+// (2 304 blocks) ~10 ms**.
+double spec_depth_in_sigma(double depth, uint32_t M) {
+    if (!(depth > 1.0)) return depth;
+    const double y = std::sqrt((double)M / 50.0) * (depth - 1.0) / std::sqrt(depth);
+    const double x = 0.5 * (y + std::sqrt(y * y + 4.0));
+    const double d_eff = x * x;
+    return d_eff > depth ? d_eff : depth;
+}
 
 // device words of a speculative sweep, behind the solve's other scalars
 struct SpecWords {
@@ -127,7 +142,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // run-in (every few windows, so that stretches stay several run-ins long); the stretches' outputs are compared where they
     // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
     // returns at once when all agreed).
-    const uint32_t burn_blocks = spec_first_run_in(c, depth);
+    const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M));
     const bool speculate = spec_wanted(c, depth) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
                            burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {

@@ -28,6 +28,16 @@ def spec_burn_blocks(depth):
     return 320 if depth < 2.1 else 640 if depth < 2.6 else 1152 if depth < 3.1 else 2304 if depth < 4.1 else 1536
 
 
+def spec_depth_in_sigma(depth, max_coverage):
+    """the depth at which M = 50 -- where the run-in table was measured -- sits as many standard deviations above M as
+    this depth does at max_coverage; never below the depth itself (csrc/api/uniform_sweep.inc.hip: spec_depth_in_sigma)"""
+    if not depth > 1.0:
+        return depth
+    y = (max_coverage / 50.0) ** 0.5 * (depth - 1.0) / depth ** 0.5
+    x = 0.5 * (y + (y * y + 4.0) ** 0.5)
+    return max(x * x, depth)
+
+
 def share_sweeps_as_stretches(reads, positions, n_contigs, read_length, max_coverage):
     """the solver's own predicate on a whole share (a list of contigs solved in one call)"""
     if not read_length or not max_coverage or positions <= 0 or n_contigs >= MAX_SPLIT_CONTIGS:
@@ -35,7 +45,7 @@ def share_sweeps_as_stretches(reads, positions, n_contigs, read_length, max_cove
     depth = float(reads) * float(read_length) / (float(positions) * float(max_coverage))
     if depth <= CUT_DEPTH:
         return positions >= 128 * read_length
-    return depth < STRETCH_DEPTH and positions >= 8 * spec_burn_blocks(depth) * read_length
+    return depth < STRETCH_DEPTH and positions >= 8 * spec_burn_blocks(spec_depth_in_sigma(depth, max_coverage)) * read_length
 
 
 def share_cost(reads, positions, longest, n_contigs, read_length=None, max_coverage=None):

@@ -215,12 +215,12 @@ def test_depths_between_4_and_11_times_m_are_swept_as_stretches_too(pkg, oracle,
 
 
 def test_one_dominant_read_length_does_not_speculate_a_broad_mix_does(pkg, oracle, solver):
-    """the mixed-span route samples the spans before it queues anything: one dominant read length with a few LONGER reads
-    (5 x M deep) forgets its state as slowly as one-length data -- its speculative boundaries would disagree nearly
-    everywhere and the exact sweep would run after two wasted tiers -- so it does not speculate; a broad mix of lengths
-    at the same depth does, and its boundaries hold; the oracle's mask either way"""
+    """the mixed-span route samples the spans before it queues anything: one dominant read length with a few LONGER reads,
+    5 x M deep at M = 60 (as many standard deviations above M as M = 50 at 5.7 x M: a run-in of 1 536 blocks) on a contig
+    that does not hold a dozen such run-ins, forgets its state too slowly for stretches to pay -- it does not speculate;
+    a broad mix of lengths at the same depth does, and its boundaries hold; the oracle's mask either way"""
     rng = np.random.default_rng(5)
-    L, M, span = 3_000_000, 60, 150
+    L, M, span = 2_000_000, 60, 150
     n = int(5 * M * L / span)
     lengths = np.array([L], np.uint32)
     s = rng.integers(0, L - span - 8, size=n, dtype=np.uint32)
