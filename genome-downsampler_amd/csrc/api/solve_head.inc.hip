@@ -90,7 +90,7 @@ int enqueue_head(qmcp_hip_ctx* c, const uint32_t* d_starts, const uint32_t* d_en
         TRY(ensure(c, c->ranges, (65537 + 7 + 771 + 5) * sizeof(uint32_t)));  // range starts, heaviest load, level-2 tables
         if (n >= rank_min_reads(c) && qmcp::range_path_supported(ltot))
             TRY(ensure(c, c->rankamb, qmcp::rank_scratch_bytes(qmcp::range_shift_for(ltot), ltot, n)));
-        TRY(ensure(c, c->stats, 8 * sizeof(uint32_t)));
+        TRY(ensure(c, c->stats, 12 * sizeof(uint32_t)));  // (words 6..8: the mixed-span route's sample of the spans)
         // (the near-uniform route's buffers: a context that has met mixed spans may look at the route on any call)
         if (c->nu_ell != 0 || c->mixed_seen) TRY(ensure_near_uniform(c, n, ltot, n_contigs));
         // The mixed-span route's own arrays.  Which route a call takes is known only after its first kernel,

@@ -271,7 +271,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                 // tells the two apart before anything is queued.
                 uint32_t* d_share = (uint32_t*)c->stats.p + 6;
                 qmcp::launch_span_mode_share(c->stream, d_starts, d_ends, n, d_share);
-                uint32_t share[2] = {0, 0};
+                uint32_t share[3] = {0, 0, 0};
                 HIP_TRY(hipMemcpyAsync(share, d_share, sizeof(share), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 if (share[0] != 0 && (uint64_t)share[1] * 10u >= (uint64_t)share[0] * 9u) {
@@ -286,7 +286,10 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                     // contig, 2 x M, M = 50) with 1 % clipped reads, this route: 14.5 s as one chain per contig, 52 ms in
                     // 1 925 stretches, no boundary disagreeing (lab/cfg5_share_mixed_spec.py) -- which is what a whole-genome
                     // BAM with reads LONGER than the dominant length (deletions) gets, since those leave the near-uniform route.
-                    const double depth_eff = spec_depth_in_sigma(depth, M);   // (uniform_sweep.inc.hip; >= depth)
+                    // (the call's depth is counted with the LONGEST span; nine tenths of the reads have this one)
+                    const double depth_mode = share[2] >= 1 && share[2] < 511 && share[2] < max_span
+                                                  ? depth * (double)share[2] / (double)max_span : depth;
+                    const double depth_eff = spec_depth_in_sigma(depth_mode, M);   // (uniform_sweep.inc.hip; >= its argument)
                     const double d_run = depth_eff;
                     hopeless = !(depth_eff < 3.1);
                     if (hopeless && depth_eff < kSpecDepth) {

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_nu_count_span(const uint32_t* __restric
 }
 
 // How uniform are the spans?  A strided sample of the reads into 512 span bins (LDS), then the fullest bin's share:
-// out[0] = reads sampled, out[1] = reads in the fullest bin.  One workgroup: the sample is 64 Ki reads at most.
+// out[0] = reads sampled, out[1] = reads in the fullest bin, out[2] = its span.  One workgroup: the sample is 64 Ki reads at most.
 __global__ __launch_bounds__(1024) void k_nu_span_mode_share(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
                                                              uint32_t n, uint32_t stride, uint32_t* __restrict__ out) {
     __shared__ uint32_t s_bin[512];
@@ -94,10 +94,12 @@ __global__ __launch_bounds__(1024) void k_nu_span_mode_share(const uint32_t* __r
         uint32_t m = 0;
         for (uint32_t w = 0; w < blockDim.x / 64; ++w) m = max(m, s_red[w]);
         out[1] = m;
+        for (uint32_t i = 0; i < 512; ++i)
+            if (s_bin[i] == m) { out[2] = i; break; }  // the fullest bin's span (511: that or longer)
     }
 }
-void launch_span_mode_share(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t* out /* 2 words, zeroed here */) {
-    (void)hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), st);
+void launch_span_mode_share(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t* out /* 3 words, zeroed here */) {
+    (void)hipMemsetAsync(out, 0, 3 * sizeof(uint32_t), st);
     const uint32_t stride = n > 65536u ? n / 65536u : 1u;
     hipLaunchKernelGGL(k_nu_span_mode_share, dim3(1), dim3(1024), 0, st, starts, ends, n, stride, out);
 }

@@ -224,7 +224,7 @@ void launch_pm_settle(hipStream_t st, const uint16_t* keys16, const uint16_t* id
 
 
 // near-uniform route (kernels/near_uniform.inc.hip): one dominant span, a few shorter reads as listed exceptions
-void launch_span_mode_share(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t* out /* 2 words */);
+void launch_span_mode_share(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t* out /* 3 words: sampled, in the fullest bin, its span */);
 size_t nu_exc_bytes(uint32_t cap);
 uint32_t* nu_exc_counts(uint32_t* exc, uint32_t cap);  // the groups' counts inside the list's buffer  // the exception list: start, end, index (k_pm_prepare_sort), selection time, event key, group counts
 void launch_nu_count_span(hipStream_t st, const uint32_t* starts, const uint32_t* ends, uint32_t n, uint32_t span, uint32_t* out);
