@@ -36,12 +36,17 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     for (uint32_t k = 0; k < n_contigs; ++k) longest = run.lengths[k] > longest ? run.lengths[k] : longest;
     // (the event-driven form's own limits: scratch for short spans, M in a packed field)
     const bool ev_ok = ell >= ev_min_span() && qmcp::sweep_uniform_ev_supported(ell, M);
-    bool stretches = depth < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth < kNuStretchDepth || longest > 2000000u || !ev_ok);
+    // (many times M and yet sparse -- a small M: more than half of the blocks hold a position without a read, the chain
+    //  would run its general step on nearly every block -- is shallow in standard deviations: stretches, as in
+    //  launch_uniform_sweep.  66 M reads on one contig of 82.6 M positions at 12 x M with M = 10, 1 % clipped: 3.2 s in chains.)
+    const bool sparse = (double)n / (double)ltot < std::log((double)ell / 0.693);
+    const double depth_gate = (depth >= kGenDepth && sparse && spec_sigma_depth(depth, M) < kGenDepth) ? spec_sigma_depth(depth, M) : depth;
+    bool stretches = depth_gate < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth_gate < kNuStretchDepth || longest > 2000000u || !ev_ok);
     if (c->opt.sweep == QMCP_SWEEP_EVENTS) stretches = false;
     if (c->opt.sweep == QMCP_SWEEP_GENERAL) stretches = qmcp::sweep_uniform_mw_supported(ell);
     if (!stretches) {
         if (!ev_ok) return QMCP_OK;
-        if (depth < kGenDepth && longest > 2000000u) return QMCP_OK;  // (spans the pipeline does not take: a whole chain per round)
+        if (depth_gate < kGenDepth && longest > 2000000u) return QMCP_OK;  // (spans the pipeline does not take: a whole chain per round)
     }
     if (c->nu_failed_n == run.n64 && c->nu_failed_ltot == pr.ltot && c->nu_failed_ell == ell && c->nu_failed_M == M) {
         local.near_uniform_giveup = QMCP_NU_GIVEUP_REMEMBERED;
@@ -124,7 +129,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                                               (const uint32_t*)c->nu_ce.p);
             n_seg_max = n_contigs + windows;
         }
-        speculate = spec_wanted(c, depth) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
+        speculate = spec_wanted(c, depth_gate) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
         // (stretches two run-ins long instead of the one-span route's four: the route sweeps several times, and a sweep is
         //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> 0.24 ms a sweep; one run-in long: 0.37)
     }

@@ -227,7 +227,11 @@ int enqueue_tail(qmcp_hip_ctx* c) {
         const double depth = (double)n * (double)max_span / ((double)ltot * (double)(M ? M : 1));
         // (a mixed-span walk is one light workgroup per stretch and slow per position: five times the windows
         //  the one-span sweeps get, whose seven-wave workgroups fill the chip at three per compute unit)
-        const uint32_t windows = sweep_cut_windows(c, ltot, max_span, n_contigs, depth < kGenDepth, qmcp::kMaxSweepWindows);
+        // (many times M and yet sparse -- a small M -- is shallow in standard deviations: launch_uniform_sweep)
+        const bool sparse_deep = depth >= kGenDepth && (double)n / (double)ltot < std::log((double)max_span / 0.693) &&
+                                 spec_sigma_depth(depth, M) < kGenDepth;
+        const double depth_gate = sparse_deep ? spec_sigma_depth(depth, M) : depth;
+        const uint32_t windows = sweep_cut_windows(c, ltot, max_span, n_contigs, depth_gate < kGenDepth, qmcp::kMaxSweepWindows);
         if (windows != 0) {
             KernelSpan sp(c, "k_find_cuts");
             seg = qmcp::launch_sweep_segments(c->stream, (const uint32_t*)c->boff.p, (const uint32_t*)c->eoff.p,
@@ -263,7 +267,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
             //  matter more, and the second tier is there)
             uint32_t burn_blocks = c->opt.speculation_run_in ? spec_first_run_in(c, depth) : spec_first_run_in(c, depth) * 3u / 5u;
             bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M;
-            if (!hopeless && spec_wanted(c, depth) && in_regs && seg != nullptr && n >= (1u << 20)) {
+            if (!hopeless && spec_wanted(c, depth_gate) && in_regs && seg != nullptr && n >= (1u << 20)) {
                 // One dominant read length (what is left for this route once the shorter reads have their own: a few
                 // LONGER ones) forgets its state as slowly as one-length data, and the walk's boundaries then disagree
                 // nearly everywhere (lab/mixed_spec_check.py: 430 against 185 ms at 7.5 x M); a broad mix of lengths
@@ -289,7 +293,8 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                     // (the call's depth is counted with the LONGEST span; nine tenths of the reads have this one)
                     const double depth_mode = share[2] >= 1 && share[2] < 511 && share[2] < max_span
                                                   ? depth * (double)share[2] / (double)max_span : depth;
-                    const double depth_eff = spec_depth_in_sigma(depth_mode, M);   // (uniform_sweep.inc.hip; >= its argument)
+                    const double depth_eff = sparse_deep ? spec_sigma_depth(depth_mode, M)     // (a small M: shallower than its depth)
+                                                         : spec_depth_in_sigma(depth_mode, M);  // (uniform_sweep.inc.hip; >= its argument)
                     const double d_run = depth_eff;
                     hopeless = !(depth_eff < 3.1);
                     if (hopeless && depth_eff < kSpecDepth) {
@@ -303,7 +308,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                 }
             }
             if (c->opt.speculation != 0 || c->opt.speculation_run_in != 0) hopeless = false;
-            const bool speculate = !hopeless && spec_wanted(c, depth) && in_regs && seg != nullptr && burn_blocks >= 2 &&
+            const bool speculate = !hopeless && spec_wanted(c, depth_gate) && in_regs && seg != nullptr && burn_blocks >= 2 &&
                                    (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {
                 TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(n_seg_max)));

@@ -47,11 +47,14 @@ uint32_t spec_first_run_in(const qmcp_hip_ctx* c, double depth) {
 // table's run-in and at the corrected one: M = 100 at 2 x M: 12 of 255 / 1.98 -> (1 152 blocks) none; M = 100 at 3 x M:
 // 16 of 85 / 5.75 -> 4 of 63 / 7.5; **M = 200 at 2 x M: 161 of 255, the second tier failing too: the exact sweep, 94 ms ->
 // (2 304 blocks) ~10 ms**.
-double spec_depth_in_sigma(double depth, uint32_t M) {
+double spec_sigma_depth(double depth, uint32_t M) {   // (may be smaller than the depth: a small M)
     if (!(depth > 1.0)) return depth;
     const double y = std::sqrt((double)M / 50.0) * (depth - 1.0) / std::sqrt(depth);
     const double x = 0.5 * (y + std::sqrt(y * y + 4.0));
-    const double d_eff = x * x;
+    return x * x;
+}
+double spec_depth_in_sigma(double depth, uint32_t M) {
+    const double d_eff = spec_sigma_depth(depth, M);
     return d_eff > depth ? d_eff : depth;
 }
 
@@ -128,6 +131,19 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // block, which holds while coverage is many times M
     const double depth = (double)n * (double)span / ((double)ltot * (double)(M ? M : 1));
     bool gen = depth < kGenDepth;
+    // Many times M and yet SPARSE (a small M: depth 12 x M with M = 10 is 0.8 reads a position): more than half of the blocks
+    // hold a position without a read, so the event-driven form is out (below) and the fast form's check fails nearly
+    // everywhere (~1 130 cycles a block measured); and in standard deviations such data is shallow -- it forgets as M = 50
+    // at 3.7 x M does.  The general pipeline in speculative stretches, then, as below 11 x M (second half of round 4,
+    // lab/cliff_hunt.py: one contig of 82.6 M positions, 66 M reads of one length, M = 10: 259 ms as one chain).
+    double depth_gate = depth;   // what decides whether boundaries are speculated on
+    {
+        const double structural0 = (double)n_contigs * (double)(span - 1);
+        const double holes0 = (double)empty_positions > structural0 ? (double)empty_positions - structural0 : 0.0;
+        const bool sparse = empty_positions != 0xFFFFFFFFu && holes0 * (double)span > 0.693 * (double)ltot;
+        const double ds = spec_sigma_depth(depth, M);
+        if (!gen && sparse && ds < kGenDepth) { gen = true; depth_gate = ds; }
+    }
     if (c->opt.sweep == QMCP_SWEEP_GENERAL) gen = true;
     if (c->opt.sweep == QMCP_SWEEP_FAST) gen = false;
     const uint32_t* boff = (const uint32_t*)c->boff.p;
@@ -143,7 +159,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
     // returns at once when all agreed).
     const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M));
-    const bool speculate = spec_wanted(c, depth) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
+    const bool speculate = spec_wanted(c, depth_gate) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
                            burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);

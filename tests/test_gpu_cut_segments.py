@@ -106,9 +106,14 @@ def test_default_is_on_for_shallow_data_and_off_for_deep(pkg, oracle, solver):
         got = solver.solve(s, e, L, 10)
         assert solver.last_stats.sweep_stretches > 1
         assert np.array_equal(got, oracle.solve(s, e, L, 10))
-        s, e = _reads(rng, 1_000_000, L, span)           # coverage 250 = 25 M
-        solver.solve(s, e, L, 10)
+        s, e = _reads(rng, 4_000_000, L, span)           # coverage 1 000 = 25 M at M = 40, 10 reads a position: one chain
+        solver.solve(s, e, L, 40)
         assert solver.last_stats.sweep_stretches == 1
+        # many times M and yet SPARSE (M = 10: 2.5 reads a position at 25 x M) is shallow in standard deviations: the
+        # general pipeline with cut points, as below 11 x M (round 4) -- and the oracle's mask
+        s, e = _reads(rng, 1_000_000, L, span)
+        got = solver.solve(s, e, L, 10)
+        assert np.array_equal(got, oracle.solve(s, e, L, 10))
 
 
 # ---------------------------------------------------------------- mixed spans: the event sweeps
