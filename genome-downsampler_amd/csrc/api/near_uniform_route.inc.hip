@@ -21,7 +21,9 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                      (int)run.may_rank, ell, (int)qmcp::sweep_uniform_ev_supported(ell, M), depth, min_span, run.nu_filter);
     double min_depth = kNuMinDepth;
     if (c->opt.near_uniform_min_depth > 0.f) min_depth = c->opt.near_uniform_min_depth;  // (lab)
-    if (!run.may_rank || depth < min_depth || min_span == 0) return QMCP_OK;
+    // (the sigma depth where it is larger: M = 400 at 1.2 x M has as few cut points as M = 50 at 1.67 x M -- and the mixed-span
+    //  walk it was left to took 233 ms for 11.9 M reads on 3.7 M positions, 200 x the one-length solve: lab/cliff_hunt.py)
+    if (!run.may_rank || spec_depth_in_sigma(depth, M) < min_depth || min_span == 0) return QMCP_OK;
     // Which sweep the rounds run.  Deeper than 11 x M: one chain per contig in the event-driven form -- what the one-span
     // route runs there too -- restarted from its checkpoints.  Shallower (round 4): the block-scan pipeline in STRETCHES,
     // as the one-span route does -- real cut points (coverage of ALL reads <= M: every read over them is kept in every
@@ -129,7 +131,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                                               (const uint32_t*)c->nu_ce.p);
             n_seg_max = n_contigs + windows;
         }
-        speculate = spec_wanted(c, depth_gate) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
+        speculate = spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
         // (stretches two run-ins long instead of the one-span route's four: the route sweeps several times, and a sweep is
         //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> 0.24 ms a sweep; one run-in long: 0.37)
     }

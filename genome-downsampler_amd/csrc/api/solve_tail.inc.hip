@@ -267,7 +267,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
             //  matter more, and the second tier is there)
             uint32_t burn_blocks = c->opt.speculation_run_in ? spec_first_run_in(c, depth) : spec_first_run_in(c, depth) * 3u / 5u;
             bool hopeless = c->spec_hopeless_n == n64 && c->spec_hopeless_ltot == pr.ltot && c->spec_hopeless_M == M;
-            if (!hopeless && spec_wanted(c, depth_gate) && in_regs && seg != nullptr && n >= (1u << 20)) {
+            if (!hopeless && spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && in_regs && seg != nullptr && n >= (1u << 20)) {
                 // One dominant read length (what is left for this route once the shorter reads have their own: a few
                 // LONGER ones) forgets its state as slowly as one-length data, and the walk's boundaries then disagree
                 // nearly everywhere (lab/mixed_spec_check.py: 430 against 185 ms at 7.5 x M); a broad mix of lengths
@@ -308,7 +308,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                 }
             }
             if (c->opt.speculation != 0 || c->opt.speculation_run_in != 0) hopeless = false;
-            const bool speculate = !hopeless && spec_wanted(c, depth_gate) && in_regs && seg != nullptr && burn_blocks >= 2 &&
+            const bool speculate = !hopeless && spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && in_regs && seg != nullptr && burn_blocks >= 2 &&
                                    (uint64_t)ltot >= 4ull * burn_blocks * max_span;
             if (speculate) {
                 TRY(ensure(c, c->specsnap, qmcp::spec_snap_bytes(n_seg_max)));

@@ -31,8 +31,12 @@ constexpr double kSpecDepth = kGenDepth, kSpecMinDepth = 1.3;
 uint32_t spec_burn_blocks(double depth) {
     return depth < 2.1 ? 320u : depth < 2.6 ? 640u : depth < 3.1 ? 1152u : depth < 4.1 ? 2304u : 1536u;
 }
-bool spec_wanted(const qmcp_hip_ctx* c, double depth) {
-    bool on = depth < kSpecDepth && depth > kSpecMinDepth;  // (shallower: nearly every window has a real cut point)
+double spec_depth_in_sigma(double depth, uint32_t M);
+bool spec_wanted(const qmcp_hip_ctx* c, double depth, double depth_lo = -1.0 /* what the lower bound looks at: the sigma
+                 depth where it is larger -- "nearly every window has a real cut point" below 1.3 x M holds for M = 50, not
+                 for M = 400, whose 1.2 x M is as far above M in standard deviations as M = 50 at 1.67 x M */) {
+    if (depth_lo < 0.0) depth_lo = depth;
+    bool on = depth < kSpecDepth && depth_lo > kSpecMinDepth;  // (shallower: nearly every window has a real cut point)
     if (c->opt.speculation != 0) on = c->opt.speculation > 0;  // (never / at any depth)
     return on;
 }
@@ -159,7 +163,7 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
     // returns at once when all agreed).
     const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M));
-    const bool speculate = spec_wanted(c, depth_gate) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
+    const bool speculate = spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
                            burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);

@@ -97,9 +97,13 @@ def test_gives_way_to_the_mixed_route(pkg, oracle, solver):
     L = 40_000
     lengths = np.array([L], np.uint32)
     # (give-up reasons: include/qmcp_hip.h QMCP_NU_GIVEUP_*: 2 longer reads, 3 too many exceptions, 1 not tried)
-    for kwargs, M, n, why in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000, 2),
-                              (dict(fraction=0.2, max_clip=30), 100, 330_000, 3),
-                              (dict(fraction=0.01, max_clip=30), 400, 135_000, 1)):     # 1.27 x M
+    for kwargs, M, n, why, L in ((dict(fraction=0.01, max_clip=30, longer=5), 100, 330_000, 2, 40_000),
+                                 (dict(fraction=0.2, max_clip=30), 100, 330_000, 3, 40_000),
+                                 # 1.25 x M at M = 10: nearly every window has a real cut point (M = 400 at 1.27 x M, this
+                                 # case until round 4, is as far above M in standard deviations as M = 50 at 1.8 x M and
+                                 # takes the route now)
+                                 (dict(fraction=0.01, max_clip=30), 10, 250_000, 1, 3_000_000)):
+        lengths = np.array([L], np.uint32)
         s, e, _ = _contigs(rng, [L], [n], 150, **kwargs)
         got = solver.solve(s, e, lengths, M)
         assert np.array_equal(got, oracle.solve(s, e, lengths, M)), (kwargs, M, solver.last_stats.as_dict())
