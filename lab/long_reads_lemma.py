@@ -82,7 +82,15 @@ for case in range(cases):
                     if raw[t] >= 1 + above:
                         flips.append(i); break
         if not flips: break
-        for i in flips: P[i] = not P[i]
+        # of the members of P that are nowhere needed, only those go that no other such member of LOWER priority overlaps
+        # (coverage against window): a surplus of one over two overlapping members is the lower one's -- the greedy takes
+        # the larger end at a deficit -- and the other is looked at again in the next round
+        failing = [i for i in flips if P[i]]
+        for i in flips:
+            if P[i]:
+                lower = [j for j in failing if j != i and s[j] <= e[i] - ell and e[j] >= s[i] and (e[j], s[j], -j) < (e[i], s[i], -i)]
+                if lower: continue
+            P[i] = not P[i]
         if rounds > 60: break
     rounds_hist[rounds] = rounds_hist.get(rounds, 0) + 1
     # the dropped reads a bucket keeps are its last S(v) - c(v) ones: larger start first, then smaller index
