@@ -122,7 +122,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const uint32_t* seg = nullptr;
     uint32_t n_seg_max = 0, windows = 0;
     bool speculate = false;
-    const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M));
+    const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M)) * ((depth_gate != depth && !c->opt.speculation_run_in) ? 3u : 1u);  // (launch_uniform_sweep)
     if (stretches) {
         windows = sweep_cut_windows(c, ltot, ell, n_contigs, true);
         if (windows != 0) {

@@ -304,7 +304,7 @@ int enqueue_tail(qmcp_hip_ctx* c) {
                         for (uint32_t k = 0; k < n_contigs; ++k) longest = lengths[k] > longest ? lengths[k] : longest;
                         hopeless = (uint64_t)longest < 12ull * spec_first_run_in(c, d_run) * max_span;
                     }
-                    if (!hopeless) burn_blocks = spec_first_run_in(c, d_run);
+                    if (!hopeless) burn_blocks = spec_first_run_in(c, sparse_deep ? depth : d_run) * ((sparse_deep && !c->opt.speculation_run_in) ? 3u : 1u);  // (launch_uniform_sweep)
                 }
             }
             if (c->opt.speculation != 0 || c->opt.speculation_run_in != 0) hopeless = false;

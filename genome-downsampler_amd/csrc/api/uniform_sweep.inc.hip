@@ -162,7 +162,10 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     // run-in (every few windows, so that stretches stay several run-ins long); the stretches' outputs are compared where they
     // meet, and if any pair disagrees the exact sweep runs after all (its launch is there either way and
     // returns at once when all agreed).
-    const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M));
+    // (sparse and many times M: three times the table's run-in -- lab/sparse_deep_run_ins.py, boundaries that disagreed, first /
+    //  second tier, and sweep ms at 1 536 and at 4 608 blocks: M = 10 at 20 x M: 17 of 21 / 0, 7.2 -> 0 of 7, 5.4; M = 10 at
+    //  12 x M: 7 of 42 / 0, 7.3 -> 0 of 14, 5.5; M = 20 at 15 x M: 31 of 31 / 7 -- the exact sweep --, 53 -> 7 of 10 / 0, 21)
+    const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M)) * ((depth_gate != depth && !c->opt.speculation_run_in) ? 3u : 1u);
     const bool speculate = spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
                            burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {
