@@ -44,6 +44,10 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     const bool sparse = (double)n / (double)ltot < std::log((double)ell / 0.693);
     const double depth_gate = (depth >= kGenDepth && sparse && spec_sigma_depth(depth, M) < kGenDepth) ? spec_sigma_depth(depth, M) : depth;
     bool stretches = depth_gate < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth_gate < kNuStretchDepth || longest > 2000000u || !ev_ok);
+    // (deep data whose M does not fit a packed field of the event-driven form -- M = 200 at reads of 250 --: the block-scan
+    //  pipeline, one chain per contig, every round a whole sweep; contigs of up to 2 M positions -- 99.7 M reads on 24
+    //  contigs at 12 x M were 112 ms on the mixed-span walk against 2.7 with one length, lab/cliff_hunt.py)
+    if (depth_gate >= kGenDepth && !ev_ok && qmcp::sweep_uniform_mw_supported(ell) && longest <= 2000000u) stretches = true;
     if (c->opt.sweep == QMCP_SWEEP_EVENTS) stretches = false;
     if (c->opt.sweep == QMCP_SWEEP_GENERAL) stretches = qmcp::sweep_uniform_mw_supported(ell);
     if (!stretches) {
