@@ -43,7 +43,9 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     //  launch_uniform_sweep.  66 M reads on one contig of 82.6 M positions at 12 x M with M = 10, 1 % clipped: 3.2 s in chains.)
     const bool sparse = (double)n / (double)ltot < std::log((double)ell / 0.693);
     const double depth_gate = (depth >= kGenDepth && sparse && spec_sigma_depth(depth, M) < kGenDepth) ? spec_sigma_depth(depth, M) : depth;
-    bool stretches = depth_gate < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth_gate < kNuStretchDepth || longest > 2000000u || !ev_ok);
+    // (sparse data -- more than half of the blocks hold a position without a read -- makes the chain run its general step on
+    //  nearly every block: 551 k reads on 1 M positions at 4 x M with M = 20, 1 % clipped: 36.7 ms in chains, lab/cliff_hunt.py)
+    bool stretches = depth_gate < kGenDepth && qmcp::sweep_uniform_mw_supported(ell) && (depth_gate < kNuStretchDepth || longest > 2000000u || !ev_ok || sparse);
     // (deep data whose M does not fit a packed field of the event-driven form -- M = 200 at reads of 250 --: the block-scan
     //  pipeline, one chain per contig, every round a whole sweep; contigs of up to 2 M positions -- 99.7 M reads on 24
     //  contigs at 12 x M were 112 ms on the mixed-span walk against 2.7 with one length, lab/cliff_hunt.py)
