@@ -137,7 +137,8 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
                                               (const uint32_t*)c->nu_ce.p);
             n_seg_max = n_contigs + windows;
         }
-        speculate = spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
+        const double sig = spec_depth_in_sigma(depth, M);
+        speculate = spec_wanted(c, depth_gate != depth ? depth_gate : (sig > depth ? sig * (kSpecDepth / 9.0) : depth), spec_depth_in_sigma(depth_gate, M)) && windows != 0 && burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * ell;
         // (stretches two run-ins long instead of the one-span route's four: the route sweeps several times, and a sweep is
         //  as long as its longest stretch -- two 10^7-position contigs at 1.5 x M: 0.43 -> 0.24 ms a sweep; one run-in long: 0.37)
     }

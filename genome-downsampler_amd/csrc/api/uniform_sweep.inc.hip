@@ -166,7 +166,13 @@ int launch_uniform_sweep(qmcp_hip_ctx* c, hipStream_t st, uint32_t n, uint32_t l
     //  second tier, and sweep ms at 1 536 and at 4 608 blocks: M = 10 at 20 x M: 17 of 21 / 0, 7.2 -> 0 of 7, 5.4; M = 10 at
     //  12 x M: 7 of 42 / 0, 7.3 -> 0 of 14, 5.5; M = 20 at 15 x M: 31 of 31 / 7 -- the exact sweep --, 53 -> 7 of 10 / 0, 21)
     const uint32_t burn_blocks = spec_first_run_in(c, spec_depth_in_sigma(depth, M)) * ((depth_gate != depth && !c->opt.speculation_run_in) ? 3u : 1u);
-    const bool speculate = spec_wanted(c, depth_gate, spec_depth_in_sigma(depth_gate, M)) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
+    // (the upper bound in standard deviations too where that is the larger -- lab/spec_run_in_large_M.py, one contig of 20 M
+    //  positions: M = 400 at 3 x M and M = 200 at 4 x M, sigma depths 12.6 and 11.5, do not forget within the contig at any
+    //  run-in up to 9 216 blocks: 42 ms with the tiers against 35 as one chain; M = 400 at 2 x M, 5.4: 10.5 against 34)
+    // (a sigma depth beyond the raw one counts a little more: 10.9 -- M = 200 at 4 x M -- behaves as 11.5 and 12.6 do)
+    const double sig = spec_depth_in_sigma(depth, M);
+    const double depth_hi = depth_gate != depth ? depth_gate : (sig > depth ? sig * (kSpecDepth / 9.0) : depth);
+    const bool speculate = spec_wanted(c, depth_hi, spec_depth_in_sigma(depth_gate, M)) && gen && windows != 0 && qmcp::sweep_uniform_mw_supported(span) &&
                            burn_blocks >= 2 && (uint64_t)ltot >= 8ull * burn_blocks * span;
     if (windows != 0) {
         KernelSpan sp(c, "k_find_cuts", st);
