@@ -23,7 +23,7 @@ int near_uniform_tail(qmcp_hip_ctx* c, uint32_t min_span, uint32_t max_span, uin
     if (c->opt.near_uniform_min_depth > 0.f) min_depth = c->opt.near_uniform_min_depth;  // (lab)
     // (the sigma depth where it is larger: M = 400 at 1.2 x M has as few cut points as M = 50 at 1.67 x M -- and the mixed-span
     //  walk it was left to took 233 ms for 11.9 M reads on 3.7 M positions, 200 x the one-length solve: lab/cliff_hunt.py)
-    if (!run.may_rank || spec_depth_in_sigma(depth, M) < min_depth || min_span == 0) return QMCP_OK;
+    if (!run.may_rank || spec_sigma_depth(depth, M) < min_depth || min_span == 0) return QMCP_OK;
     // Which sweep the rounds run.  Deeper than 11 x M: one chain per contig in the event-driven form -- what the one-span
     // route runs there too -- restarted from its checkpoints.  Shallower (round 4): the block-scan pipeline in STRETCHES,
     // as the one-span route does -- real cut points (coverage of ALL reads <= M: every read over them is kept in every

@@ -26,7 +26,13 @@ uint32_t nu_round_budget(const qmcp_hip_ctx* c, const uint32_t* lengths, uint32_
 // 5 x M 12.4 / 579; 3 x M 15.7 / 710; 2.1 x M: gives up after four sweeps, 648 / 627 -- runs of used-up buckets with
 // neither an anchor nor a cut point --; 1.5 x M 41.9 / 600, from cut points).  Below 1.3 x M nearly every window of the
 // mixed-span sweep has a real cut point and that sweep is quick.
-constexpr double kNuMinDepth = 1.3;
+// Second half of round 4: the gate is the SIGMA depth (spec_sigma_depth: how far above M the coverage sits, as the depth at
+// which M = 50 sits as far), and the crossover with the mixed-span walk -- which real cut points make quick where the
+// coverage comes near M often -- was measured (lab/near_uniform_long_shallow.py, two contigs of 40 M positions, 1 % clipped,
+// near-uniform / mixed-span ms by sigma depth): 1.24 (M = 20 at 1.4 x M) 18.9 / 7.3; 1.30 (30, 1.4) 23.4 / 10.0; 1.35 (20,
+// 1.6) 14.1 / 7.9; 1.37 (10, 2.0) 8.9 / 5.6; 1.40 (50, 1.4) 24.1 / 17.3; 1.44 (30, 1.6) 15.9 / 13.7 | 1.56 (20, 2.0) 10.4 /
+// 16.1; 1.60 (50, 1.6) 16.7 / 33.9; 1.67 (10, 3.0) 10.0 / 22.3; 1.72 (30, 2.0) 12.5 / 22.7 -- the route is tried from 1.5.
+constexpr double kNuMinDepth = 1.5;
 // marks per stretch of a table: contig starts + at most kSweepWindowsOneSpan windows (a fixed 4 096 until round 4: a call of
 // more than 3 328 contigs would have cleared past its array)
 uint32_t nu_marks_words(uint32_t n_contigs) { return n_contigs + qmcp::kSweepWindowsOneSpan + 256u; }

@@ -11,7 +11,7 @@ import torch
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 depth = float(sys.argv[2]) if len(sys.argv) > 2 else 1.5
 frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.01
-M = 100
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 pairs = int(depth * M * L / 150 / 2)
 ss, ee = [], []
 for c in range(2):

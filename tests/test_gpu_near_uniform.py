@@ -316,7 +316,7 @@ def test_partial_rounds_with_boundaries_that_disagree(pkg, oracle, solver, run_i
     stretch), and the mask is still the oracle's"""
     rng = np.random.default_rng(1000 + run_in)
     lengths = np.array([3_000_000, 2_000_000], np.uint32)
-    counts = [int(1.8 * 20 * int(x) / 150) for x in lengths]
+    counts = [int(2.2 * 20 * int(x) / 150) for x in lengths]   # (a sigma depth of 1.66: the route is tried from 1.5)
     s, e, offs = _contigs(rng, lengths, counts, 150, 0.01, 50)
     with solver.options(speculation=1, speculation_run_in=run_in):
         got = solver.solve(s, e, lengths, 20, contig_read_offsets=offs)
