@@ -151,7 +151,8 @@ typedef struct qmcp_hip_options {
     uint32_t speculation_run_in;  /* blocks of run-in of the first tier (QMCP_HIP_SPEC_BURN)                              */
     int32_t near_uniform;         /* near-uniform route: -1 off (QMCP_HIP_NEAR=0)                                         */
     uint32_t near_uniform_rounds; /* its budget of rounds (QMCP_HIP_NEAR_ROUNDS)                                          */
-    float near_uniform_min_depth; /* mean coverage / M below which it is not tried (QMCP_HIP_NEAR_MIN_DEPTH)              */
+    float near_uniform_min_depth; /* sigma depth below which it is not tried (default 1.5: DESIGN.md 4.1; the mean coverage in
+                                     units of M where M = 50) (QMCP_HIP_NEAR_MIN_DEPTH)                                  */
     int32_t near_uniform_debug;   /* 1: what every pair of rounds did, to stderr (QMCP_HIP_NEAR_DEBUG); 2 (lab): the rounds
                                      after the first sweep every stretch again, not only those a selection reaches     */
     int32_t force_sort_route;     /* 1: the keep mask from the radix sort even where the ranked route applies
